@@ -1,0 +1,307 @@
+"""Generate golden fixtures by running the REFERENCE in the build container.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Run from the repo root:
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [--ref /root/reference] [--out tests/golden]
+
+It imports the reference package (never copied into this repo, never present on the GPU box), builds seeded
+tiny models / per-op cases, and stores inputs, state_dicts, outputs and gradients as ``*.safetensors`` (tensor
+data only).  ``torch.__version__`` and the thread count are recorded in each file's metadata.
+"""
+
+import argparse
+import os
+import sys
+
+import torch
+from safetensors.torch import save_file
+
+SEED = 123
+
+
+def _save(path, tensors, note):
+    flat = {k: v.detach().clone().contiguous() for k, v in tensors.items()}
+    meta = {"torch": torch.__version__, "threads": str(torch.get_num_threads()), "note": note}
+    save_file(flat, path, metadata=meta)
+    kb = os.path.getsize(path) / 1024
+    print(f"wrote {path} ({kb:.0f} KiB, {len(flat)} tensors)")
+
+
+def _sd(model, prefix="sd."):
+    return {prefix + k: v for k, v in model.state_dict().items() if k != "mask"}
+
+
+def _grads(model, prefix="grad."):
+    return {prefix + n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+
+
+TINY_QWEN = dict(
+    vocab_size=512, emb_dim=128, n_layers=2, n_heads=4, num_kv_groups=2, head_dim=128, hidden_dim=256,
+    context_length=64, rope_base=1_000_000, dtype=torch.bfloat16, tie_embeddings=True,
+)
+TINY_VIT = dict(
+    img_width=32, img_height=32, patch_size=8, num_channels=3, emb_dim=64, n_layers=2, n_heads=1,
+    drop_rate=0.0, qkv_bias=True, num_classes=10,
+)
+TINY_GPT = dict(vocab_size=256, context_length=32, emb_dim=64, n_heads=2, n_layers=2, drop_rate=0.0, qkv_bias=True)
+
+
+def gen_index(out):
+    from llm_quest.common.buffers import GlobalBuffers
+    from llm_quest.multimodal.vision_transformer.vit_model import PatchEmbedding2D
+    from llm_quest.multimodal.vlm_engine import vlm_loss
+
+    t = {}
+    # patch order: identity projection turns PatchEmbedding2D into a pure gather of the arange image
+    for name, (hw, p) in {"p32_4": (32, 4), "p224_16": (224, 16)}.items():
+        k = 3 * p * p
+        pe = PatchEmbedding2D(hw, hw, p, 3, k)
+        with torch.no_grad():
+            pe.conv_proj.weight.copy_(torch.eye(k).view(k, 3, p, p))
+            pe.conv_proj.bias.zero_()
+            pe.cls_token.zero_()
+            img = torch.arange(3 * hw * hw, dtype=torch.float32).view(1, 3, hw, hw)
+            t[f"patch_gather.{name}"] = pe(img)[0, 1:].to(torch.int32)  # (num_patches, K) source offsets
+    # early-fusion cat + mask + label shift (vlm_engine.py:111-119, 36-39)
+    vis = torch.arange(2 * 3 * 4, dtype=torch.float32).view(2, 3, 4)
+    txt = 1000 + torch.arange(2 * 5 * 4, dtype=torch.float32).view(2, 5, 4)
+    t["fusion.vis"], t["fusion.txt"] = vis, txt
+    t["fusion.cat"] = torch.cat([vis, txt], dim=1)
+    tm = torch.tensor([[1, 1, 1, 0, 0], [1, 1, 1, 1, 1]], dtype=torch.bool)
+    t["fusion.text_mask"] = tm.to(torch.uint8)
+    t["fusion.mask"] = torch.cat([torch.ones(2, 3, dtype=torch.bool), tm], dim=1).to(torch.uint8)
+    torch.manual_seed(SEED)
+    logits = torch.randn(2, 8, 11)
+    ids = torch.randint(0, 11, (2, 5))
+    t["vlm_loss.logits"], t["vlm_loss.ids"] = logits, ids
+    t["vlm_loss.loss"] = vlm_loss(logits, ids, tm, 3)
+    t["vlm_loss.labels"] = ids.masked_fill(tm == 0, -100)
+    # causal mask, GQA head map
+    t["causal_mask.8"] = GlobalBuffers.get_causal_mask(8).to(torch.uint8)
+    kv = torch.arange(2 * 3 * 1 * 1).view(1, 3, 2, 1).float()  # (b, kv_heads=3, s=2, d=1)
+    t["gqa.repeat_interleave"] = kv.repeat_interleave(2, dim=1)[0, :, 0, 0].to(torch.int32) // 2  # kv head per q head
+    _save(os.path.join(out, "index_ops.safetensors"), t, "bit-exact index/gather fixtures")
+
+
+def gen_ops(out):
+    from llm_quest.common.buffers import GlobalBuffers
+    from llm_quest.common.rope import RoPE
+    from llm_quest.engine import LearningRateScheduler
+    from llm_quest.multimodal.vision_transformer.vit_transformer_block import GELU, LayerNorm
+    from llm_quest.qwen.qwen3.qwen3_attention import GroupedQueryAttention, PytorchRMSNorm
+    from llm_quest.qwen.qwen3.qwen3_transformer_block import FFN
+
+    t = {}
+    torch.manual_seed(SEED)
+    for width in (1024, 128):
+        n = PytorchRMSNorm(width, dtype=torch.bfloat16)
+        with torch.no_grad():
+            n.weight.copy_(1 + 0.1 * torch.randn(width))
+        x = (torch.randn(6, width) * 1.7).to(torch.bfloat16).requires_grad_(True)
+        y = n(x)
+        g = torch.randn_like(y)
+        y.backward(g)
+        t[f"rmsnorm.{width}.x"], t[f"rmsnorm.{width}.w"], t[f"rmsnorm.{width}.y"] = x, n.weight, y
+        t[f"rmsnorm.{width}.gy"], t[f"rmsnorm.{width}.gx"], t[f"rmsnorm.{width}.gw"] = g, x.grad, n.weight.grad
+    # RoPE tables + apply (bf16), with and without position_ids
+    cos, sin = RoPE.compute_angles(base=1_000_000, head_dim=128, ctx_len=96)
+    t["rope.cos"], t["rope.sin"] = cos, sin
+    x = torch.randn(2, 4, 64, 128).to(torch.bfloat16)
+    t["rope.x"] = x
+    t["rope.y"] = RoPE.apply(x, cos, sin)
+    pid = torch.randint(0, 96, (2, 64))
+    t["rope.pid"] = pid
+    t["rope.y_pid"] = RoPE.apply(x, cos, sin, pid)
+    # LayerNorm (sigma + eps), GELU erf
+    ln = LayerNorm(768)
+    with torch.no_grad():
+        ln.scale.copy_(1 + 0.1 * torch.randn(768))
+        ln.shift.copy_(0.1 * torch.randn(768))
+    x = torch.randn(5, 768, requires_grad=True)
+    y = ln(x)
+    g = torch.randn_like(y)
+    y.backward(g)
+    t["layernorm.x"], t["layernorm.scale"], t["layernorm.shift"], t["layernorm.y"] = x, ln.scale, ln.shift, y
+    t["layernorm.gy"], t["layernorm.gx"] = g, x.grad
+    t["layernorm.gscale"], t["layernorm.gshift"] = ln.scale.grad, ln.shift.grad
+    x = torch.randn(4, 256) * 2
+    t["gelu.x"], t["gelu.y"] = x, GELU()(x)
+    # SwiGLU FFN bf16
+    ffn = FFN({"emb_dim": 128, "hidden_dim": 256, "dtype": torch.bfloat16})
+    x = torch.randn(3, 7, 128).to(torch.bfloat16)
+    t["swiglu.x"], t["swiglu.y"] = x, ffn(x)
+    t["swiglu.w1"], t["swiglu.wg"], t["swiglu.w2"] = ffn.lin1.weight, ffn.lin_gate.weight, ffn.lin2.weight
+    # GQA module, real head width, with a right-padded key mask, bf16
+    att = GroupedQueryAttention(d_in=128, num_heads=4, num_kv_groups=2, head_dim=128, dtype=torch.bfloat16)
+    with torch.no_grad():
+        att.q_norm.weight.copy_(1 + 0.1 * torch.randn(128))
+        att.k_norm.weight.copy_(1 + 0.1 * torch.randn(128))
+    x = torch.randn(2, 40, 128).to(torch.bfloat16)
+    km = torch.ones(2, 40, dtype=torch.bool)
+    km[0, 29:] = False
+    mask = GlobalBuffers.get_causal_mask(96)
+    t["gqa.x"], t["gqa.key_mask"] = x, km.to(torch.uint8)
+    t["gqa.y"] = att(x, mask, cos, sin, km)
+    t["gqa.y_nomask"] = att(x, mask, cos, sin)
+    for k_, v_ in att.state_dict().items():
+        t["gqa.sd." + k_] = v_
+    # upstream __main__ known-answer block of qwen3_attention.py:154-185 (seed 123, fp32 toy)
+    torch.manual_seed(SEED)
+    toy = torch.tensor(
+        [[0.43, 0.15, 0.89, 0.15, 0.15], [0.55, 0.87, 0.66, 0.87, 0.87], [0.57, 0.85, 0.64, 0.85, 0.85],
+         [0.22, 0.58, 0.33, 0.58, 0.58], [0.77, 0.25, 0.10, 0.25, 0.25], [0.05, 0.80, 0.55, 0.80, 0.80]]
+    )
+    xb = torch.stack((toy, toy), dim=0)
+    m6 = GlobalBuffers.get_causal_mask(6)
+    c2, s2 = GlobalBuffers.get_rope_params(6, 10_000, 2)
+    toy_att = GroupedQueryAttention(d_in=5, head_dim=2, num_heads=6, num_kv_groups=2)
+    t["gqa_toy.x"], t["gqa_toy.y"] = xb, toy_att(xb, m6, c2, s2)
+    for k_, v_ in toy_att.state_dict().items():
+        t["gqa_toy.sd." + k_] = v_
+    # cross-entropy with ignore_index on bf16 logits
+    lg = (torch.randn(12, 512) * 3).to(torch.bfloat16).requires_grad_(True)
+    tg = torch.randint(0, 512, (12,))
+    tg[[2, 7]] = -100
+    loss = torch.nn.functional.cross_entropy(lg, tg, ignore_index=-100)
+    loss.backward()
+    t["ce.logits"], t["ce.targets"], t["ce.loss"], t["ce.glogits"] = lg, tg, loss, lg.grad
+    # LR scheduler trace
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+    sch = LearningRateScheduler(opt, total_steps=10, init_lr=1e-5, peak_lr=1e-3, warmup_steps=3, min_lr=1e-4, decay="cosine")
+    trace = []
+    for s in range(10):
+        sch.step(s)
+        trace.append(sch.current_lr)
+    t["lr.trace"] = torch.tensor(trace, dtype=torch.float64)
+    _save(os.path.join(out, "per_op.safetensors"), t, "per-op numeric fixtures")
+
+
+def gen_qwen(out):
+    from llm_quest.engine import global_loss
+    from llm_quest.qwen.qwen3.qwen3_model import Qwen3Model
+
+    torch.manual_seed(SEED)
+    m = Qwen3Model(dict(TINY_QWEN)).train()
+    ids = torch.randint(0, 512, (2, 24))
+    tgt = torch.randint(0, 512, (2, 24))
+    km = torch.ones(2, 24, dtype=torch.bool)
+    km[1, 17:] = False
+    t = _sd(m)
+    t["in.ids"], t["in.targets"], t["in.key_mask"] = ids, tgt, km.to(torch.uint8)
+    logits = m(ids, attn_mask=km)
+    loss = global_loss(logits, tgt, model=m)
+    loss.backward()
+    t["out.logits"], t["out.loss"] = logits, loss
+    t.update(_grads(m))
+    m.zero_grad()
+    t["out.logits_nomask"] = m(ids)
+    # fp32 twin: same weights upcast
+    cfg32 = dict(TINY_QWEN, dtype=torch.float32)
+    m32 = Qwen3Model(cfg32).train()
+    m32.load_state_dict({k: (v.float() if v.is_floating_point() else v) for k, v in m.state_dict().items()})
+    lg32 = m32(ids, attn_mask=km)
+    l32 = global_loss(lg32, tgt, model=m32)
+    l32.backward()
+    t["twin.logits"], t["twin.loss"] = lg32, l32
+    t["twin.grad.emb_dict.weight"] = m32.emb_dict.weight.grad
+    t["twin.grad.trf_blocks.0.att.w_queries.weight"] = m32.trf_blocks[0].att.w_queries.weight.grad
+    t["twin.grad.trf_blocks.1.ffn.lin2.weight"] = m32.trf_blocks[1].ffn.lin2.weight.grad
+    _save(os.path.join(out, "qwen3_tiny.safetensors"), t, "tiny Qwen3 dense, bf16 + fp32 twin outputs")
+
+
+def gen_vit(out):
+    from llm_quest.multimodal.vision_transformer.vit_model import ViTModel
+
+    torch.manual_seed(SEED)
+    m = ViTModel(dict(TINY_VIT)).train()
+    img = torch.randn(3, 3, 32, 32)
+    y = torch.randint(0, 10, (3,))
+    t = _sd(m)
+    t["in.image"], t["in.labels"] = img, y
+    logits = m(img)
+    loss = torch.nn.functional.cross_entropy(logits, y)
+    loss.backward()
+    t["out.logits"], t["out.loss"] = logits, loss
+    t["out.hidden"] = m(img, output_hidden_states=True)
+    t.update(_grads(m))
+    _save(os.path.join(out, "vit_tiny.safetensors"), t, "tiny ViT fp32, drop_rate 0")
+
+
+def gen_vlm(out):
+    from llm_quest.multimodal.vision_transformer.vit_engine import ViTAdapter
+    from llm_quest.multimodal.vision_transformer.vit_model import ViTModel
+    from llm_quest.multimodal.vlm_engine import vlm_loss
+    from llm_quest.qwen.qwen3.qwen3_model import Qwen3Model
+
+    torch.manual_seed(SEED)
+    vit = ViTModel(dict(TINY_VIT)).eval()
+    for p in vit.parameters():
+        p.requires_grad = False
+    llm = Qwen3Model(dict(TINY_QWEN)).train()
+    ad = ViTAdapter(64, 128, adapter_type="ffn", dtype=torch.bfloat16).train()
+    img = torch.randn(2, 3, 32, 32)
+    ids = torch.randint(0, 512, (2, 20))
+    tm = torch.ones(2, 20, dtype=torch.bool)
+    tm[0, 13:] = False
+    # composition harness of SURVEY.md section 8c over the reference's public attributes
+    h = vit(img, output_hidden_states=True)
+    ve = ad(h.to(torch.bfloat16))
+    te = llm.emb_dict(ids)
+    x = torch.cat([ve, te], dim=1)
+    nv = ve.shape[1]
+    cm = torch.cat([torch.ones(2, nv, dtype=torch.bool), tm], dim=1)
+    fused = x
+    for blk in llm.trf_blocks:
+        x = blk(x, llm.mask, llm.cos, llm.sin, cm, None, None)
+    logits = llm.out_head(llm.final_norm(x))
+    loss = vlm_loss(logits, ids, tm, nv)
+    loss.backward()
+    t = {}
+    t.update(_sd(vit, "vit."))
+    t.update(_sd(llm, "llm."))
+    t.update(_sd(ad, "ad."))
+    t["in.image"], t["in.ids"], t["in.text_mask"] = img, ids, tm.to(torch.uint8)
+    t["out.vit_hidden"], t["out.fused"], t["out.logits"], t["out.loss"] = h, fused, logits, loss
+    t.update(_grads(llm, "grad.llm."))
+    t.update(_grads(ad, "grad.ad."))
+    # simple-adapter variant forward only
+    ad2 = ViTAdapter(64, 128, adapter_type="simple", dtype=torch.bfloat16)
+    t["ad_simple.weight"] = ad2.adapter.weight
+    t["ad_simple.out"] = ad2(h.to(torch.bfloat16))
+    _save(os.path.join(out, "vlm_tiny.safetensors"), t, "composed ViT+adapter+Qwen3 early-fusion step (config 4 harness)")
+
+
+def gen_gpt(out):
+    from llm_quest.gpt.gpt_model import GPTModel
+
+    torch.manual_seed(SEED)
+    m = GPTModel(dict(TINY_GPT)).eval()
+    ids = torch.randint(0, 256, (4, 16))
+    km = torch.ones(4, 16, dtype=torch.bool)
+    km[2, 11:] = False
+    t = _sd(m)
+    t = {k: v for k, v in t.items() if not k.endswith(".mask")}
+    t["in.ids"], t["in.key_mask"] = ids, km.to(torch.uint8)
+    with torch.no_grad():
+        t["out.logits"] = m(ids)
+        t["out.logits_masked"] = m(ids, attn_mask=km)
+        emb = m.emb_dict(ids) + m.pos_emb_dict(torch.arange(16))
+        t["out.logits_embedded"] = m(emb, input_embedded=True)
+    _save(os.path.join(out, "gpt2_tiny.safetensors"), t, "tiny GPT-2 forward (config-1 plumbing)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    args = ap.parse_args()
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, args.ref)
+    os.makedirs(args.out, exist_ok=True)
+    torch.set_num_threads(8)
+    for fn in (gen_index, gen_ops, gen_qwen, gen_vit, gen_vlm, gen_gpt):
+        fn(args.out)
+
+
+if __name__ == "__main__":
+    main()
