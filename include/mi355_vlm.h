@@ -1,0 +1,147 @@
+/*
+ * mi355_vlm.h -- C ABI of libmi355vlm.so: hand-written gfx950 (MI355X / CDNA4) HIP kernels for the
+ * LLM-quest VLM forward/backward hot path.
+ *
+ * The reference (casinca/LLM-quest) has NO native/FFI layer: every op is a stock torch call inside an
+ * nn.Module.forward.  Each entry point below therefore cites the reference *call site*
+ * it replaces (file:line relative to the reference checkout); the binding a maintainer adds on the reference
+ * side is a ctypes stub, shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers are DEVICE pointers (HBM) unless stated; sizes are element counts unless "_bytes"
+ *   - bf16 tensors are passed as `const void*` / `void*` (2 bytes per element, round-to-nearest-even)
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); all calls are asynchronous on it
+ *   - no allocation, no synchronisation, no global state inside any entry point (graph-capture safe)
+ *   - return 0 on success; non-zero = error, text via mi355_last_error() (thread-local)
+ *   - row-major everywhere; "ld" = leading dimension in elements
+ */
+#ifndef MI355_VLM_H
+#define MI355_VLM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_DT_BF16 0
+#define MI355_DT_F32 1
+
+/* GEMM operand forms (all row-major storage):
+ *   NT: C[m,n] = sum_k A[m,k] * B[n,k]   (A: MxK, B: NxK)  -- y = x W^T, nn.Linear forward
+ *   NN: C[m,n] = sum_k A[m,k] * B[k,n]   (A: MxK, B: KxN)  -- dx = dy W,   nn.Linear dgrad
+ *   TN: C[m,n] = sum_k A[k,m] * B[k,n]   (A: KxM, B: KxN)  -- dW = dy^T x, nn.Linear wgrad            */
+#define MI355_GEMM_NT 0
+#define MI355_GEMM_NN 1
+#define MI355_GEMM_TN 2
+
+/* epilogue flags */
+#define MI355_EPI_NONE 0
+#define MI355_EPI_GELU_ERF 1 /* out = gelu(acc + bias) (applied before the residual add) */
+
+const char* mi355_last_error(void);
+int mi355_abi_version(void);
+
+/* bf16 x bf16 -> fp32-accumulate MFMA GEMM with fused epilogue:
+ *   C = epi(acc + bias[n]) + residual[m,n]
+ * Replaces F.linear / nn.Linear (+ bias, + GELU, + residual add) at qwen3_attention.py:91-93,148,
+ * qwen3_transformer_block.py:48-53, vit_attention.py:59-61,88, vit_transformer_block.py:59-67,
+ * vit_engine.py:43-53, qwen3_model.py:92 and their autograd backward.
+ *   out_dtype    MI355_DT_BF16 | MI355_DT_F32 (dtype of C and of `residual`)
+ *   bias         fp32 [N] or NULL;  residual  [M,N] with ldr, or NULL (may alias C: accumulate)
+ * Requirements: K-contiguous dims multiple of 8 elements (16-byte rows); see DESIGN.md.            */
+int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                    int64_t ldb, void* C, int64_t ldc, int out_dtype, const float* bias, const void* residual,
+                    int64_t ldr, int epilogue, void* stream);
+
+/* column sums: out[n] (+)= sum_m X[m,n]  (bias gradients).  X bf16 [M,N] ld=ldx, out fp32 [N]. */
+int mi355_colsum_bf16(int64_t M, int64_t N, const void* X, int64_t ldx, float* out, int accumulate, void* stream);
+
+/* RMSNorm, fp32 math, rows of `width` (PytorchRMSNorm, qwen3_attention.py:19-29): y = x*rsqrt(mean(x^2)+eps)*w.
+ * x,y,w bf16; rstd fp32 [rows] saved for backward. */
+int mi355_rmsnorm_fwd(int64_t rows, int width, const void* x, const void* w, void* y, float* rstd, float eps,
+                      void* stream);
+/* dx = rstd*(w*dy - xhat*mean(w*dy*xhat)) (+ dres if given); dw_partial fp32 [parts, width] (sum over parts
+ * done by mi355_reduce_rows_f32). */
+int mi355_rmsnorm_bwd(int64_t rows, int width, const void* x, const void* w, const float* rstd, const void* dy,
+                      const void* dres, void* dx, float* dw_partial, int parts, void* stream);
+/* out_bf16[n] (+)= sum_p partial[p,n] */
+int mi355_reduce_rows_f32(int parts, int64_t n, const float* partial, void* out, int out_dtype, int accumulate,
+                          void* stream);
+
+/* Fused per-head QK-RMSNorm + RoPE on the token-major QKV projection (qwen3_attention.py:99-115,
+ * common/rope.py:180-243).  qkv bf16 [tokens, (Hq+2Hkv)*D] (q heads, then k heads, then v heads);
+ * writes q_out [tokens,Hq*D], k_out [tokens,Hkv*D] bf16 and rstd fp32 [tokens, Hq+Hkv].
+ * cos/sin fp32 [ctx, D] (cast to bf16 before use, as the reference does); pos int32 [tokens] = row of cos/sin. */
+int mi355_qknorm_rope_fwd(int64_t tokens, int Hq, int Hkv, int D, const void* qkv, const void* qw, const void* kw,
+                          const float* cos, const float* sin, const int32_t* pos, void* q_out, void* k_out,
+                          float* rstd, float eps, void* stream);
+/* backward: dq,dk (post-RoPE grads) -> d(qkv)[:, :Hq*D + Hkv*D] written into dqkv (v part untouched);
+ * weight-grad partials fp32 [parts, 2*D] (q then k). */
+int mi355_qknorm_rope_bwd(int64_t tokens, int Hq, int Hkv, int D, const void* qkv, const void* qw, const void* kw,
+                          const float* cos, const float* sin, const int32_t* pos, const float* rstd,
+                          const void* dq, const void* dk, void* dqkv, float* dw_partial, int parts, void* stream);
+
+/* SwiGLU (qwen3_transformer_block.py:48-53): gu bf16 [tokens, 2*F] = [lin1 | lin_gate]; a = lin1*silu(gate). */
+int mi355_swiglu_fwd(int64_t tokens, int F, const void* gu, void* a, void* stream);
+int mi355_swiglu_bwd(int64_t tokens, int F, const void* gu, const void* da, void* dgu, void* stream);
+
+/* Flash-style attention, token-major operands, never materialising SxS (replaces qwen3_attention.py:121-146,
+ * vit_attention.py:74-86).  q [B*S, Hq*D] ld=ldq, k/v [B*S, Hkv*D] ld=ldk/ldv, o [B*S, Hq*D] ld=ldo, bf16;
+ * lse fp32 [B,Hq,S] (natural-log-sum-exp of scaled, masked scores).  D in {64,128}.
+ * causal: key j visible to query i iff j<=i.  key_mask uint8 [B,S] (1 = real token) or NULL.
+ * Masked scores take the reference's finite fill value (finfo(bf16).min/2), not -inf. */
+int mi355_attn_fwd(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk,
+                   const void* v, int64_t ldv, void* o, int64_t ldo, float* lse, const uint8_t* key_mask,
+                   int causal, float scale, void* stream);
+/* delta fp32 [B,Hq,S] workspace; dq/dk/dv token-major like q/k/v. */
+int mi355_attn_bwd(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk,
+                   const void* v, int64_t ldv, const void* o, int64_t ldo, const void* d_o, int64_t lddo,
+                   const float* lse, float* delta, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv,
+                   int64_t lddv, const uint8_t* key_mask, int causal, float scale, void* stream);
+
+/* Row-wise cross entropy on bf16 logits with ignore_index=-100 (engine.py:45,60; vlm_engine.py:39).
+ * logits [rows, V] ld=ldl.  loss_rows fp32 [rows] (0 for ignored).  If dlogits != NULL writes
+ * (softmax - onehot) * (*grad_scale) (0 for ignored rows) as bf16 (may alias logits: in place). */
+int mi355_cross_entropy(int64_t rows, int64_t V, const void* logits, int64_t ldl, const int64_t* targets,
+                        float* loss_rows, void* dlogits, const float* grad_scale, void* stream);
+/* out[0] = sum(loss_rows)/count, out[1] = count, out[2] = 1/count  (count = #targets != -100) */
+int mi355_ce_finalize(int64_t rows, const float* loss_rows, const int64_t* targets, float* out3, void* stream);
+
+/* Embedding gather (qwen3_model.py:69): out[t,:] = table[ids[t],:]; bit-exact copy. */
+int mi355_embedding_fwd(int64_t tokens, int width, int64_t vocab, const int64_t* ids, const void* table, void* out,
+                        int64_t ldo, void* stream);
+/* scatter-add of token grads into an fp32 accumulator [vocab,width] */
+int mi355_embedding_bwd(int64_t tokens, int width, int64_t vocab, const int64_t* ids, const void* dout, int64_t ldd,
+                        float* dtable_f32, void* stream);
+
+/* Strided 2-D copy (early-fusion concat, vlm_engine.py:114; logits/hidden row slicing): bit-exact.
+ * dst[r, 0:width] = src[r, 0:width] for r in [0, rows), element size elem_bytes. */
+int mi355_copy2d(int64_t rows, int64_t width_bytes, const void* src, int64_t src_pitch_bytes, void* dst,
+                 int64_t dst_pitch_bytes, void* stream);
+
+/* im2row patch gather for Conv2d(k=s=P) (vit_model.py:50-57,77-84): img fp32 NCHW -> rows bf16 or fp32
+ * [B*gh*gw, C*P*P] with K ordered (c,i,j); patches row-major over (ph,pw). */
+int mi355_patchify(int B, int C, int H, int W, int P, const float* img, void* rows, int out_dtype, void* stream);
+
+/* ViT LayerNorm with eps added to sigma (vit_transformer_block.py:12-31): x fp32 [rows,width];
+ * y bf16 or fp32; saves mean/rsig fp32 [rows] if non-NULL. */
+int mi355_layernorm_fwd(int64_t rows, int width, const float* x, const float* scale, const float* shift, void* y,
+                        int y_dtype, float* mean, float* rsig, float eps, void* stream);
+
+/* dtype conversion / elementwise helpers */
+int mi355_cast(int64_t n, const void* src, int src_dtype, void* dst, int dst_dtype, void* stream);
+/* y[b, s, :] = x[b, s, :] + pos[s, :]  with row 0 of each batch = cls + pos[0] (vit_model.py:86-87,145) */
+int mi355_vit_embed_assemble(int B, int S, int width, const float* patch_proj, const float* cls, const float* pos,
+                             float* out, void* stream);
+/* sum of squares of a bf16/fp32 vector into out[0] (+=) : global grad-norm for clip_grad_norm_ (engine.py:445) */
+int mi355_sumsq(int64_t n, const void* x, int dtype, float* out, void* stream);
+/* x *= min(1, max_norm / (sqrt(*sumsq) + 1e-6))  (torch.nn.utils.clip_grad_norm_ semantics) */
+int mi355_clip_scale(int64_t n, void* x, int dtype, const float* sumsq, float max_norm, void* stream);
+/* fp32 -> bf16 with add: dst_bf16 = bf16(a_f32 + (b_bf16 or 0)) */
+int mi355_add_f32_to_bf16(int64_t n, const float* a, const void* b_bf16, void* dst_bf16, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_VLM_H */

@@ -1,0 +1,117 @@
+"""ctypes binding of libmi355vlm.so (C ABI in include/mi355_vlm.h).
+
+The library is the product: if it is missing the package raises at first use -- there is no CPU or eager-PyTorch
+fallback.  ``build()`` compiles it in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+"""
+
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355vlm.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+DT_BF16, DT_F32 = 0, 1
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+EPI_NONE, EPI_GELU = 0, 1
+
+_c = ctypes
+_P, _I, _L, _F = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float
+
+# name -> argtypes; every entry point returns int.  Must list exactly what include/mi355_vlm.h declares.
+SIGNATURES = {
+    "mi355_gemm_bf16": [_I, _L, _L, _L, _P, _L, _P, _L, _P, _L, _I, _P, _P, _L, _I, _P],
+    "mi355_colsum_bf16": [_L, _L, _P, _L, _P, _I, _P],
+    "mi355_rmsnorm_fwd": [_L, _I, _P, _P, _P, _P, _F, _P],
+    "mi355_rmsnorm_bwd": [_L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "mi355_reduce_rows_f32": [_I, _L, _P, _P, _I, _I, _P],
+    "mi355_qknorm_rope_fwd": [_L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P],
+    "mi355_qknorm_rope_bwd": [_L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "mi355_swiglu_fwd": [_L, _I, _P, _P, _P],
+    "mi355_swiglu_bwd": [_L, _I, _P, _P, _P, _P],
+    "mi355_attn_fwd": [_I, _I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _I, _F, _P],
+    "mi355_attn_bwd": [_I, _I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _L, _P, _L, _P, _L, _P, _I, _F, _P],
+    "mi355_cross_entropy": [_L, _L, _P, _L, _P, _P, _P, _P, _P],
+    "mi355_ce_finalize": [_L, _P, _P, _P, _P],
+    "mi355_embedding_fwd": [_L, _I, _L, _P, _P, _P, _L, _P],
+    "mi355_embedding_bwd": [_L, _I, _L, _P, _P, _L, _P, _P],
+    "mi355_copy2d": [_L, _L, _P, _L, _P, _L, _P],
+    "mi355_patchify": [_I, _I, _I, _I, _I, _P, _P, _I, _P],
+    "mi355_layernorm_fwd": [_L, _I, _P, _P, _P, _P, _I, _P, _P, _F, _P],
+    "mi355_cast": [_L, _P, _I, _P, _I, _P],
+    "mi355_vit_embed_assemble": [_I, _I, _I, _P, _P, _P, _P, _P],
+    "mi355_sumsq": [_L, _P, _I, _P, _P],
+    "mi355_clip_scale": [_L, _P, _I, _P, _F, _P],
+    "mi355_add_f32_to_bf16": [_L, _P, _P, _P, _P],
+}
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile libmi355vlm.so in-tree (hipcc --offload-arch=gfx950)."""
+    cmd = ["make", "-C", CSRC, "-j4"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("building libmi355vlm.so failed:\n" + res.stdout[-4000:] + res.stderr[-4000:])
+    if verbose:
+        print(res.stdout[-2000:])
+    return LIB_PATH
+
+
+def load():
+    """Load the shared library (no GPU needed) and bind every declared symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension is the only implementation of this path "
+            "(no CPU fallback). Build it with `python -c 'import __graft_entry__ as g; g.build()'`."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.mi355_last_error.restype = ctypes.c_char_p
+    lib.mi355_last_error.argtypes = []
+    lib.mi355_abi_version.restype = ctypes.c_int
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Invoke an entry point on the current HIP stream; raise RuntimeError with the library's message on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args, stream())
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (rc={rc}): {lib.mi355_last_error().decode()}")
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "llm_quest_amd ops run only on an MI355X (HIP) device; got a CPU tensor. "
+                "There is no CPU fallback for this path."
+            )
+
+
+def dt_code(dtype):
+    if dtype == torch.bfloat16:
+        return DT_BF16
+    if dtype == torch.float32:
+        return DT_F32
+    raise TypeError(f"unsupported dtype {dtype}")

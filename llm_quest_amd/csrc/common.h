@@ -1,0 +1,61 @@
+// Shared device/host helpers for the gfx950 kernels.  gfx950 only: wave = 64 lanes, no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/mi355_vlm.h"
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+__device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float(((unsigned)b) << 16); }
+
+// round-to-nearest-even, NaN preserving (hipcc lowers the cast to v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    f2 v = {lo, hi};
+    bf2 r = __builtin_convertvector(v, bf2);
+    return __builtin_bit_cast(unsigned, r);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- host side error plumbing -------------------------------------------------------------
+void mi355_set_error(const char* fmt, ...);
+#define MI355_REQUIRE(cond, ...)          \
+    do {                                  \
+        if (!(cond)) {                    \
+            mi355_set_error(__VA_ARGS__); \
+            return 1;                     \
+        }                                 \
+    } while (0)
+#define MI355_LAUNCH_CHECK(name)                                                      \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) {                                                       \
+            mi355_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));    \
+            return 2;                                                                 \
+        }                                                                             \
+    } while (0)

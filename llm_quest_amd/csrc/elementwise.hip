@@ -1,0 +1,424 @@
+// HBM-bound elementwise / gather kernels: SwiGLU, cross-entropy rows, embedding gather + scatter-add,
+// strided copy (early-fusion concat), im2row patch gather, casts, grad-norm helpers.
+// All use 16-byte per-lane accesses where the layout allows and grid-stride over <= 2048 workgroups.
+#include <stdarg.h>
+
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------ error state
+static thread_local char g_err[512] = "";
+void mi355_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* mi355_last_error(void) { return g_err; }
+extern "C" int mi355_abi_version(void) { return 1; }
+
+namespace {
+
+__device__ __forceinline__ void unpack8(const u32x4 v, float (&f)[8]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f[2 * e] = __uint_as_float(v[e] << 16);
+        f[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack_bf2(f[2 * e], f[2 * e + 1]);
+    return o;
+}
+__device__ __forceinline__ float rbf(float x) { return bf2f(f2bf(x)); }
+
+inline int grid_for(int64_t work_items, int per_block) {
+    int64_t g = (work_items + per_block - 1) / per_block;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+// ------------------------------------------------------------------------------------------------ SwiGLU
+// gu [tokens, 2F] = [u | g];  a = bf16( u * bf16(silu(g)) )   (reference: silu output is a bf16 tensor, then *)
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(int64_t tokens, int F, const bf16_t* __restrict__ gu, bf16_t* __restrict__ a) {
+    const int fv = F >> 3;
+    const int64_t total = tokens * fv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t t = i / fv;
+        const int c = (int)(i - t * fv) * 8;
+        float u[8], g[8], o[8];
+        unpack8(*reinterpret_cast<const u32x4*>(gu + t * 2 * F + c), u);
+        unpack8(*reinterpret_cast<const u32x4*>(gu + t * 2 * F + F + c), g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = u[e] * rbf(g[e] / (1.0f + __expf(-g[e])));
+        *reinterpret_cast<u32x4*>(a + t * F + c) = pack8(o);
+    }
+}
+// du = da * silu(g);  dg = da * u * sig(g) * (1 + g*(1-sig(g)))
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(int64_t tokens, int F, const bf16_t* __restrict__ gu,
+                                                         const bf16_t* __restrict__ da, bf16_t* __restrict__ dgu) {
+    const int fv = F >> 3;
+    const int64_t total = tokens * fv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t t = i / fv;
+        const int c = (int)(i - t * fv) * 8;
+        float u[8], g[8], d[8], du[8], dg[8];
+        unpack8(*reinterpret_cast<const u32x4*>(gu + t * 2 * F + c), u);
+        unpack8(*reinterpret_cast<const u32x4*>(gu + t * 2 * F + F + c), g);
+        unpack8(*reinterpret_cast<const u32x4*>(da + t * F + c), d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sg = 1.0f / (1.0f + __expf(-g[e]));
+            du[e] = d[e] * g[e] * sg;
+            dg[e] = d[e] * u[e] * sg * (1.0f + g[e] * (1.0f - sg));
+        }
+        *reinterpret_cast<u32x4*>(dgu + t * 2 * F + c) = pack8(du);
+        *reinterpret_cast<u32x4*>(dgu + t * 2 * F + F + c) = pack8(dg);
+    }
+}
+
+// ----------------------------------------------------------------------------------------- cross entropy
+// One 256-thread block per row.  Pass 1: online max / sum-exp over V (16-byte loads).  Pass 2 (optional):
+// dlogits = (exp(l - lse) - onehot) * scale, written bf16 (in place allowed).  The row (V*2 bytes ~ 300 KB)
+// is re-read from L2/Infinity Cache in pass 2.
+__global__ __launch_bounds__(256) void ce_rows_kernel(int64_t rows, int64_t V, const bf16_t* __restrict__ logits, int64_t ldl,
+                                                      const int64_t* __restrict__ targets, float* __restrict__ loss_rows,
+                                                      bf16_t* dlogits, const float* __restrict__ grad_scale) {
+    __shared__ float red_m[4], red_s[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int64_t tgt = targets[row];
+        const bf16_t* lr = logits + row * ldl;
+        bf16_t* dr = dlogits ? dlogits + row * ldl : nullptr;
+        if (tgt < 0) {  // ignore_index (-100): zero loss, zero gradient
+            if (threadIdx.x == 0) loss_rows[row] = 0.f;
+            if (dr) {
+                const int64_t nv = V >> 3;
+                for (int64_t i = threadIdx.x; i < nv; i += 256) *reinterpret_cast<u32x4*>(dr + i * 8) = (u32x4){0, 0, 0, 0};
+                for (int64_t i = (nv << 3) + threadIdx.x; i < V; i += 256) dr[i] = 0;
+            }
+            continue;
+        }
+        float m = -INFINITY, s = 0.f;
+        const int64_t nv = V >> 3;
+        for (int64_t i = threadIdx.x; i < nv; i += 256) {
+            float v[8];
+            unpack8(*reinterpret_cast<const u32x4*>(lr + i * 8), v);
+            float vm = v[0];
+#pragma unroll
+            for (int e = 1; e < 8; ++e) vm = fmaxf(vm, v[e]);
+            if (vm > m) {
+                s *= __expf(m - vm);
+                m = vm;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += __expf(v[e] - m);
+        }
+        for (int64_t i = (nv << 3) + threadIdx.x; i < V; i += 256) {
+            const float v = bf2f(lr[i]);
+            if (v > m) {
+                s *= __expf(m - v);
+                m = v;
+            }
+            s += __expf(v - m);
+        }
+        const float wm = wave_max(m);
+        s = wave_sum(m == -INFINITY ? 0.f : s * __expf(m - wm));  // lanes/waves that saw no element carry (-inf, 0)
+        __syncthreads();  // protects red_* reuse across rows
+        if (lane == 0) {
+            red_m[wid] = wm;
+            red_s[wid] = s;
+        }
+        __syncthreads();
+        const float bm = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
+        float bs = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) bs += red_m[wv] == -INFINITY ? 0.f : red_s[wv] * __expf(red_m[wv] - bm);
+        const float lse = bm + __logf(bs);
+        if (threadIdx.x == 0) loss_rows[row] = lse - bf2f(lr[tgt]);
+        if (dr) {
+            const float sc = *grad_scale;
+            for (int64_t i = threadIdx.x; i < nv; i += 256) {
+                float v[8], o[8];
+                unpack8(*reinterpret_cast<const u32x4*>(lr + i * 8), v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (__expf(v[e] - lse) - ((i * 8 + e) == tgt ? 1.0f : 0.0f)) * sc;
+                *reinterpret_cast<u32x4*>(dr + i * 8) = pack8(o);
+            }
+            for (int64_t i = (nv << 3) + threadIdx.x; i < V; i += 256)
+                dr[i] = f2bf((__expf(bf2f(lr[i]) - lse) - (i == tgt ? 1.0f : 0.0f)) * sc);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ce_finalize_kernel(int64_t rows, const float* __restrict__ loss_rows,
+                                                          const int64_t* __restrict__ targets, float* __restrict__ out3) {
+    __shared__ float rs[4], rc[4];
+    float s = 0.f, c = 0.f;
+    for (int64_t i = threadIdx.x; i < rows; i += 256) {
+        if (targets[i] >= 0) {
+            s += loss_rows[i];
+            c += 1.f;
+        }
+    }
+    s = wave_sum(s);
+    c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0) {
+        rs[threadIdx.x >> 6] = s;
+        rc[threadIdx.x >> 6] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float ts = rs[0] + rs[1] + rs[2] + rs[3], tc = rc[0] + rc[1] + rc[2] + rc[3];
+        out3[0] = ts / tc;  // NaN when every target is ignored, like F.cross_entropy
+        out3[1] = tc;
+        out3[2] = 1.0f / tc;
+    }
+}
+
+// --------------------------------------------------------------------------------------------- embedding
+__global__ __launch_bounds__(256) void embedding_fwd_kernel(int64_t tokens, int width, int64_t vocab, const int64_t* __restrict__ ids,
+                                                            const bf16_t* __restrict__ table, bf16_t* __restrict__ out, int64_t ldo) {
+    const int wv = width >> 3;
+    const int64_t total = tokens * wv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t t = i / wv;
+        const int c = (int)(i - t * wv) * 8;
+        int64_t id = ids[t];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // host validates; clamp keeps a bad id from faulting
+        *reinterpret_cast<u32x4*>(out + t * ldo + c) = *reinterpret_cast<const u32x4*>(table + id * width + c);
+    }
+}
+// one wave per token; fp32 atomics, 256 contiguous bytes per wave-instruction (the shape the atomic units like)
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(int64_t tokens, int width, int64_t vocab, const int64_t* __restrict__ ids,
+                                                            const bf16_t* __restrict__ dout, int64_t ldd, float* __restrict__ dtable) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < tokens; t += (int64_t)gridDim.x * 4) {
+        const int64_t id = ids[t];
+        if (id < 0 || id >= vocab) continue;
+        for (int c = lane; c < width; c += 64) atomicAdd(dtable + id * width + c, bf2f(dout[t * ldd + c]));
+    }
+}
+
+// ------------------------------------------------------------------------------------------- strided copy
+__global__ __launch_bounds__(256) void copy2d_kernel(int64_t rows, int64_t wvec, const char* __restrict__ src, int64_t sp,
+                                                     char* __restrict__ dst, int64_t dp) {
+    const int64_t total = rows * wvec;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / wvec, c = (i - r * wvec) * 16;
+        *reinterpret_cast<u32x4*>(dst + r * dp + c) = *reinterpret_cast<const u32x4*>(src + r * sp + c);
+    }
+}
+__global__ __launch_bounds__(256) void copy2d_bytes_kernel(int64_t rows, int64_t w, const char* __restrict__ src, int64_t sp,
+                                                           char* __restrict__ dst, int64_t dp) {
+    const int64_t total = rows * w;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / w, c = i - r * w;
+        dst[r * dp + c] = src[r * sp + c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------- patch gather
+// rows[(b*gh+ph)*gw+pw][(c*P+i)*P+j] = img[b][c][ph*P+i][pw*P+j].  One thread moves 4 consecutive j (16-B read).
+template <int OUT_DT>
+__global__ __launch_bounds__(256) void patchify_kernel(int B, int C, int H, int W, int P, const float* __restrict__ img, void* __restrict__ rows) {
+    const int gh = H / P, gw = W / P, K = C * P * P, pv = P >> 2;
+    const int64_t total = (int64_t)B * gh * gw * C * P * pv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        // order the work so consecutive threads read consecutive image addresses: (b, c, y, pw, jv)
+        int64_t r = i;
+        const int jv = (int)(r % pv); r /= pv;
+        const int pw = (int)(r % gw); r /= gw;
+        const int y = (int)(r % H); r /= H;
+        const int c = (int)(r % C); r /= C;
+        const int b = (int)r;
+        const int ph = y / P, ii = y - ph * P;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(img + (((int64_t)b * C + c) * H + y) * W + pw * P + jv * 4);
+        const int64_t orow = ((int64_t)b * gh + ph) * gw + pw;
+        const int k = (c * P + ii) * P + jv * 4;
+        if constexpr (OUT_DT == MI355_DT_BF16) {
+            u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(rows) + orow * K + k) = pk;
+        } else {
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(rows) + orow * K + k) = v;
+        }
+    }
+}
+
+// out[b, 0, :] = cls + pos[0];  out[b, 1+p, :] = proj[b*Np + p, :] + pos[1+p]
+__global__ __launch_bounds__(256) void vit_embed_assemble_kernel(int B, int S, int width, const float* __restrict__ proj,
+                                                                 const float* __restrict__ cls, const float* __restrict__ pos,
+                                                                 float* __restrict__ out) {
+    const int wv = width >> 2;
+    const int64_t total = (int64_t)B * S * wv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % wv) * 4;
+        const int64_t bs = i / wv;
+        const int s = (int)(bs % S);
+        const int64_t b = bs / S;
+        const f32x4 pe = *reinterpret_cast<const f32x4*>(pos + (int64_t)s * width + c);
+        const f32x4 base = s == 0 ? *reinterpret_cast<const f32x4*>(cls + c)
+                                  : *reinterpret_cast<const f32x4*>(proj + (b * (S - 1) + (s - 1)) * width + c);
+        *reinterpret_cast<f32x4*>(out + bs * width + c) = base + pe;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------- casts
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(int64_t n, const float* __restrict__ s, bf16_t* __restrict__ d) {
+    const int64_t nv = n >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(s + i * 8), b = *reinterpret_cast<const f32x4*>(s + i * 8 + 4);
+        *reinterpret_cast<u32x4*>(d + i * 8) = (u32x4){pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]), pack_bf2(b[0], b[1]), pack_bf2(b[2], b[3])};
+    }
+    for (int64_t i = (nv << 3) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = f2bf(s[i]);
+}
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(int64_t n, const bf16_t* __restrict__ s, float* __restrict__ d) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = bf2f(s[i]);
+}
+__global__ __launch_bounds__(256) void add_f32_to_bf16_kernel(int64_t n, const float* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ d) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        d[i] = f2bf(a[i] + (b ? bf2f(b[i]) : 0.f));
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void sumsq_kernel(int64_t n, const void* __restrict__ x, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = DT == MI355_DT_BF16 ? bf2f(reinterpret_cast<const bf16_t*>(x)[i]) : reinterpret_cast<const float*>(x)[i];
+        s += v * v;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+template <int DT>
+__global__ __launch_bounds__(256) void clip_scale_kernel(int64_t n, void* __restrict__ x, const float* __restrict__ sumsq, float max_norm) {
+    const float coef = fminf(1.0f, max_norm / (sqrtf(*sumsq) + 1e-6f));
+    if (coef >= 1.0f) return;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        if (DT == MI355_DT_BF16) {
+            bf16_t* p = reinterpret_cast<bf16_t*>(x);
+            p[i] = f2bf(bf2f(p[i]) * coef);
+        } else {
+            reinterpret_cast<float*>(x)[i] *= coef;
+        }
+    }
+}
+
+}  // namespace
+
+#define STREAM ((hipStream_t)stream)
+
+extern "C" int mi355_swiglu_fwd(int64_t tokens, int F, const void* gu, void* a, void* stream) {
+    MI355_REQUIRE(tokens > 0 && F > 0 && (F & 7) == 0 && gu && a, "mi355_swiglu_fwd: F must be a multiple of 8 and pointers non-null");
+    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for(tokens * (F >> 3), 256)), dim3(256), 0, STREAM, tokens, F, (const bf16_t*)gu, (bf16_t*)a);
+    MI355_LAUNCH_CHECK("mi355_swiglu_fwd");
+    return 0;
+}
+extern "C" int mi355_swiglu_bwd(int64_t tokens, int F, const void* gu, const void* da, void* dgu, void* stream) {
+    MI355_REQUIRE(tokens > 0 && F > 0 && (F & 7) == 0 && gu && da && dgu, "mi355_swiglu_bwd: bad arguments");
+    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(tokens * (F >> 3), 256)), dim3(256), 0, STREAM, tokens, F, (const bf16_t*)gu, (const bf16_t*)da, (bf16_t*)dgu);
+    MI355_LAUNCH_CHECK("mi355_swiglu_bwd");
+    return 0;
+}
+
+extern "C" int mi355_cross_entropy(int64_t rows, int64_t V, const void* logits, int64_t ldl, const int64_t* targets,
+                                   float* loss_rows, void* dlogits, const float* grad_scale, void* stream) {
+    MI355_REQUIRE(rows > 0 && V > 0 && logits && targets && loss_rows, "mi355_cross_entropy: bad arguments");
+    MI355_REQUIRE((ldl & 7) == 0 && ((uintptr_t)logits & 15) == 0, "mi355_cross_entropy: logits rows must be 16-byte aligned");
+    MI355_REQUIRE(dlogits == nullptr || grad_scale != nullptr, "mi355_cross_entropy: dlogits needs grad_scale");
+    hipLaunchKernelGGL(ce_rows_kernel, dim3((unsigned)(rows < 65535 ? rows : 65535)), dim3(256), 0, STREAM, rows, V, (const bf16_t*)logits, ldl, targets, loss_rows, (bf16_t*)dlogits, grad_scale);
+    MI355_LAUNCH_CHECK("mi355_cross_entropy");
+    return 0;
+}
+extern "C" int mi355_ce_finalize(int64_t rows, const float* loss_rows, const int64_t* targets, float* out3, void* stream) {
+    MI355_REQUIRE(rows > 0 && loss_rows && targets && out3, "mi355_ce_finalize: bad arguments");
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, STREAM, rows, loss_rows, targets, out3);
+    MI355_LAUNCH_CHECK("mi355_ce_finalize");
+    return 0;
+}
+
+extern "C" int mi355_embedding_fwd(int64_t tokens, int width, int64_t vocab, const int64_t* ids, const void* table, void* out,
+                                   int64_t ldo, void* stream) {
+    MI355_REQUIRE(tokens > 0 && width > 0 && (width & 7) == 0 && (ldo & 7) == 0 && ids && table && out, "mi355_embedding_fwd: bad arguments (width/ldo multiple of 8)");
+    hipLaunchKernelGGL(embedding_fwd_kernel, dim3(grid_for(tokens * (width >> 3), 256)), dim3(256), 0, STREAM, tokens, width, vocab, ids, (const bf16_t*)table, (bf16_t*)out, ldo);
+    MI355_LAUNCH_CHECK("mi355_embedding_fwd");
+    return 0;
+}
+extern "C" int mi355_embedding_bwd(int64_t tokens, int width, int64_t vocab, const int64_t* ids, const void* dout, int64_t ldd,
+                                   float* dtable_f32, void* stream) {
+    MI355_REQUIRE(tokens > 0 && width > 0 && ids && dout && dtable_f32, "mi355_embedding_bwd: bad arguments");
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(grid_for(tokens, 4)), dim3(256), 0, STREAM, tokens, width, vocab, ids, (const bf16_t*)dout, ldd, dtable_f32);
+    MI355_LAUNCH_CHECK("mi355_embedding_bwd");
+    return 0;
+}
+
+extern "C" int mi355_copy2d(int64_t rows, int64_t width_bytes, const void* src, int64_t src_pitch_bytes, void* dst,
+                            int64_t dst_pitch_bytes, void* stream) {
+    MI355_REQUIRE(rows > 0 && width_bytes > 0 && src && dst, "mi355_copy2d: bad arguments");
+    const bool vec = ((width_bytes | src_pitch_bytes | dst_pitch_bytes) & 15) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for(rows * (width_bytes >> 4), 256)), dim3(256), 0, STREAM, rows, width_bytes >> 4, (const char*)src, src_pitch_bytes, (char*)dst, dst_pitch_bytes);
+    else
+        hipLaunchKernelGGL(copy2d_bytes_kernel, dim3(grid_for(rows * width_bytes, 256)), dim3(256), 0, STREAM, rows, width_bytes, (const char*)src, src_pitch_bytes, (char*)dst, dst_pitch_bytes);
+    MI355_LAUNCH_CHECK("mi355_copy2d");
+    return 0;
+}
+
+extern "C" int mi355_patchify(int B, int C, int H, int W, int P, const float* img, void* rows, int out_dtype, void* stream) {
+    MI355_REQUIRE(B > 0 && C > 0 && P > 0 && (P & 3) == 0 && H % P == 0 && W % P == 0 && img && rows, "mi355_patchify: patch size must be a multiple of 4 and divide H and W");
+    MI355_REQUIRE(((uintptr_t)img & 15) == 0, "mi355_patchify: image must be 16-byte aligned");
+    const int64_t work = (int64_t)B * C * H * (W / 4);
+    if (out_dtype == MI355_DT_BF16)
+        hipLaunchKernelGGL(patchify_kernel<MI355_DT_BF16>, dim3(grid_for(work, 256)), dim3(256), 0, STREAM, B, C, H, W, P, img, rows);
+    else
+        hipLaunchKernelGGL(patchify_kernel<MI355_DT_F32>, dim3(grid_for(work, 256)), dim3(256), 0, STREAM, B, C, H, W, P, img, rows);
+    MI355_LAUNCH_CHECK("mi355_patchify");
+    return 0;
+}
+
+extern "C" int mi355_vit_embed_assemble(int B, int S, int width, const float* patch_proj, const float* cls, const float* pos,
+                                        float* out, void* stream) {
+    MI355_REQUIRE(B > 0 && S > 1 && width > 0 && (width & 3) == 0 && patch_proj && cls && pos && out, "mi355_vit_embed_assemble: bad arguments");
+    hipLaunchKernelGGL(vit_embed_assemble_kernel, dim3(grid_for((int64_t)B * S * (width >> 2), 256)), dim3(256), 0, STREAM, B, S, width, patch_proj, cls, pos, out);
+    MI355_LAUNCH_CHECK("mi355_vit_embed_assemble");
+    return 0;
+}
+
+extern "C" int mi355_cast(int64_t n, const void* src, int src_dtype, void* dst, int dst_dtype, void* stream) {
+    MI355_REQUIRE(n > 0 && src && dst && src_dtype != dst_dtype, "mi355_cast: bad arguments");
+    if (src_dtype == MI355_DT_F32)
+        hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n >> 3, 256)), dim3(256), 0, STREAM, n, (const float*)src, (bf16_t*)dst);
+    else
+        hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, STREAM, n, (const bf16_t*)src, (float*)dst);
+    MI355_LAUNCH_CHECK("mi355_cast");
+    return 0;
+}
+
+extern "C" int mi355_add_f32_to_bf16(int64_t n, const float* a, const void* b_bf16, void* dst_bf16, void* stream) {
+    MI355_REQUIRE(n > 0 && a && dst_bf16, "mi355_add_f32_to_bf16: bad arguments");
+    hipLaunchKernelGGL(add_f32_to_bf16_kernel, dim3(grid_for(n, 256)), dim3(256), 0, STREAM, n, a, (const bf16_t*)b_bf16, (bf16_t*)dst_bf16);
+    MI355_LAUNCH_CHECK("mi355_add_f32_to_bf16");
+    return 0;
+}
+
+extern "C" int mi355_sumsq(int64_t n, const void* x, int dtype, float* out, void* stream) {
+    MI355_REQUIRE(n > 0 && x && out, "mi355_sumsq: bad arguments");
+    if (dtype == MI355_DT_BF16)
+        hipLaunchKernelGGL(sumsq_kernel<MI355_DT_BF16>, dim3(grid_for(n, 256 * 8)), dim3(256), 0, STREAM, n, x, out);
+    else
+        hipLaunchKernelGGL(sumsq_kernel<MI355_DT_F32>, dim3(grid_for(n, 256 * 8)), dim3(256), 0, STREAM, n, x, out);
+    MI355_LAUNCH_CHECK("mi355_sumsq");
+    return 0;
+}
+extern "C" int mi355_clip_scale(int64_t n, void* x, int dtype, const float* sumsq, float max_norm, void* stream) {
+    MI355_REQUIRE(n > 0 && x && sumsq, "mi355_clip_scale: bad arguments");
+    if (dtype == MI355_DT_BF16)
+        hipLaunchKernelGGL(clip_scale_kernel<MI355_DT_BF16>, dim3(grid_for(n, 256 * 4)), dim3(256), 0, STREAM, n, x, sumsq, max_norm);
+    else
+        hipLaunchKernelGGL(clip_scale_kernel<MI355_DT_F32>, dim3(grid_for(n, 256 * 4)), dim3(256), 0, STREAM, n, x, sumsq, max_norm);
+    MI355_LAUNCH_CHECK("mi355_clip_scale");
+    return 0;
+}

@@ -1,0 +1,392 @@
+// HBM-bound row kernels: RMSNorm fwd/bwd, fused QK-RMSNorm + RoPE fwd/bwd, ViT LayerNorm (sigma + eps).
+// One wave (64 lanes) per row, 16-byte vector loads, fp32 math, wavefront-shuffle reductions; rounding
+// points follow the reference (RMSNorm fully in fp32, RoPE multiplies in bf16 with bf16-rounded cos/sin).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ void unpack8(const u32x4 v, float (&f)[8]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f[2 * e] = __uint_as_float(v[e] << 16);
+        f[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack_bf2(f[2 * e], f[2 * e + 1]);
+    return o;
+}
+__device__ __forceinline__ float rbf(float x) { return bf2f(f2bf(x)); }  // round through bf16
+
+// ------------------------------------------------------------------------------------------- RMSNorm
+// width = 64 * 8 * VPL elements per row (VPL 16-byte vectors per lane); width 1024 -> VPL 2, 128 handled apart.
+template <int VPL>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(int64_t rows, int width, const bf16_t* __restrict__ x,
+                                                          const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
+                                                          float* __restrict__ rstd, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (int64_t row = row0; row < rows; row += (int64_t)gridDim.x * 4) {
+        const bf16_t* xr = x + row * width;
+        float v[VPL][8];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            unpack8(*reinterpret_cast<const u32x4*>(xr + (i * 64 + lane) * 8), v[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
+        }
+        ss = wave_sum(ss);
+        const float r = rsqrtf(ss / (float)width + eps);
+        if (lane == 0 && rstd) rstd[row] = r;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            float wv[8], o[8];
+            unpack8(*reinterpret_cast<const u32x4*>(w + (i * 64 + lane) * 8), wv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = v[i][e] * r * wv[e];
+            *reinterpret_cast<u32x4*>(y + row * width + (i * 64 + lane) * 8) = pack8(o);
+        }
+    }
+}
+
+// generic-width fallback (width multiple of 8, <= 64*8*8): lanes stride over vectors
+__global__ __launch_bounds__(256) void rmsnorm_fwd_generic(int64_t rows, int width, const bf16_t* __restrict__ x,
+                                                           const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
+                                                           float* __restrict__ rstd, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int nvec = width >> 3;
+    const int64_t row0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (int64_t row = row0; row < rows; row += (int64_t)gridDim.x * 4) {
+        const bf16_t* xr = x + row * width;
+        float ss = 0.f;
+        for (int i = lane; i < nvec; i += 64) {
+            float v[8];
+            unpack8(*reinterpret_cast<const u32x4*>(xr + i * 8), v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
+        }
+        ss = wave_sum(ss);
+        const float r = rsqrtf(ss / (float)width + eps);
+        if (lane == 0 && rstd) rstd[row] = r;
+        for (int i = lane; i < nvec; i += 64) {
+            float v[8], wv[8], o[8];
+            unpack8(*reinterpret_cast<const u32x4*>(xr + i * 8), v);
+            unpack8(*reinterpret_cast<const u32x4*>(w + i * 8), wv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = v[e] * r * wv[e];
+            *reinterpret_cast<u32x4*>(y + row * width + i * 8) = pack8(o);
+        }
+    }
+}
+
+// dx = rstd * (g - xhat * mean(g * xhat)) with g = w*dy, xhat = x*rstd;  dx += dres (residual-stream grad);
+// dw partial[part][c] += dy*xhat summed over the rows this block owns (one partial row per block).
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(int64_t rows, int width, const bf16_t* __restrict__ x,
+                                                          const bf16_t* __restrict__ w, const float* __restrict__ rstd,
+                                                          const bf16_t* __restrict__ dy, const bf16_t* __restrict__ dres,
+                                                          bf16_t* __restrict__ dx, float* __restrict__ dw_partial) {
+    extern __shared__ __attribute__((aligned(16))) float dw_lds[];  // [width]
+    const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
+    const int nvec = width >> 3;
+    for (int i = threadIdx.x; i < width; i += 256) dw_lds[i] = 0.f;
+    __syncthreads();
+    const int64_t row0 = (int64_t)blockIdx.x * 4 + wv_id;
+    for (int i0 = 0; i0 < nvec; i0 += 64) {  // column slab of 512 elements: keeps dw accumulators in registers
+        const int i = i0 + lane;
+        float dwacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        float wf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (i < nvec) unpack8(*reinterpret_cast<const u32x4*>(w + i * 8), wf);
+        for (int64_t row = row0; row < rows; row += (int64_t)gridDim.x * 4) {
+            if (i < nvec) {
+                float xv[8], dyv[8];
+                unpack8(*reinterpret_cast<const u32x4*>(x + row * width + i * 8), xv);
+                unpack8(*reinterpret_cast<const u32x4*>(dy + row * width + i * 8), dyv);
+                const float r = rstd[row];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dwacc[e] += dyv[e] * xv[e] * r;
+            }
+        }
+        if (i < nvec) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(&dw_lds[i * 8 + e], dwacc[e]);
+        }
+    }
+    // dx: a second sweep per row (row data is L2-hot from the sweep above when width <= 512*..; HBM-bound anyway)
+    for (int64_t row = row0; row < rows; row += (int64_t)gridDim.x * 4) {
+        const float r = rstd[row];
+        float dot = 0.f;
+        for (int i = lane; i < nvec; i += 64) {
+            float xv[8], dyv[8], wf[8];
+            unpack8(*reinterpret_cast<const u32x4*>(x + row * width + i * 8), xv);
+            unpack8(*reinterpret_cast<const u32x4*>(dy + row * width + i * 8), dyv);
+            unpack8(*reinterpret_cast<const u32x4*>(w + i * 8), wf);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dot += dyv[e] * wf[e] * xv[e];
+        }
+        dot = wave_sum(dot) * r * r / (float)width;
+        for (int i = lane; i < nvec; i += 64) {
+            float xv[8], dyv[8], wf[8], o[8];
+            unpack8(*reinterpret_cast<const u32x4*>(x + row * width + i * 8), xv);
+            unpack8(*reinterpret_cast<const u32x4*>(dy + row * width + i * 8), dyv);
+            unpack8(*reinterpret_cast<const u32x4*>(w + i * 8), wf);
+            float rs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (dres) unpack8(*reinterpret_cast<const u32x4*>(dres + row * width + i * 8), rs);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = r * (dyv[e] * wf[e] - xv[e] * dot) + rs[e];
+            *reinterpret_cast<u32x4*>(dx + row * width + i * 8) = pack8(o);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < width; i += 256) dw_partial[(int64_t)blockIdx.x * width + i] = dw_lds[i];
+}
+
+__global__ __launch_bounds__(256) void reduce_rows_kernel(int parts, int64_t n, const float* __restrict__ partial,
+                                                          void* __restrict__ out, int out_dtype, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int p = 0; p < parts; ++p) s += partial[(int64_t)p * n + i];
+    if (out_dtype == MI355_DT_BF16) {
+        bf16_t* o = reinterpret_cast<bf16_t*>(out);
+        if (accumulate) s += bf2f(o[i]);
+        o[i] = f2bf(s);
+    } else {
+        float* o = reinterpret_cast<float*>(out);
+        if (accumulate) s += o[i];
+        o[i] = s;
+    }
+}
+
+// --------------------------------------------------------------------------- fused QK-RMSNorm + RoPE
+// One wave per (token, head) for D=128: lane holds elements 2*lane, 2*lane+1?  RoPE pairs element i with i+D/2,
+// so lane l (< D/2/ ... ) keeps x[l] and x[l + D/2]: D=128 -> lanes 0..63 hold (x[l], x[l+64]).
+// For D=64 lanes 0..31 are active (half wave).  Reference rounding points:
+//   n  = bf16( float(x) * rstd * float(w) )                      (PytorchRMSNorm)
+//   y1 = bf16( bf16(cos_b*n1) + bf16(sin_b*(-n2)) ),  y2 = bf16( bf16(cos_b*n2) + bf16(sin_b*n1) )   (RoPE.apply in bf16)
+template <int D>
+__global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(int64_t tokens, int Hq, int Hkv, const bf16_t* __restrict__ qkv,
+                                                              const bf16_t* __restrict__ qw, const bf16_t* __restrict__ kw,
+                                                              const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                                              const int32_t* __restrict__ pos, bf16_t* __restrict__ qo,
+                                                              bf16_t* __restrict__ ko, float* __restrict__ rstd, float eps) {
+    constexpr int HALF = D / 2;
+    const int lane = threadIdx.x & 63;
+    const int H = Hq + Hkv;
+    const int64_t ld = (int64_t)(Hq + 2 * Hkv) * D;
+    const int64_t total = tokens * H;
+    const bool act = lane < HALF;
+    const int l = act ? lane : 0;
+    for (int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); item < total; item += (int64_t)gridDim.x * 4) {
+        const int64_t t = item / H;
+        const int h = (int)(item - t * H);
+        const bf16_t* src = qkv + t * ld + (int64_t)h * D;
+        const bf16_t* wgt = h < Hq ? qw : kw;
+        const float x1 = bf2f(src[l]), x2 = bf2f(src[l + HALF]);
+        float ss = act ? x1 * x1 + x2 * x2 : 0.f;
+        ss = wave_sum(ss);
+        const float r = rsqrtf(ss / (float)D + eps);
+        const float n1 = rbf(x1 * r * bf2f(wgt[l])), n2 = rbf(x2 * r * bf2f(wgt[l + HALF]));
+        const int p = pos[t];
+        const float c1 = rbf(cosT[(int64_t)p * D + l]), s1 = rbf(sinT[(int64_t)p * D + l]);
+        const float c2 = rbf(cosT[(int64_t)p * D + l + HALF]), s2 = rbf(sinT[(int64_t)p * D + l + HALF]);
+        const float y1 = rbf(c1 * n1) + rbf(s1 * (-n2));
+        const float y2 = rbf(c2 * n2) + rbf(s2 * n1);
+        bf16_t* dst = h < Hq ? qo + t * (int64_t)Hq * D + (int64_t)h * D : ko + t * (int64_t)Hkv * D + (int64_t)(h - Hq) * D;
+        if (act) {
+            dst[l] = f2bf(y1);
+            dst[l + HALF] = f2bf(y2);
+        }
+        if (lane == 0) rstd[t * H + h] = r;
+    }
+}
+
+// backward of the same: dn = RoPE^T dy (fp32), then RMSNorm backward per head; dw partials per block.
+template <int D>
+__global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(int64_t tokens, int Hq, int Hkv, const bf16_t* __restrict__ qkv,
+                                                              const bf16_t* __restrict__ qw, const bf16_t* __restrict__ kw,
+                                                              const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                                              const int32_t* __restrict__ pos, const float* __restrict__ rstd,
+                                                              const bf16_t* __restrict__ dq, const bf16_t* __restrict__ dk,
+                                                              bf16_t* __restrict__ dqkv, float* __restrict__ dw_partial) {
+    constexpr int HALF = D / 2;
+    __shared__ float dw_lds[2 * D];
+    const int lane = threadIdx.x & 63;
+    const int H = Hq + Hkv;
+    const int64_t ld = (int64_t)(Hq + 2 * Hkv) * D;
+    const int64_t total = tokens * H;
+    const bool act = lane < HALF;
+    const int l = act ? lane : 0;
+    for (int i = threadIdx.x; i < 2 * D; i += 256) dw_lds[i] = 0.f;
+    __syncthreads();
+    float dwq1 = 0.f, dwq2 = 0.f, dwk1 = 0.f, dwk2 = 0.f;
+    for (int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); item < total; item += (int64_t)gridDim.x * 4) {
+        const int64_t t = item / H;
+        const int h = (int)(item - t * H);
+        const bool isq = h < Hq;
+        const bf16_t* src = qkv + t * ld + (int64_t)h * D;
+        const bf16_t* wgt = isq ? qw : kw;
+        const bf16_t* g = isq ? dq + t * (int64_t)Hq * D + (int64_t)h * D : dk + t * (int64_t)Hkv * D + (int64_t)(h - Hq) * D;
+        const float x1 = bf2f(src[l]), x2 = bf2f(src[l + HALF]);
+        const float w1 = bf2f(wgt[l]), w2 = bf2f(wgt[l + HALF]);
+        const float r = rstd[t * H + h];
+        const int p = pos[t];
+        const float c1 = rbf(cosT[(int64_t)p * D + l]), s1 = rbf(sinT[(int64_t)p * D + l]);
+        const float c2 = rbf(cosT[(int64_t)p * D + l + HALF]), s2 = rbf(sinT[(int64_t)p * D + l + HALF]);
+        const float g1 = bf2f(g[l]), g2 = bf2f(g[l + HALF]);
+        // y1 = c1*n1 - s1*n2 ; y2 = c2*n2 + s2*n1
+        const float dn1 = c1 * g1 + s2 * g2;
+        const float dn2 = c2 * g2 - s1 * g1;
+        const float xh1 = x1 * r, xh2 = x2 * r;
+        float dot = act ? dn1 * w1 * xh1 + dn2 * w2 * xh2 : 0.f;
+        dot = wave_sum(dot) / (float)D;
+        const float dx1 = r * (dn1 * w1 - xh1 * dot), dx2 = r * (dn2 * w2 - xh2 * dot);
+        if (act) {
+            bf16_t* dst = dqkv + t * ld + (int64_t)h * D;
+            dst[l] = f2bf(dx1);
+            dst[l + HALF] = f2bf(dx2);
+            if (isq) { dwq1 += dn1 * xh1; dwq2 += dn2 * xh2; } else { dwk1 += dn1 * xh1; dwk2 += dn2 * xh2; }
+        }
+    }
+    if (act) {
+        atomicAdd(&dw_lds[l], dwq1);
+        atomicAdd(&dw_lds[l + HALF], dwq2);
+        atomicAdd(&dw_lds[D + l], dwk1);
+        atomicAdd(&dw_lds[D + l + HALF], dwk2);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * D; i += 256) dw_partial[(int64_t)blockIdx.x * 2 * D + i] = dw_lds[i];
+}
+
+// ------------------------------------------------------------------------ ViT LayerNorm (sigma + eps)
+// x fp32 rows; y = scale*(x-mean)/(sqrt(mean((x-mean)^2)) + eps) + shift
+template <int OUT_DT>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(int64_t rows, int width, const float* __restrict__ x,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            void* __restrict__ y, float* __restrict__ mean_out,
+                                                            float* __restrict__ rsig_out, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int nvec = width >> 2;
+    const int64_t row0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (int64_t row = row0; row < rows; row += (int64_t)gridDim.x * 4) {
+        const float* xr = x + row * width;
+        float s = 0.f;
+        for (int i = lane; i < nvec; i += 64) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xr + i * 4);
+            s += v[0] + v[1] + v[2] + v[3];
+        }
+        const float mu = wave_sum(s) / (float)width;
+        float ss = 0.f;
+        for (int i = lane; i < nvec; i += 64) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xr + i * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ss += (v[e] - mu) * (v[e] - mu);
+        }
+        const float sd = sqrtf(wave_sum(ss) / (float)width);
+        const float inv = 1.0f / (sd + eps);
+        if (lane == 0) {
+            if (mean_out) mean_out[row] = mu;
+            if (rsig_out) rsig_out[row] = inv;
+        }
+        for (int i = lane; i < nvec; i += 64) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xr + i * 4);
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + i * 4);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + i * 4);
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = sc[e] * ((v[e] - mu) * inv) + sh[e];
+            if constexpr (OUT_DT == MI355_DT_BF16) {
+                u32x2 pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+                *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(y) + row * width + i * 4) = pk;
+            } else {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(y) + row * width + i * 4) = (f32x4){o[0], o[1], o[2], o[3]};
+            }
+        }
+    }
+}
+
+inline int row_grid(int64_t rows) {
+    int64_t g = (rows + 3) / 4;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace
+
+extern "C" int mi355_rmsnorm_fwd(int64_t rows, int width, const void* x, const void* w, void* y, float* rstd, float eps,
+                                 void* stream) {
+    MI355_REQUIRE(rows > 0 && width > 0 && (width & 7) == 0 && width <= 8192, "mi355_rmsnorm_fwd: width must be a multiple of 8 and <= 8192 (got %d)", width);
+    MI355_REQUIRE(x && w && y, "mi355_rmsnorm_fwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = row_grid(rows);
+    if (width == 1024)
+        hipLaunchKernelGGL(rmsnorm_fwd_kernel<2>, dim3(grid), dim3(256), 0, s, rows, width, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, eps);
+    else
+        hipLaunchKernelGGL(rmsnorm_fwd_generic, dim3(grid), dim3(256), 0, s, rows, width, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, eps);
+    MI355_LAUNCH_CHECK("mi355_rmsnorm_fwd");
+    return 0;
+}
+
+extern "C" int mi355_rmsnorm_bwd(int64_t rows, int width, const void* x, const void* w, const float* rstd, const void* dy,
+                                 const void* dres, void* dx, float* dw_partial, int parts, void* stream) {
+    MI355_REQUIRE(rows > 0 && (width & 7) == 0 && width <= 8192, "mi355_rmsnorm_bwd: bad width %d", width);
+    MI355_REQUIRE(x && w && rstd && dy && dx && dw_partial && parts > 0, "mi355_rmsnorm_bwd: null pointer / parts");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(parts), dim3(256), width * sizeof(float), s, rows, width, (const bf16_t*)x,
+                       (const bf16_t*)w, rstd, (const bf16_t*)dy, (const bf16_t*)dres, (bf16_t*)dx, dw_partial);
+    MI355_LAUNCH_CHECK("mi355_rmsnorm_bwd");
+    return 0;
+}
+
+extern "C" int mi355_reduce_rows_f32(int parts, int64_t n, const float* partial, void* out, int out_dtype, int accumulate,
+                                     void* stream) {
+    MI355_REQUIRE(parts > 0 && n > 0 && partial && out, "mi355_reduce_rows_f32: bad arguments");
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, parts, n,
+                       partial, out, out_dtype, accumulate);
+    MI355_LAUNCH_CHECK("mi355_reduce_rows_f32");
+    return 0;
+}
+
+extern "C" int mi355_qknorm_rope_fwd(int64_t tokens, int Hq, int Hkv, int D, const void* qkv, const void* qw, const void* kw,
+                                     const float* cos, const float* sin, const int32_t* pos, void* q_out, void* k_out,
+                                     float* rstd, float eps, void* stream) {
+    MI355_REQUIRE(D == 128 || D == 64, "mi355_qknorm_rope_fwd: head_dim must be 64 or 128 (got %d)", D);
+    MI355_REQUIRE(tokens > 0 && Hq > 0 && Hkv > 0 && qkv && qw && kw && cos && sin && pos && q_out && k_out && rstd, "mi355_qknorm_rope_fwd: bad arguments");
+    const int grid = row_grid(tokens * (Hq + Hkv));
+    hipStream_t s = (hipStream_t)stream;
+    if (D == 128)
+        hipLaunchKernelGGL(qknorm_rope_fwd_kernel<128>, dim3(grid), dim3(256), 0, s, tokens, Hq, Hkv, (const bf16_t*)qkv, (const bf16_t*)qw, (const bf16_t*)kw, cos, sin, pos, (bf16_t*)q_out, (bf16_t*)k_out, rstd, eps);
+    else
+        hipLaunchKernelGGL(qknorm_rope_fwd_kernel<64>, dim3(grid), dim3(256), 0, s, tokens, Hq, Hkv, (const bf16_t*)qkv, (const bf16_t*)qw, (const bf16_t*)kw, cos, sin, pos, (bf16_t*)q_out, (bf16_t*)k_out, rstd, eps);
+    MI355_LAUNCH_CHECK("mi355_qknorm_rope_fwd");
+    return 0;
+}
+
+extern "C" int mi355_qknorm_rope_bwd(int64_t tokens, int Hq, int Hkv, int D, const void* qkv, const void* qw, const void* kw,
+                                     const float* cos, const float* sin, const int32_t* pos, const float* rstd,
+                                     const void* dq, const void* dk, void* dqkv, float* dw_partial, int parts, void* stream) {
+    MI355_REQUIRE(D == 128 || D == 64, "mi355_qknorm_rope_bwd: head_dim must be 64 or 128 (got %d)", D);
+    MI355_REQUIRE(tokens > 0 && parts > 0 && qkv && qw && kw && cos && sin && pos && rstd && dq && dk && dqkv && dw_partial, "mi355_qknorm_rope_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (D == 128)
+        hipLaunchKernelGGL(qknorm_rope_bwd_kernel<128>, dim3(parts), dim3(256), 0, s, tokens, Hq, Hkv, (const bf16_t*)qkv, (const bf16_t*)qw, (const bf16_t*)kw, cos, sin, pos, rstd, (const bf16_t*)dq, (const bf16_t*)dk, (bf16_t*)dqkv, dw_partial);
+    else
+        hipLaunchKernelGGL(qknorm_rope_bwd_kernel<64>, dim3(parts), dim3(256), 0, s, tokens, Hq, Hkv, (const bf16_t*)qkv, (const bf16_t*)qw, (const bf16_t*)kw, cos, sin, pos, rstd, (const bf16_t*)dq, (const bf16_t*)dk, (bf16_t*)dqkv, dw_partial);
+    MI355_LAUNCH_CHECK("mi355_qknorm_rope_bwd");
+    return 0;
+}
+
+extern "C" int mi355_layernorm_fwd(int64_t rows, int width, const float* x, const float* scale, const float* shift, void* y,
+                                   int y_dtype, float* mean, float* rsig, float eps, void* stream) {
+    MI355_REQUIRE(rows > 0 && width > 0 && (width & 3) == 0, "mi355_layernorm_fwd: width must be a multiple of 4 (got %d)", width);
+    MI355_REQUIRE(x && scale && shift && y, "mi355_layernorm_fwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = row_grid(rows);
+    if (y_dtype == MI355_DT_BF16)
+        hipLaunchKernelGGL(layernorm_fwd_kernel<MI355_DT_BF16>, dim3(grid), dim3(256), 0, s, rows, width, x, scale, shift, y, mean, rsig, eps);
+    else
+        hipLaunchKernelGGL(layernorm_fwd_kernel<MI355_DT_F32>, dim3(grid), dim3(256), 0, s, rows, width, x, scale, shift, y, mean, rsig, eps);
+    MI355_LAUNCH_CHECK("mi355_layernorm_fwd");
+    return 0;
+}

@@ -1,0 +1,294 @@
+"""Tensor-level launchers over the C ABI (no autograd here).
+
+Every launcher checks on the host that shapes / strides / dtypes are what the kernel and its grid assume before any
+pointer reaches the GPU, allocates outputs with torch (device memory plumbing only) and enqueues the HIP kernel on
+torch's current stream.
+"""
+
+import torch
+
+from . import _lib as L
+
+BF16, F32 = torch.bfloat16, torch.float32
+NORM_PARTS = 256  # blocks (= partial rows) of the norm backward kernels
+
+
+def _rowmajor(t, name):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name}: expected a 2-D tensor with unit inner stride, got shape {tuple(t.shape)} strides {t.stride()}")
+
+
+def gemm(form, a, b, out=None, out_dtype=BF16, bias=None, residual=None, gelu=False):
+    """C = epi(op(A) op(B) + bias) + residual.  form NT: A[M,K] B[N,K]; NN: A[M,K] B[K,N]; TN: A[K,M] B[K,N]."""
+    L.require_gpu(a, b, out, bias, residual)
+    _rowmajor(a, "A")
+    _rowmajor(b, "B")
+    if a.dtype != BF16 or b.dtype != BF16:
+        raise TypeError("gemm operands must be bf16")
+    if form == L.GEMM_NT:
+        M, K = a.shape
+        N, K2 = b.shape
+    elif form == L.GEMM_NN:
+        M, K = a.shape
+        K2, N = b.shape
+    else:
+        K, M = a.shape
+        K2, N = b.shape
+    if K != K2:
+        raise ValueError(f"gemm: inner dimensions differ ({K} vs {K2})")
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    _rowmajor(out, "C")
+    if tuple(out.shape) != (M, N):
+        raise ValueError(f"gemm: output shape {tuple(out.shape)} != {(M, N)}")
+    if bias is not None and (bias.dtype != F32 or bias.numel() != N or not bias.is_contiguous()):
+        raise ValueError("gemm: bias must be contiguous fp32 [N]")
+    ldr = 0
+    if residual is not None:
+        _rowmajor(residual, "residual")
+        if residual.dtype != out.dtype or tuple(residual.shape) != (M, N):
+            raise ValueError("gemm: residual must match the output's shape and dtype")
+        ldr = residual.stride(0)
+    L.call(
+        "mi355_gemm_bf16", form, M, N, K, L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), L.ptr(out), out.stride(0),
+        L.dt_code(out.dtype), L.ptr(bias), L.ptr(residual), ldr, L.EPI_GELU if gelu else L.EPI_NONE,
+    )
+    return out
+
+
+def colsum(x, out=None, accumulate=False):
+    L.require_gpu(x)
+    _rowmajor(x, "X")
+    if out is None:
+        out = torch.empty(x.shape[1], dtype=F32, device=x.device)
+    L.call("mi355_colsum_bf16", x.shape[0], x.shape[1], L.ptr(x), x.stride(0), L.ptr(out), int(accumulate))
+    return out
+
+
+def rmsnorm_fwd(x2d, w, eps=1e-6, want_rstd=True):
+    L.require_gpu(x2d, w)
+    if x2d.dtype != BF16 or w.dtype != BF16 or not x2d.is_contiguous() or w.numel() != x2d.shape[1]:
+        raise ValueError("rmsnorm_fwd: x must be contiguous bf16 [rows,width], w bf16 [width]")
+    y = torch.empty_like(x2d)
+    rstd = torch.empty(x2d.shape[0], dtype=F32, device=x2d.device) if want_rstd else None
+    L.call("mi355_rmsnorm_fwd", x2d.shape[0], x2d.shape[1], L.ptr(x2d), L.ptr(w), L.ptr(y), L.ptr(rstd), eps)
+    return y, rstd
+
+
+def rmsnorm_bwd(x2d, w, rstd, dy, dres=None):
+    """Returns (dx [+ dres], dw_fp32)."""
+    L.require_gpu(x2d, w, rstd, dy, dres)
+    rows, width = x2d.shape
+    if not (dy.is_contiguous() and dy.shape == x2d.shape and dy.dtype == BF16):
+        raise ValueError("rmsnorm_bwd: dy must be contiguous bf16 like x")
+    if dres is not None and not (dres.is_contiguous() and dres.shape == x2d.shape and dres.dtype == BF16):
+        raise ValueError("rmsnorm_bwd: dres must be contiguous bf16 like x")
+    dx = torch.empty_like(x2d)
+    parts = min(NORM_PARTS, (rows + 3) // 4)
+    part = torch.empty((parts, width), dtype=F32, device=x2d.device)
+    L.call("mi355_rmsnorm_bwd", rows, width, L.ptr(x2d), L.ptr(w), L.ptr(rstd), L.ptr(dy), L.ptr(dres), L.ptr(dx), L.ptr(part), parts)
+    dw = torch.empty(width, dtype=F32, device=x2d.device)
+    L.call("mi355_reduce_rows_f32", parts, width, L.ptr(part), L.ptr(dw), L.DT_F32, 0)
+    return dx, dw
+
+
+def qknorm_rope_fwd(qkv, qw, kw, cos, sin, pos, Hq, Hkv, D, eps=1e-6):
+    L.require_gpu(qkv, qw, kw, cos, sin, pos)
+    tokens = qkv.shape[0]
+    if not (qkv.is_contiguous() and qkv.dtype == BF16 and qkv.shape[1] == (Hq + 2 * Hkv) * D):
+        raise ValueError("qknorm_rope_fwd: qkv must be contiguous bf16 [tokens,(Hq+2Hkv)*D]")
+    if not (cos.dtype == F32 and sin.dtype == F32 and cos.is_contiguous() and sin.is_contiguous() and cos.shape[1] == D):
+        raise ValueError("qknorm_rope_fwd: cos/sin must be contiguous fp32 [ctx,D]")
+    if not (pos.dtype == torch.int32 and pos.numel() == tokens and pos.is_contiguous()):
+        raise ValueError("qknorm_rope_fwd: pos must be contiguous int32 [tokens]")
+    q = torch.empty((tokens, Hq * D), dtype=BF16, device=qkv.device)
+    k = torch.empty((tokens, Hkv * D), dtype=BF16, device=qkv.device)
+    rstd = torch.empty((tokens, Hq + Hkv), dtype=F32, device=qkv.device)
+    L.call("mi355_qknorm_rope_fwd", tokens, Hq, Hkv, D, L.ptr(qkv), L.ptr(qw), L.ptr(kw), L.ptr(cos), L.ptr(sin), L.ptr(pos), L.ptr(q), L.ptr(k), L.ptr(rstd), eps)
+    return q, k, rstd
+
+
+def qknorm_rope_bwd(qkv, qw, kw, cos, sin, pos, rstd, dq, dk, dqkv, Hq, Hkv, D):
+    """Writes d(qkv)[:, :(Hq+Hkv)*D] into dqkv (the V third is left to the caller); returns (dqw_f32, dkw_f32)."""
+    L.require_gpu(qkv, dq, dk, dqkv)
+    tokens = qkv.shape[0]
+    for t, n in ((dq, Hq * D), (dk, Hkv * D)):
+        if not (t.is_contiguous() and t.dtype == BF16 and tuple(t.shape) == (tokens, n)):
+            raise ValueError("qknorm_rope_bwd: dq/dk must be contiguous bf16 [tokens,H*D]")
+    if not (dqkv.is_contiguous() and dqkv.shape == qkv.shape and dqkv.dtype == BF16):
+        raise ValueError("qknorm_rope_bwd: dqkv must be contiguous bf16 like qkv")
+    parts = min(NORM_PARTS, (tokens * (Hq + Hkv) + 3) // 4)
+    part = torch.empty((parts, 2 * D), dtype=F32, device=qkv.device)
+    L.call("mi355_qknorm_rope_bwd", tokens, Hq, Hkv, D, L.ptr(qkv), L.ptr(qw), L.ptr(kw), L.ptr(cos), L.ptr(sin), L.ptr(pos), L.ptr(rstd), L.ptr(dq), L.ptr(dk), L.ptr(dqkv), L.ptr(part), parts)
+    dw = torch.empty(2 * D, dtype=F32, device=qkv.device)
+    L.call("mi355_reduce_rows_f32", parts, 2 * D, L.ptr(part), L.ptr(dw), L.DT_F32, 0)
+    return dw[:D], dw[D:]
+
+
+def swiglu_fwd(gu, F):
+    L.require_gpu(gu)
+    if not (gu.is_contiguous() and gu.dtype == BF16 and gu.shape[1] == 2 * F):
+        raise ValueError("swiglu_fwd: gu must be contiguous bf16 [tokens,2F]")
+    a = torch.empty((gu.shape[0], F), dtype=BF16, device=gu.device)
+    L.call("mi355_swiglu_fwd", gu.shape[0], F, L.ptr(gu), L.ptr(a))
+    return a
+
+
+def swiglu_bwd(gu, da, F):
+    L.require_gpu(gu, da)
+    if not (da.is_contiguous() and da.dtype == BF16 and tuple(da.shape) == (gu.shape[0], F)):
+        raise ValueError("swiglu_bwd: da must be contiguous bf16 [tokens,F]")
+    dgu = torch.empty_like(gu)
+    L.call("mi355_swiglu_bwd", gu.shape[0], F, L.ptr(gu), L.ptr(da), L.ptr(dgu))
+    return dgu
+
+
+def _check_attn_operand(t, name, tokens, width):
+    if t.dtype != BF16 or t.dim() != 2 or t.stride(1) != 1 or t.shape[0] != tokens or t.shape[1] != width:
+        raise ValueError(f"attention: {name} must be bf16 [tokens={tokens}, {width}] with unit inner stride, got {tuple(t.shape)} {t.stride()}")
+
+
+def attn_fwd(q, k, v, B, S, Hq, Hkv, D, key_mask=None, causal=True, scale=None):
+    """q [B*S,Hq*D], k/v [B*S,Hkv*D] (row-strided views allowed).  Returns (o [B*S,Hq*D], lse fp32 [B,Hq,S])."""
+    L.require_gpu(q, k, v, key_mask)
+    _check_attn_operand(q, "q", B * S, Hq * D)
+    _check_attn_operand(k, "k", B * S, Hkv * D)
+    _check_attn_operand(v, "v", B * S, Hkv * D)
+    if key_mask is not None and not (key_mask.dtype == torch.uint8 and key_mask.is_contiguous() and tuple(key_mask.shape) == (B, S)):
+        raise ValueError("attention: key_mask must be contiguous uint8 [B,S]")
+    o = torch.empty((B * S, Hq * D), dtype=BF16, device=q.device)
+    lse = torch.empty((B, Hq, S), dtype=F32, device=q.device)
+    scale = D ** -0.5 if scale is None else scale
+    L.call("mi355_attn_fwd", B, S, Hq, Hkv, D, L.ptr(q), q.stride(0), L.ptr(k), k.stride(0), L.ptr(v), v.stride(0), L.ptr(o), o.stride(0), L.ptr(lse), L.ptr(key_mask), int(causal), scale)
+    return o, lse
+
+
+def attn_bwd(q, k, v, o, do, lse, B, S, Hq, Hkv, D, dq, dk, dv, key_mask=None, causal=True, scale=None):
+    """dq/dk/dv are caller-provided (possibly row-strided) destinations."""
+    L.require_gpu(q, k, v, o, do, lse, dq, dk, dv)
+    for t, n, w in ((q, "q", Hq), (k, "k", Hkv), (v, "v", Hkv), (o, "o", Hq), (do, "do", Hq), (dq, "dq", Hq), (dk, "dk", Hkv), (dv, "dv", Hkv)):
+        _check_attn_operand(t, n, B * S, w * D)
+    if not (lse.dtype == F32 and lse.is_contiguous() and tuple(lse.shape) == (B, Hq, S)):
+        raise ValueError("attention: lse must be contiguous fp32 [B,Hq,S]")
+    delta = torch.empty_like(lse)
+    scale = D ** -0.5 if scale is None else scale
+    L.call(
+        "mi355_attn_bwd", B, S, Hq, Hkv, D, L.ptr(q), q.stride(0), L.ptr(k), k.stride(0), L.ptr(v), v.stride(0), L.ptr(o), o.stride(0),
+        L.ptr(do), do.stride(0), L.ptr(lse), L.ptr(delta), L.ptr(dq), dq.stride(0), L.ptr(dk), dk.stride(0), L.ptr(dv), dv.stride(0),
+        L.ptr(key_mask), int(causal), scale,
+    )
+
+
+def cross_entropy(logits2d, targets, want_grad, grad_scale=None, inplace=True):
+    """Row CE with ignore_index=-100 on bf16 logits.  Returns (loss_rows fp32, dlogits or None).  grad_scale: fp32 [1] device."""
+    L.require_gpu(logits2d, targets)
+    _rowmajor(logits2d, "logits")
+    if logits2d.dtype != BF16 or targets.dtype != torch.int64 or targets.numel() != logits2d.shape[0] or not targets.is_contiguous():
+        raise ValueError("cross_entropy: logits bf16 [rows,V], targets contiguous int64 [rows]")
+    rows, V = logits2d.shape
+    loss_rows = torch.empty(rows, dtype=F32, device=logits2d.device)
+    dl = None
+    if want_grad:
+        dl = logits2d if inplace else torch.empty_like(logits2d)
+        if dl.stride(0) != logits2d.stride(0):
+            raise ValueError("cross_entropy: dlogits must share the logits row pitch")
+    L.call("mi355_cross_entropy", rows, V, L.ptr(logits2d), logits2d.stride(0), L.ptr(targets), L.ptr(loss_rows), L.ptr(dl), L.ptr(grad_scale))
+    return loss_rows, dl
+
+
+def ce_finalize(loss_rows, targets):
+    out3 = torch.empty(3, dtype=F32, device=loss_rows.device)
+    L.call("mi355_ce_finalize", loss_rows.numel(), L.ptr(loss_rows), L.ptr(targets), L.ptr(out3))
+    return out3
+
+
+def embedding_fwd(ids, table, out=None):
+    L.require_gpu(ids, table)
+    if ids.dtype != torch.int64 or table.dtype != BF16 or not table.is_contiguous():
+        raise ValueError("embedding_fwd: ids int64, table contiguous bf16")
+    flat = ids.reshape(-1).contiguous()
+    width = table.shape[1]
+    if out is None:
+        out = torch.empty((flat.numel(), width), dtype=BF16, device=table.device)
+    _rowmajor(out, "out")
+    L.call("mi355_embedding_fwd", flat.numel(), width, table.shape[0], L.ptr(flat), L.ptr(table), L.ptr(out), out.stride(0))
+    return out
+
+
+def embedding_bwd(ids, dout, dtable_f32):
+    L.require_gpu(ids, dout, dtable_f32)
+    flat = ids.reshape(-1).contiguous()
+    _rowmajor(dout, "dout")
+    if dtable_f32.dtype != F32 or not dtable_f32.is_contiguous() or dout.shape[0] != flat.numel():
+        raise ValueError("embedding_bwd: accumulator must be contiguous fp32 and dout must have one row per id")
+    L.call("mi355_embedding_bwd", flat.numel(), dout.shape[1], dtable_f32.shape[0], L.ptr(flat), L.ptr(dout), dout.stride(0), L.ptr(dtable_f32))
+
+
+def copy2d(src, dst):
+    """dst[r,:] = src[r,:] for 2-D views with unit inner stride (bit-exact)."""
+    L.require_gpu(src, dst)
+    _rowmajor(src, "src")
+    _rowmajor(dst, "dst")
+    if src.shape != dst.shape or src.dtype != dst.dtype:
+        raise ValueError("copy2d: shape/dtype mismatch")
+    es = src.element_size()
+    L.call("mi355_copy2d", src.shape[0], src.shape[1] * es, L.ptr(src), src.stride(0) * es, L.ptr(dst), dst.stride(0) * es)
+    return dst
+
+
+def patchify(img, patch, out_dtype=BF16):
+    L.require_gpu(img)
+    if img.dtype != F32 or img.dim() != 4 or not img.is_contiguous():
+        raise ValueError("patchify: image must be contiguous fp32 NCHW")
+    B, C, H, W = img.shape
+    rows = torch.empty((B * (H // patch) * (W // patch), C * patch * patch), dtype=out_dtype, device=img.device)
+    L.call("mi355_patchify", B, C, H, W, patch, L.ptr(img), L.ptr(rows), L.dt_code(out_dtype))
+    return rows
+
+
+def layernorm_fwd(x2d, scale, shift, out_dtype=BF16, eps=1e-5, want_stats=False):
+    L.require_gpu(x2d, scale, shift)
+    if x2d.dtype != F32 or not x2d.is_contiguous() or scale.dtype != F32 or shift.dtype != F32:
+        raise ValueError("layernorm_fwd: x/scale/shift must be fp32, x contiguous")
+    y = torch.empty(x2d.shape, dtype=out_dtype, device=x2d.device)
+    mean = rsig = None
+    if want_stats:
+        mean = torch.empty(x2d.shape[0], dtype=F32, device=x2d.device)
+        rsig = torch.empty_like(mean)
+    L.call("mi355_layernorm_fwd", x2d.shape[0], x2d.shape[1], L.ptr(x2d), L.ptr(scale), L.ptr(shift), L.ptr(y), L.dt_code(out_dtype), L.ptr(mean), L.ptr(rsig), eps)
+    return (y, mean, rsig) if want_stats else y
+
+
+def cast(src, dtype):
+    L.require_gpu(src)
+    if src.dtype == dtype:
+        return src
+    src = src.contiguous()
+    dst = torch.empty(src.shape, dtype=dtype, device=src.device)
+    L.call("mi355_cast", src.numel(), L.ptr(src), L.dt_code(src.dtype), L.ptr(dst), L.dt_code(dtype))
+    return dst
+
+
+def vit_embed_assemble(proj, cls, pos, B, S, width):
+    L.require_gpu(proj, cls, pos)
+    out = torch.empty((B, S, width), dtype=F32, device=proj.device)
+    L.call("mi355_vit_embed_assemble", B, S, width, L.ptr(proj), L.ptr(cls), L.ptr(pos), L.ptr(out))
+    return out
+
+
+def sumsq_into(x, acc):
+    L.require_gpu(x, acc)
+    x = x if x.is_contiguous() else x.contiguous()
+    L.call("mi355_sumsq", x.numel(), L.ptr(x), L.dt_code(x.dtype), L.ptr(acc))
+
+
+def clip_scale_(x, sumsq, max_norm):
+    L.require_gpu(x, sumsq)
+    if not x.is_contiguous():
+        raise ValueError("clip_scale_: tensor must be contiguous")
+    L.call("mi355_clip_scale", x.numel(), L.ptr(x), L.dt_code(x.dtype), L.ptr(sumsq), float(max_norm))
+
+
+def add_f32_to_bf16(a_f32, b_bf16, dst_bf16):
+    L.require_gpu(a_f32, dst_bf16)
+    L.call("mi355_add_f32_to_bf16", a_f32.numel(), L.ptr(a_f32), L.ptr(b_bf16), L.ptr(dst_bf16))

@@ -1,0 +1,69 @@
+"""CPU-side checks of the C-ABI boundary: the library loads without a GPU and exports exactly what
+include/mi355_vlm.h declares; the product path refuses CPU tensors instead of falling back."""
+
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "mi355_vlm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(?:int|const char\*)\s+(mi355_\w+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    from llm_quest_amd import _lib
+
+    declared = set(header_functions())
+    bound = set(_lib.SIGNATURES) | {"mi355_last_error", "mi355_abi_version"}
+    assert declared == bound, f"header-only: {declared - bound}; binding-only: {bound - declared}"
+
+
+def test_library_loads_and_exports_every_symbol():
+    from llm_quest_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    lib = _lib.load()
+    for name in header_functions():
+        assert hasattr(lib, name), name
+    assert lib.mi355_abi_version() == 1
+
+
+def test_argument_counts_match_header():
+    from llm_quest_amd import _lib
+
+    text = open(os.path.join(ROOT, "include", "mi355_vlm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    for name, argtypes in _lib.SIGNATURES.items():
+        m = re.search(r"\b" + name + r"\s*\((.*?)\)\s*;", text, flags=re.S)
+        assert m, name
+        nargs = len([a for a in m.group(1).split(",") if a.strip()])
+        assert nargs == len(argtypes) + 0, f"{name}: header has {nargs} args, binding {len(argtypes)}"
+
+
+def test_host_side_validation_rejects_bad_calls_without_touching_the_gpu():
+    """Errors are returned (not faults): the ABI validates before launching."""
+    from llm_quest_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    lib = _lib.load()
+    rc = lib.mi355_gemm_bf16(7, 1, 1, 8, None, 8, None, 8, None, 8, 0, None, None, 0, 0, None)
+    assert rc != 0 and b"bad form" in lib.mi355_last_error()
+    rc = lib.mi355_attn_fwd(1, 4, 2, 1, 96, None, 0, None, 0, None, 0, None, 0, None, None, 1, 1.0, None)
+    assert rc != 0 and b"head_dim" in lib.mi355_last_error()
+
+
+def test_no_cpu_fallback():
+    from llm_quest_amd import kernels
+
+    x = torch.zeros(4, 1024, dtype=torch.bfloat16)
+    w = torch.ones(1024, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        kernels.rmsnorm_fwd(x, w)
