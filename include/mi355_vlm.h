@@ -86,6 +86,10 @@ int mi355_qknorm_rope_bwd(int64_t tokens, int Hq, int Hkv, int D, const void* qk
 int mi355_swiglu_fwd(int64_t tokens, int F, const void* gu, void* a, void* stream);
 int mi355_swiglu_bwd(int64_t tokens, int F, const void* gu, const void* da, void* dgu, void* stream);
 
+/* Exact (erf) GELU on a bf16 tensor and its backward (nn.GELU() in ViTAdapter, vit_engine.py:50). n % 8 == 0. */
+int mi355_gelu_fwd(int64_t n, const void* x, void* y, void* stream);
+int mi355_gelu_bwd(int64_t n, const void* x, const void* dy, void* dx, void* stream);
+
 /* Flash-style attention, token-major operands, never materialising SxS (replaces qwen3_attention.py:121-146,
  * vit_attention.py:74-86).  q [B*S, Hq*D] ld=ldq, k/v [B*S, Hkv*D] ld=ldk/ldv, o [B*S, Hq*D] ld=ldo, bf16;
  * lse fp32 [B,Hq,S] (natural-log-sum-exp of scaled, masked scores).  D in {64,128}.
@@ -138,6 +142,8 @@ int mi355_vit_embed_assemble(int B, int S, int width, const float* patch_proj, c
 int mi355_sumsq(int64_t n, const void* x, int dtype, float* out, void* stream);
 /* x *= min(1, max_norm / (sqrt(*sumsq) + 1e-6))  (torch.nn.utils.clip_grad_norm_ semantics) */
 int mi355_clip_scale(int64_t n, void* x, int dtype, const float* sumsq, float max_norm, void* stream);
+/* y = x * (*scale), bf16, scale is a DEVICE fp32 scalar (autograd's incoming grad_output, no host sync) */
+int mi355_scale_bf16(int64_t n, const void* x, const float* scale, void* y, void* stream);
 /* fp32 -> bf16 with add: dst_bf16 = bf16(a_f32 + (b_bf16 or 0)) */
 int mi355_add_f32_to_bf16(int64_t n, const float* a, const void* b_bf16, void* dst_bf16, void* stream);
 

@@ -46,6 +46,9 @@ SIGNATURES = {
     "mi355_sumsq": [_L, _P, _I, _P, _P],
     "mi355_clip_scale": [_L, _P, _I, _P, _F, _P],
     "mi355_add_f32_to_bf16": [_L, _P, _P, _P, _P],
+    "mi355_scale_bf16": [_L, _P, _P, _P, _P],
+    "mi355_gelu_fwd": [_L, _P, _P, _P],
+    "mi355_gelu_bwd": [_L, _P, _P, _P, _P],
 }
 
 _lib = None

@@ -77,6 +77,34 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(int64_t tokens, int F, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ GELU (erf)
+// nn.GELU() on a bf16 tensor (ViTAdapter, vit_engine.py:50): a = bf16(gelu(x));  backward dx = da * gelu'(x)
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(int64_t n, const bf16_t* __restrict__ x, bf16_t* __restrict__ y) {
+    const int64_t nv = n >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+        float v[8];
+        unpack8(*reinterpret_cast<const u32x4*>(x + i * 8), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * 0.5f * (1.0f + erff(v[e] * 0.70710678118654752440f));
+        *reinterpret_cast<u32x4*>(y + i * 8) = pack8(v);
+    }
+}
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(int64_t n, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx) {
+    const int64_t nv = n >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+        float v[8], g[8];
+        unpack8(*reinterpret_cast<const u32x4*>(x + i * 8), v);
+        unpack8(*reinterpret_cast<const u32x4*>(dy + i * 8), g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float cdf = 0.5f * (1.0f + erff(v[e] * 0.70710678118654752440f));
+            const float pdf = 0.3989422804014327f * __expf(-0.5f * v[e] * v[e]);
+            g[e] *= cdf + v[e] * pdf;
+        }
+        *reinterpret_cast<u32x4*>(dx + i * 8) = pack8(g);
+    }
+}
+
 // ----------------------------------------------------------------------------------------- cross entropy
 // One 256-thread block per row.  Pass 1: online max / sum-exp over V (16-byte loads).  Pass 2 (optional):
 // dlogits = (exp(l - lse) - onehot) * scale, written bf16 (in place allowed).  The row (V*2 bytes ~ 300 KB)
@@ -280,6 +308,19 @@ __global__ __launch_bounds__(256) void add_f32_to_bf16_kernel(int64_t n, const f
         d[i] = f2bf(a[i] + (b ? bf2f(b[i]) : 0.f));
 }
 
+__global__ __launch_bounds__(256) void scale_bf16_kernel(int64_t n, const bf16_t* __restrict__ x, const float* __restrict__ scale, bf16_t* __restrict__ y) {
+    const float sc = *scale;
+    const int64_t nv = n >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+        float v[8];
+        unpack8(*reinterpret_cast<const u32x4*>(x + i * 8), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= sc;
+        *reinterpret_cast<u32x4*>(y + i * 8) = pack8(v);
+    }
+    for (int64_t i = (nv << 3) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = f2bf(bf2f(x[i]) * sc);
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void sumsq_kernel(int64_t n, const void* __restrict__ x, float* __restrict__ out) {
     __shared__ float red[4];
@@ -321,6 +362,19 @@ extern "C" int mi355_swiglu_bwd(int64_t tokens, int F, const void* gu, const voi
     MI355_REQUIRE(tokens > 0 && F > 0 && (F & 7) == 0 && gu && da && dgu, "mi355_swiglu_bwd: bad arguments");
     hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(tokens * (F >> 3), 256)), dim3(256), 0, STREAM, tokens, F, (const bf16_t*)gu, (const bf16_t*)da, (bf16_t*)dgu);
     MI355_LAUNCH_CHECK("mi355_swiglu_bwd");
+    return 0;
+}
+
+extern "C" int mi355_gelu_fwd(int64_t n, const void* x, void* y, void* stream) {
+    MI355_REQUIRE(n > 0 && (n & 7) == 0 && x && y, "mi355_gelu_fwd: n must be a positive multiple of 8");
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid_for(n >> 3, 256)), dim3(256), 0, STREAM, n, (const bf16_t*)x, (bf16_t*)y);
+    MI355_LAUNCH_CHECK("mi355_gelu_fwd");
+    return 0;
+}
+extern "C" int mi355_gelu_bwd(int64_t n, const void* x, const void* dy, void* dx, void* stream) {
+    MI355_REQUIRE(n > 0 && (n & 7) == 0 && x && dy && dx, "mi355_gelu_bwd: n must be a positive multiple of 8");
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n >> 3, 256)), dim3(256), 0, STREAM, n, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx);
+    MI355_LAUNCH_CHECK("mi355_gelu_bwd");
     return 0;
 }
 
@@ -401,6 +455,13 @@ extern "C" int mi355_add_f32_to_bf16(int64_t n, const float* a, const void* b_bf
     MI355_REQUIRE(n > 0 && a && dst_bf16, "mi355_add_f32_to_bf16: bad arguments");
     hipLaunchKernelGGL(add_f32_to_bf16_kernel, dim3(grid_for(n, 256)), dim3(256), 0, STREAM, n, a, (const bf16_t*)b_bf16, (bf16_t*)dst_bf16);
     MI355_LAUNCH_CHECK("mi355_add_f32_to_bf16");
+    return 0;
+}
+
+extern "C" int mi355_scale_bf16(int64_t n, const void* x, const float* scale, void* y, void* stream) {
+    MI355_REQUIRE(n > 0 && x && scale && y, "mi355_scale_bf16: bad arguments");
+    hipLaunchKernelGGL(scale_bf16_kernel, dim3(grid_for(n >> 3, 256)), dim3(256), 0, STREAM, n, (const bf16_t*)x, scale, (bf16_t*)y);
+    MI355_LAUNCH_CHECK("mi355_scale_bf16");
     return 0;
 }
 

@@ -75,8 +75,8 @@ def rmsnorm_fwd(x2d, w, eps=1e-6, want_rstd=True):
     return y, rstd
 
 
-def rmsnorm_bwd(x2d, w, rstd, dy, dres=None):
-    """Returns (dx [+ dres], dw_fp32)."""
+def rmsnorm_bwd(x2d, w, rstd, dy, dres=None, dw_out=None, dw_accumulate=False):
+    """Returns (dx [+ dres], dw).  dw goes to ``dw_out`` (bf16/fp32, optionally accumulated) or a new fp32 tensor."""
     L.require_gpu(x2d, w, rstd, dy, dres)
     rows, width = x2d.shape
     if not (dy.is_contiguous() and dy.shape == x2d.shape and dy.dtype == BF16):
@@ -87,8 +87,8 @@ def rmsnorm_bwd(x2d, w, rstd, dy, dres=None):
     parts = min(NORM_PARTS, (rows + 3) // 4)
     part = torch.empty((parts, width), dtype=F32, device=x2d.device)
     L.call("mi355_rmsnorm_bwd", rows, width, L.ptr(x2d), L.ptr(w), L.ptr(rstd), L.ptr(dy), L.ptr(dres), L.ptr(dx), L.ptr(part), parts)
-    dw = torch.empty(width, dtype=F32, device=x2d.device)
-    L.call("mi355_reduce_rows_f32", parts, width, L.ptr(part), L.ptr(dw), L.DT_F32, 0)
+    dw = torch.empty(width, dtype=F32, device=x2d.device) if dw_out is None else dw_out
+    L.call("mi355_reduce_rows_f32", parts, width, L.ptr(part), L.ptr(dw), L.dt_code(dw.dtype), int(dw_accumulate and dw_out is not None))
     return dx, dw
 
 
@@ -292,3 +292,31 @@ def clip_scale_(x, sumsq, max_norm):
 def add_f32_to_bf16(a_f32, b_bf16, dst_bf16):
     L.require_gpu(a_f32, dst_bf16)
     L.call("mi355_add_f32_to_bf16", a_f32.numel(), L.ptr(a_f32), L.ptr(b_bf16), L.ptr(dst_bf16))
+
+
+def scale_bf16(x, scale_f32, out=None):
+    """out = x * scale (device fp32 scalar tensor)."""
+    L.require_gpu(x, scale_f32)
+    if x.dtype != BF16 or not x.is_contiguous() or scale_f32.dtype != F32:
+        raise ValueError("scale_bf16: x contiguous bf16, scale fp32 device scalar")
+    out = torch.empty_like(x) if out is None else out
+    L.call("mi355_scale_bf16", x.numel(), L.ptr(x), L.ptr(scale_f32), L.ptr(out))
+    return out
+
+
+def gelu_fwd(x):
+    L.require_gpu(x)
+    if x.dtype != BF16 or not x.is_contiguous() or x.numel() % 8:
+        raise ValueError("gelu_fwd: contiguous bf16 with numel % 8 == 0")
+    y = torch.empty_like(x)
+    L.call("mi355_gelu_fwd", x.numel(), L.ptr(x), L.ptr(y))
+    return y
+
+
+def gelu_bwd(x, dy):
+    L.require_gpu(x, dy)
+    if dy.dtype != BF16 or not dy.is_contiguous() or dy.shape != x.shape:
+        raise ValueError("gelu_bwd: dy must be contiguous bf16 like x")
+    dx = torch.empty_like(x)
+    L.call("mi355_gelu_bwd", x.numel(), L.ptr(x), L.ptr(dy), L.ptr(dx))
+    return dx

@@ -1,0 +1,149 @@
+"""ViT -> LLM adapter and the ViT train/eval loop -- API of ``llm_quest/multimodal/vision_transformer/vit_engine.py``."""
+
+import torch
+
+from llm_quest_amd import _lib as L
+from llm_quest_amd import kernels as K
+from llm_quest_amd import ops
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+class _AdapterFn(torch.autograd.Function):
+    """simple: y = x W^T (+b);  ffn: y = gelu(x W0^T (+b0)) W3^T (+b3).  bf16, same rounding points as the reference
+    (Linear output rounded to bf16, then nn.GELU on the bf16 tensor)."""
+
+    @staticmethod
+    def forward(ctx, x, mod, keep, *params):
+        arena = ops.arena_for(mod)
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1]).contiguous()
+        lins = mod._linears()
+        bias = [None if l.bias is None else K.cast(l.bias.detach(), F32) for l in lins]
+        if len(lins) == 1:
+            y = K.gemm(L.GEMM_NT, x2, lins[0].weight, bias=bias[0])
+            saved = (x2,)
+        else:
+            y1 = K.gemm(L.GEMM_NT, x2, lins[0].weight, bias=bias[0])
+            a = K.gelu_fwd(y1)
+            y = K.gemm(L.GEMM_NT, a, lins[1].weight, bias=bias[1])
+            saved = (x2, y1, a)
+        ctx.mod, ctx.saved, ctx.shp, ctx.need_dx = mod, saved if keep else None, shp, x.requires_grad
+        return y.view(*shp[:-1], y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        mod = ctx.mod
+        arena = ops.arena_for(mod)
+        lins = mod._linears()
+        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+
+        def bias_grad(lin, g):
+            if lin.bias is not None and lin.bias.requires_grad:
+                view, acc = arena.grad_target(lin.bias)
+                K.add_f32_to_bf16(K.colsum(g), view if acc else None, view)
+
+        dx = None
+        if len(lins) == 1:
+            (x2,) = ctx.saved
+            ops._wgrad(arena, lins[0].weight, None, dy2, x2)
+            bias_grad(lins[0], dy2)
+            if ctx.need_dx:
+                dx = K.gemm(L.GEMM_NN, dy2, lins[0].weight)
+        else:
+            x2, y1, a = ctx.saved
+            ops._wgrad(arena, lins[1].weight, None, dy2, a)
+            bias_grad(lins[1], dy2)
+            da = K.gemm(L.GEMM_NN, dy2, lins[1].weight)
+            dy1 = K.gelu_bwd(y1, da)
+            ops._wgrad(arena, lins[0].weight, None, dy1, x2)
+            bias_grad(lins[0], dy1)
+            if ctx.need_dx:
+                dx = K.gemm(L.GEMM_NN, dy1, lins[0].weight)
+        ctx.saved = None
+        hook = getattr(mod, "_grad_ready", None)
+        if hook is not None:
+            hook(mod)
+        return (None if dx is None else dx.view(ctx.shp), None, None) + (None,) * len(mod._param_list)
+
+
+class ViTAdapter(torch.nn.Module):
+    """Connector from ViT hidden size to the LLM embedding size (reference: vit_engine.py:9-59); keys ``adapter.weight``
+    or ``adapter.{0,3}.weight``."""
+
+    def __init__(self, vit_d_out, llm_d_in, adapter_type="simple", hidden_size_factor=4, bias=False, dropout=0.0, dtype=torch.float32):
+        super().__init__()
+        if adapter_type == "simple":
+            self.adapter = torch.nn.Linear(vit_d_out, llm_d_in, bias=bias, dtype=dtype)
+        elif adapter_type == "ffn":
+            self.adapter = torch.nn.Sequential(
+                torch.nn.Linear(vit_d_out, vit_d_out * hidden_size_factor, bias=bias, dtype=dtype),
+                torch.nn.GELU(),
+                torch.nn.Dropout(dropout) if dropout > 0.0 else torch.nn.Identity(),
+                torch.nn.Linear(vit_d_out * hidden_size_factor, llm_d_in, bias=bias, dtype=dtype),
+            )
+        else:
+            raise ValueError(f"Invalid adapter type: {adapter_type}")
+        self._dropout_p = dropout if adapter_type == "ffn" else 0.0
+
+    def _linears(self):
+        return [self.adapter] if isinstance(self.adapter, torch.nn.Linear) else [self.adapter[0], self.adapter[3]]
+
+    def forward(self, x):
+        L.require_gpu(x)
+        w = self._linears()[0].weight
+        if w.dtype != BF16:
+            raise TypeError("the HIP adapter computes in bf16: construct ViTAdapter(..., dtype=torch.bfloat16) (as the VLM step needs to feed Qwen3)")
+        if self.training and self._dropout_p > 0:
+            raise NotImplementedError("adapter dropout is not implemented on the HIP path")
+        if x.dtype != BF16:
+            x = K.cast(x.contiguous(), BF16)  # the reference casts the fp32 ViT states before a bf16 adapter too
+        if not hasattr(self, "_param_list"):
+            object.__setattr__(self, "_param_list", list(self.parameters()))
+        return _AdapterFn.apply(x, self, torch.is_grad_enabled(), *self._param_list)
+
+
+def vit_training_eval_loop(train_loader, val_loader, model, optimizer, num_epoch, lr_scheduler, eval_freq, eval_iter, device, use_amp=True):
+    """Signature of the reference loop (vit_engine.py:62-147).  Training the ViT needs its backward kernels, which are
+    not part of this round (the VLM step keeps the ViT frozen); evaluation helpers below work."""
+    raise NotImplementedError("ViT training (BASELINE config 2) needs the ViT backward kernels: planned, see DESIGN.md 'next'")
+
+
+class ViT:
+    """Evaluation helpers with the reference's static-method API (vit_engine.py:150-265)."""
+
+    @staticmethod
+    @torch.no_grad()
+    def accuracy_loader(dataloader, model, device, num_batches=None):
+        model.eval()
+        n = len(dataloader) if num_batches is None else min(num_batches, len(dataloader))
+        if n == 0:
+            return float("nan")
+        correct = total = 0
+        for i, (x, y) in enumerate(dataloader):
+            if i >= n:
+                break
+            pred = model(x.to(device)).argmax(dim=-1)
+            correct += int((pred == y.to(device)).sum())
+            total += y.numel()
+        return correct / total
+
+    @staticmethod
+    @torch.no_grad()
+    def calc_loss_loader(dataloader, model, device, num_batches=None):
+        n = len(dataloader) if num_batches is None else min(num_batches, len(dataloader))
+        if n == 0:
+            return float("nan")
+        tot = 0.0
+        for i, (x, y) in enumerate(dataloader):
+            if i >= n:
+                break
+            tot += float(torch.nn.functional.cross_entropy(model(x.to(device)).float(), y.to(device)))
+        return tot / n
+
+    @staticmethod
+    def evaluate(train_loader, val_loader, model, eval_iter, device):
+        model.eval()
+        out = (ViT.calc_loss_loader(train_loader, model, device, eval_iter), ViT.calc_loss_loader(val_loader, model, device, eval_iter))
+        model.train()
+        return out

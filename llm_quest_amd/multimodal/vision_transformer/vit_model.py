@@ -1,0 +1,79 @@
+"""ViT model on HIP kernels -- API of ``llm_quest/multimodal/vision_transformer/vit_model.py``."""
+
+import torch
+import torch.nn as nn
+
+from llm_quest_amd import _lib as L
+from llm_quest_amd import kernels as K
+from llm_quest_amd.multimodal.vision_transformer.vit_attention import bf16_cached, refuse_training
+from llm_quest_amd.multimodal.vision_transformer.vit_transformer_block import LayerNorm, ViTTransformerBlock
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+class PatchEmbedding2D(nn.Module):
+    """Non-overlapping patches -> embeddings, CLS token prepended (reference: vit_model.py:19-89).
+
+    ``conv_proj`` is kept as an ``nn.Conv2d`` so the state_dict keys/shapes are the reference's, but it is never
+    called: the patches are gathered by a coalesced im2row kernel (bit-exact index map, K ordered (c, i, j)) and
+    projected by the MFMA GEMM against the (emb, C*P*P) view of the conv weight.
+    """
+
+    def __init__(self, img_width, img_height, patch_size, num_channels, emb_dim):
+        super().__init__()
+        assert img_width % patch_size == 0, f"Image width {img_width} not divisible by patch size {patch_size}"
+        assert img_height % patch_size == 0, f"Image height {img_height} not divisible by patch size {patch_size}"
+        self.img_width, self.img_height, self.patch_size = img_width, img_height, patch_size
+        self.num_patches = (img_width * img_height) // patch_size**2
+        self.conv_proj = nn.Conv2d(num_channels, emb_dim, kernel_size=(patch_size, patch_size), stride=(patch_size, patch_size), padding=0, bias=True)
+        self.cls_token = nn.Parameter(torch.randn(1, 1, emb_dim))
+
+    def project(self, x):
+        """(b, c, h, w) fp32 -> patch projections fp32 [b*num_patches, emb] (bias added, no CLS)."""
+        assert x.shape[2] == self.img_width and x.shape[3] == self.img_height, (
+            f"Input image shape {x.shape} does not match expected shape {self.img_width}x{self.img_height}"
+        )
+        rows = K.patchify(x.contiguous().to(F32), self.patch_size, out_dtype=BF16)
+        w = bf16_cached(self, "wconv", [self.conv_proj.weight])
+        return K.gemm(L.GEMM_NT, rows, w, bias=self.conv_proj.bias.detach(), out_dtype=F32)
+
+    def forward(self, x):
+        L.require_gpu(x)
+        refuse_training(self, "PatchEmbedding2D")
+        b = x.shape[0]
+        proj = self.project(x).view(b, self.num_patches, -1)
+        return torch.cat([self.cls_token.detach().expand(b, -1, -1), proj], dim=1)
+
+
+class ViTModel(nn.Module):
+    """Patch embed + learned positions + pre-LN encoder + final LN (+ class head) (reference: vit_model.py:92-160)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.patch_embedding = PatchEmbedding2D(cfg["img_width"], cfg["img_height"], cfg["patch_size"], cfg["num_channels"], cfg["emb_dim"])
+        self.pos_embedding = nn.Parameter(torch.randn(1, self.patch_embedding.num_patches + 1, cfg["emb_dim"]))
+        self.dropout = nn.Dropout(cfg["drop_rate"])
+        self.transformer_blocks = nn.ModuleList([ViTTransformerBlock(cfg) for _ in range(cfg["n_layers"])])
+        self.final_ln = LayerNorm(cfg["emb_dim"])
+        self.classifier = nn.Linear(cfg["emb_dim"], cfg["num_classes"])
+
+    def forward(self, x, output_hidden_states=False):
+        L.require_gpu(x)
+        refuse_training(self, "ViTModel")
+        if self.training and self.dropout.p > 0:
+            raise NotImplementedError("dropout is not implemented on the HIP path; use eval() or drop_rate=0")
+        b = x.shape[0]
+        pe = self.patch_embedding
+        s, d = pe.num_patches + 1, self.pos_embedding.shape[-1]
+        proj = pe.project(x)
+        # CLS row + positional embedding in one pass (vit_model.py:86-87,145)
+        h = K.vit_embed_assemble(proj, pe.cls_token.detach().reshape(-1).contiguous(), self.pos_embedding.detach().reshape(s, d).contiguous(), b, s, d)
+        h2 = h.view(b * s, d)
+        for blk in self.transformer_blocks:
+            h2 = blk.run(h2, b, s)
+        if output_hidden_states:
+            return self.final_ln.normalize(h2, F32).view(b, s, d)
+        cls_rows = h2.view(b, s, d)[:, 0].contiguous()
+        cls_n = self.final_ln.normalize(cls_rows, BF16)
+        wc = bf16_cached(self, "wcls", [self.classifier.weight])
+        return K.gemm(L.GEMM_NT, cls_n, wc, bias=self.classifier.bias.detach(), out_dtype=F32)

@@ -1,0 +1,131 @@
+"""Host logic on the CPU: GPT-2 plumbing model (BASELINE config 1), engine loops, LR schedule, VLM generic path,
+and the gradient arena bookkeeping (on CPU tensors, no kernels)."""
+
+import pytest
+import torch
+
+from conftest import sub_dict
+from oracle.gen_golden import TINY_GPT
+
+
+def test_gpt2_plumbing_matches_reference(golden):
+    from llm_quest_amd.gpt.gpt_model import GPTModel
+
+    t = golden("gpt2_tiny")
+    m = GPTModel(dict(TINY_GPT)).eval()
+    sd = sub_dict(t, "sd.")
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert all(k.endswith(".mask") for k in missing) and not unexpected
+    with torch.no_grad():
+        assert torch.allclose(m(t["in.ids"]), t["out.logits"], atol=1e-5)
+        assert torch.allclose(m(t["in.ids"], attn_mask=t["in.key_mask"].bool()), t["out.logits_masked"], atol=1e-5)
+        emb = m.emb_dict(t["in.ids"]) + m.pos_emb_dict(torch.arange(16))
+        assert torch.allclose(m(emb, input_embedded=True), t["out.logits"], atol=1e-5)
+        last = m(t["in.ids"], attn_mask=t["in.key_mask"].bool(), last_token_only=True)
+        assert last.shape == (4, 256)
+
+
+def test_config1_shape_gpt2_small_cpu_forward():
+    """BASELINE config 1: GPT-2-small forward on CPU, batch 4 x seq 128, random tokens (plumbing)."""
+    from llm_quest_amd.config import gpt2_config_creator
+    from llm_quest_amd.gpt.gpt_model import GPTModel
+
+    torch.manual_seed(123)
+    cfg = gpt2_config_creator("gpt_s")
+    cfg["n_layers"] = 2  # keep the CPU suite fast; width/heads/vocab are the real ones
+    m = GPTModel(cfg).eval()
+    x = torch.randint(0, 50257, (4, 128))
+    with torch.no_grad():
+        y = m(x)
+    assert y.shape == (4, 128, 50257) and torch.isfinite(y).all()
+
+
+def test_lr_scheduler_matches_reference_trace(golden):
+    from llm_quest_amd.engine import LearningRateScheduler
+
+    t = golden("per_op")
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+    sch = LearningRateScheduler(opt, total_steps=10, init_lr=1e-5, peak_lr=1e-3, warmup_steps=3, min_lr=1e-4, decay="cosine")
+    trace = []
+    for s in range(10):
+        sch.step(s)
+        trace.append(sch.current_lr)
+        assert opt.param_groups[0]["lr"] == sch.current_lr
+    assert torch.allclose(torch.tensor(trace, dtype=torch.float64), t["lr.trace"], rtol=1e-12, atol=0)
+    with pytest.raises(ValueError):
+        LearningRateScheduler(opt, 10, init_lr=1e-3, peak_lr=1e-3, warmup_steps=2)
+    with pytest.raises(ValueError):
+        LearningRateScheduler(opt, 10, init_lr=1e-5, peak_lr=1e-3, min_lr=1e-4)
+
+
+def _tiny_gpt():
+    from llm_quest_amd.gpt.gpt_model import GPTModel
+
+    torch.manual_seed(0)
+    return GPTModel(dict(TINY_GPT))
+
+
+def test_training_eval_loop_cpu_semantics():
+    """accumulation with a ragged last window, eval at step 1 and every eval_freq, returns two lists."""
+    from llm_quest_amd.engine import LearningRateScheduler, global_loss, training_eval_loop
+
+    m = _tiny_gpt()
+    g = torch.Generator().manual_seed(1)
+    data = [(torch.randint(0, 256, (2, 16), generator=g), torch.randint(0, 256, (2, 16), generator=g)) for _ in range(5)]
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
+    sch = LearningRateScheduler(opt, total_steps=10, init_lr=1e-5, peak_lr=1e-3, warmup_steps=2)
+    tr, va = training_eval_loop(data, data[:2], m, opt, 1, sch, eval_freq=2, eval_iter=1, device=torch.device("cpu"), accumulation_steps=2, use_amp=False)
+    assert len(tr) == 2 and len(va) == 2  # 3 optimizer steps: evals at step 1 and 2
+    with pytest.raises(AttributeError):
+        global_loss(torch.zeros(1, 2, 3), torch.zeros(1, 2, dtype=torch.long), model=None)  # upstream quirk: model required
+
+
+def test_vlm_generic_path_on_cpu():
+    """The reference's own wiring (ViT-ish encoder -> adapter -> GPT-2 with input_embedded) through our engine."""
+    from llm_quest_amd.multimodal.vlm_engine import get_embeddings, vlm_loss, vlm_step_loss
+
+    class FakeViT(torch.nn.Module):
+        def forward(self, x, output_hidden_states=False):
+            return x.flatten(2).transpose(1, 2)[:, :5, :8].contiguous()
+
+    llm = _tiny_gpt()
+    adapter = torch.nn.Linear(8, 64, bias=False)
+    img = torch.randn(2, 8, 3, 3)
+    ids = torch.randint(0, 256, (2, 7))
+    tm = torch.ones(2, 7, dtype=torch.bool)
+    tm[0, 5:] = False
+    loss = vlm_step_loss(FakeViT(), llm, adapter, img, ids, tm, hf_vit_model=False)
+    # same thing written out as the reference does
+    ve = adapter(FakeViT()(img))
+    x = torch.cat([ve, get_embeddings(ids, llm)], dim=1)
+    cm = torch.cat([torch.ones(2, 5, dtype=torch.bool), tm], dim=1)
+    ref = vlm_loss(llm(x, attn_mask=cm, input_embedded=True), ids, tm, 5)
+    assert torch.allclose(loss, ref)
+    loss.backward()
+    assert adapter.weight.grad is not None
+
+
+def test_param_arena_views_and_grad_targets():
+    from llm_quest_amd.arena import ParamArena
+
+    lin_a, lin_b, lin_c = torch.nn.Linear(8, 16, bias=False), torch.nn.Linear(8, 8, bias=False), torch.nn.Linear(8, 8, bias=False)
+    named = [("a", lin_a.weight), ("b", lin_b.weight), ("c", lin_c.weight)]
+    before = [p.detach().clone() for _, p in named]
+    ar = ParamArena(named)
+    assert ar.ensure() is True and ar.ensure() is False
+    for (_, p), b in zip(named, before):
+        assert torch.equal(p, b)
+    fused = ar.fused(lin_a.weight, lin_c.weight)
+    assert fused.shape == (32, 8) and fused.data_ptr() == lin_a.weight.data_ptr()
+    assert torch.equal(fused[16:24], lin_b.weight)
+    view, acc = ar.grad_target(lin_a.weight, lin_c.weight)
+    assert view.shape == (32, 8) and acc is False and lin_b.weight.grad.data_ptr() == view[16:24].data_ptr()
+    view2, acc2 = ar.grad_target(lin_b.weight)
+    assert acc2 is True
+    for p in (lin_a.weight, lin_b.weight, lin_c.weight):
+        p.grad = None  # zero_grad(set_to_none=True)
+    _, acc3 = ar.grad_target(lin_b.weight)
+    assert acc3 is False
+    # .to()/rebinding is detected and the arena is rebuilt around the new storage
+    lin_b.weight.data = lin_b.weight.data.clone()
+    assert ar.ensure() is True and ar.fused(lin_a.weight, lin_c.weight).shape == (32, 8)
