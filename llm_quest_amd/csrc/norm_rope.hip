@@ -83,39 +83,69 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_generic(int64_t rows, int wid
 }
 
 // dx = rstd * (g - xhat * mean(g * xhat)) with g = w*dy, xhat = x*rstd;  dx += dres (residual-stream grad);
-// dw partial[part][c] += dy*xhat summed over the rows this block owns (one partial row per block).
+// dw partial[block][c] = sum over the block's rows of dy*xhat.
+// Fast path (width == 512*VPL): one wave per row, the row stays in registers (x, dy read ONCE), dw accumulated in
+// registers across the rows a wave owns and merged through LDS at the end.
+template <int VPL>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_rowreg_kernel(int64_t rows, int width, const bf16_t* __restrict__ x,
+                                                                 const bf16_t* __restrict__ w, const float* __restrict__ rstd,
+                                                                 const bf16_t* __restrict__ dy, const bf16_t* __restrict__ dres,
+                                                                 bf16_t* __restrict__ dx, float* __restrict__ dw_partial) {
+    __shared__ float dw_lds[512 * VPL];
+    const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < width; i += 256) dw_lds[i] = 0.f;
+    __syncthreads();
+    float wf[VPL][8], dwacc[VPL][8];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        unpack8(*reinterpret_cast<const u32x4*>(w + (i * 64 + lane) * 8), wf[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dwacc[i][e] = 0.f;
+    }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wv_id; row < rows; row += (int64_t)gridDim.x * 4) {
+        float xv[VPL][8], gv[VPL][8];
+        float dot = 0.f;
+        const float r = rstd[row];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            unpack8(*reinterpret_cast<const u32x4*>(x + row * width + (i * 64 + lane) * 8), xv[i]);
+            unpack8(*reinterpret_cast<const u32x4*>(dy + row * width + (i * 64 + lane) * 8), gv[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                dwacc[i][e] += gv[i][e] * xv[i][e] * r;
+                gv[i][e] *= wf[i][e];
+                dot += gv[i][e] * xv[i][e];
+            }
+        }
+        dot = wave_sum(dot) * r * r / (float)width;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            float rs[8] = {0, 0, 0, 0, 0, 0, 0, 0}, o[8];
+            if (dres) unpack8(*reinterpret_cast<const u32x4*>(dres + row * width + (i * 64 + lane) * 8), rs);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = r * (gv[i][e] - xv[i][e] * dot) + rs[e];
+            *reinterpret_cast<u32x4*>(dx + row * width + (i * 64 + lane) * 8) = pack8(o);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(&dw_lds[(i * 64 + lane) * 8 + e], dwacc[i][e]);
+    __syncthreads();
+    for (int i = threadIdx.x; i < width; i += 256) dw_partial[(int64_t)blockIdx.x * width + i] = dw_lds[i];
+}
+
+// generic width (multiple of 8): three sweeps over the row
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(int64_t rows, int width, const bf16_t* __restrict__ x,
                                                           const bf16_t* __restrict__ w, const float* __restrict__ rstd,
                                                           const bf16_t* __restrict__ dy, const bf16_t* __restrict__ dres,
                                                           bf16_t* __restrict__ dx, float* __restrict__ dw_partial) {
-    extern __shared__ __attribute__((aligned(16))) float dw_lds[];  // [width]
+    extern __shared__ __attribute__((aligned(16))) float dw_lds_dyn[];  // [width]
     const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
     const int nvec = width >> 3;
-    for (int i = threadIdx.x; i < width; i += 256) dw_lds[i] = 0.f;
+    for (int i = threadIdx.x; i < width; i += 256) dw_lds_dyn[i] = 0.f;
     __syncthreads();
-    const int64_t row0 = (int64_t)blockIdx.x * 4 + wv_id;
-    for (int i0 = 0; i0 < nvec; i0 += 64) {  // column slab of 512 elements: keeps dw accumulators in registers
-        const int i = i0 + lane;
-        float dwacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        float wf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (i < nvec) unpack8(*reinterpret_cast<const u32x4*>(w + i * 8), wf);
-        for (int64_t row = row0; row < rows; row += (int64_t)gridDim.x * 4) {
-            if (i < nvec) {
-                float xv[8], dyv[8];
-                unpack8(*reinterpret_cast<const u32x4*>(x + row * width + i * 8), xv);
-                unpack8(*reinterpret_cast<const u32x4*>(dy + row * width + i * 8), dyv);
-                const float r = rstd[row];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) dwacc[e] += dyv[e] * xv[e] * r;
-            }
-        }
-        if (i < nvec) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) atomicAdd(&dw_lds[i * 8 + e], dwacc[e]);
-        }
-    }
-    // dx: a second sweep per row (row data is L2-hot from the sweep above when width <= 512*..; HBM-bound anyway)
-    for (int64_t row = row0; row < rows; row += (int64_t)gridDim.x * 4) {
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wv_id; row < rows; row += (int64_t)gridDim.x * 4) {
         const float r = rstd[row];
         float dot = 0.f;
         for (int i = lane; i < nvec; i += 64) {
@@ -124,7 +154,10 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(int64_t rows, int widt
             unpack8(*reinterpret_cast<const u32x4*>(dy + row * width + i * 8), dyv);
             unpack8(*reinterpret_cast<const u32x4*>(w + i * 8), wf);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) dot += dyv[e] * wf[e] * xv[e];
+            for (int e = 0; e < 8; ++e) {
+                dot += dyv[e] * wf[e] * xv[e];
+                atomicAdd(&dw_lds_dyn[i * 8 + e], dyv[e] * xv[e] * r);
+            }
         }
         dot = wave_sum(dot) * r * r / (float)width;
         for (int i = lane; i < nvec; i += 64) {
@@ -140,15 +173,22 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(int64_t rows, int widt
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < width; i += 256) dw_partial[(int64_t)blockIdx.x * width + i] = dw_lds[i];
+    for (int i = threadIdx.x; i < width; i += 256) dw_partial[(int64_t)blockIdx.x * width + i] = dw_lds_dyn[i];
 }
 
+// out[n] (+)= sum_p partial[p][n]: 64 columns per block, the 4 waves split the parts
 __global__ __launch_bounds__(256) void reduce_rows_kernel(int parts, int64_t n, const float* __restrict__ partial,
                                                           void* __restrict__ out, int out_dtype, int accumulate) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + c;
     float s = 0.f;
-    for (int p = 0; p < parts; ++p) s += partial[(int64_t)p * n + i];
+    if (i < n)
+        for (int p = rl; p < parts; p += 4) s += partial[(int64_t)p * n + i];
+    red[rl][c] = s;
+    __syncthreads();
+    if (rl != 0 || i >= n) return;
+    s = red[0][c] + red[1][c] + red[2][c] + red[3][c];
     if (out_dtype == MI355_DT_BF16) {
         bf16_t* o = reinterpret_cast<bf16_t*>(out);
         if (accumulate) s += bf2f(o[i]);
@@ -161,45 +201,75 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(int parts, int64_t n, 
 }
 
 // --------------------------------------------------------------------------- fused QK-RMSNorm + RoPE
-// One wave per (token, head) for D=128: lane holds elements 2*lane, 2*lane+1?  RoPE pairs element i with i+D/2,
-// so lane l (< D/2/ ... ) keeps x[l] and x[l + D/2]: D=128 -> lanes 0..63 hold (x[l], x[l+64]).
-// For D=64 lanes 0..31 are active (half wave).  Reference rounding points:
-//   n  = bf16( float(x) * rstd * float(w) )                      (PytorchRMSNorm)
-//   y1 = bf16( bf16(cos_b*n1) + bf16(sin_b*(-n2)) ),  y2 = bf16( bf16(cos_b*n2) + bf16(sin_b*n1) )   (RoPE.apply in bf16)
+// RoPE pairs element i with i + D/2, so a lane owns 4 consecutive elements of the first half and the matching 4 of the
+// second half (two 8-byte loads); D/8 lanes cover a head and a wave processes 64/(D/8) heads of one token at a time
+// (4 for D=128, 8 for D=64).  Reference rounding points:
+//   n  = bf16( float(x) * rstd * float(w) )                                                     (PytorchRMSNorm)
+//   y1 = bf16( bf16(cos_b*n1) + bf16(sin_b*(-n2)) ),  y2 = bf16( bf16(cos_b*n2) + bf16(sin_b*n1) )  (RoPE.apply in bf16)
+__device__ __forceinline__ void unpack4(const u32x2 v, float (&f)[4]) {
+    f[0] = __uint_as_float(v[0] << 16); f[1] = __uint_as_float(v[0] & 0xffff0000u);
+    f[2] = __uint_as_float(v[1] << 16); f[3] = __uint_as_float(v[1] & 0xffff0000u);
+}
+__device__ __forceinline__ u32x2 pack4(const float (&f)[4]) { return (u32x2){pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3])}; }
+
+template <int D>
+struct QkGeom {
+    static constexpr int HALF = D / 2, LPH = HALF / 4, HPW = 64 / LPH;
+};
+
+template <int LPH>
+__device__ __forceinline__ float head_sum(float v) {
+#pragma unroll
+    for (int o = LPH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(int64_t tokens, int Hq, int Hkv, const bf16_t* __restrict__ qkv,
                                                               const bf16_t* __restrict__ qw, const bf16_t* __restrict__ kw,
                                                               const float* __restrict__ cosT, const float* __restrict__ sinT,
                                                               const int32_t* __restrict__ pos, bf16_t* __restrict__ qo,
                                                               bf16_t* __restrict__ ko, float* __restrict__ rstd, float eps) {
-    constexpr int HALF = D / 2;
+    using G = QkGeom<D>;
     const int lane = threadIdx.x & 63;
+    const int sub = lane / G::LPH, i = (lane % G::LPH) * 4;
     const int H = Hq + Hkv;
+    const int groups = (H + G::HPW - 1) / G::HPW;
     const int64_t ld = (int64_t)(Hq + 2 * Hkv) * D;
-    const int64_t total = tokens * H;
-    const bool act = lane < HALF;
-    const int l = act ? lane : 0;
+    const int64_t total = tokens * groups;
     for (int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); item < total; item += (int64_t)gridDim.x * 4) {
-        const int64_t t = item / H;
-        const int h = (int)(item - t * H);
-        const bf16_t* src = qkv + t * ld + (int64_t)h * D;
-        const bf16_t* wgt = h < Hq ? qw : kw;
-        const float x1 = bf2f(src[l]), x2 = bf2f(src[l + HALF]);
-        float ss = act ? x1 * x1 + x2 * x2 : 0.f;
-        ss = wave_sum(ss);
+        const int64_t t = item / groups;
+        const int h = (int)(item - t * groups) * G::HPW + sub;
+        const bool valid = h < H;
+        const int hh = valid ? h : 0;
+        const bf16_t* src = qkv + t * ld + (int64_t)hh * D;
+        const bf16_t* wgt = hh < Hq ? qw : kw;
+        float x1[4], x2[4], w1[4], w2[4];
+        unpack4(*reinterpret_cast<const u32x2*>(src + i), x1);
+        unpack4(*reinterpret_cast<const u32x2*>(src + G::HALF + i), x2);
+        unpack4(*reinterpret_cast<const u32x2*>(wgt + i), w1);
+        unpack4(*reinterpret_cast<const u32x2*>(wgt + G::HALF + i), w2);
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ss += x1[e] * x1[e] + x2[e] * x2[e];
+        ss = head_sum<G::LPH>(ss);
         const float r = rsqrtf(ss / (float)D + eps);
-        const float n1 = rbf(x1 * r * bf2f(wgt[l])), n2 = rbf(x2 * r * bf2f(wgt[l + HALF]));
-        const int p = pos[t];
-        const float c1 = rbf(cosT[(int64_t)p * D + l]), s1 = rbf(sinT[(int64_t)p * D + l]);
-        const float c2 = rbf(cosT[(int64_t)p * D + l + HALF]), s2 = rbf(sinT[(int64_t)p * D + l + HALF]);
-        const float y1 = rbf(c1 * n1) + rbf(s1 * (-n2));
-        const float y2 = rbf(c2 * n2) + rbf(s2 * n1);
-        bf16_t* dst = h < Hq ? qo + t * (int64_t)Hq * D + (int64_t)h * D : ko + t * (int64_t)Hkv * D + (int64_t)(h - Hq) * D;
-        if (act) {
-            dst[l] = f2bf(y1);
-            dst[l + HALF] = f2bf(y2);
+        const int64_t p = pos[t];
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(cosT + p * D + i), s1 = *reinterpret_cast<const f32x4*>(sinT + p * D + i);
+        const f32x4 c2 = *reinterpret_cast<const f32x4*>(cosT + p * D + G::HALF + i), s2 = *reinterpret_cast<const f32x4*>(sinT + p * D + G::HALF + i);
+        float y1[4], y2[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float n1 = rbf(x1[e] * r * w1[e]), n2 = rbf(x2[e] * r * w2[e]);
+            y1[e] = rbf(rbf(c1[e]) * n1) + rbf(rbf(s1[e]) * (-n2));
+            y2[e] = rbf(rbf(c2[e]) * n2) + rbf(rbf(s2[e]) * n1);
         }
-        if (lane == 0) rstd[t * H + h] = r;
+        if (valid) {
+            bf16_t* dst = h < Hq ? qo + t * (int64_t)Hq * D + (int64_t)h * D : ko + t * (int64_t)Hkv * D + (int64_t)(h - Hq) * D;
+            *reinterpret_cast<u32x2*>(dst + i) = pack4(y1);
+            *reinterpret_cast<u32x2*>(dst + G::HALF + i) = pack4(y2);
+            if (i == 0) rstd[t * H + h] = r;
+        }
     }
 }
 
@@ -211,53 +281,71 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(int64_t tokens, in
                                                               const int32_t* __restrict__ pos, const float* __restrict__ rstd,
                                                               const bf16_t* __restrict__ dq, const bf16_t* __restrict__ dk,
                                                               bf16_t* __restrict__ dqkv, float* __restrict__ dw_partial) {
-    constexpr int HALF = D / 2;
+    using G = QkGeom<D>;
     __shared__ float dw_lds[2 * D];
     const int lane = threadIdx.x & 63;
+    const int sub = lane / G::LPH, i = (lane % G::LPH) * 4;
     const int H = Hq + Hkv;
+    const int groups = (H + G::HPW - 1) / G::HPW;
     const int64_t ld = (int64_t)(Hq + 2 * Hkv) * D;
-    const int64_t total = tokens * H;
-    const bool act = lane < HALF;
-    const int l = act ? lane : 0;
-    for (int i = threadIdx.x; i < 2 * D; i += 256) dw_lds[i] = 0.f;
+    const int64_t total = tokens * groups;
+    for (int j = threadIdx.x; j < 2 * D; j += 256) dw_lds[j] = 0.f;
     __syncthreads();
-    float dwq1 = 0.f, dwq2 = 0.f, dwk1 = 0.f, dwk2 = 0.f;
+    float dwq1[4] = {0, 0, 0, 0}, dwq2[4] = {0, 0, 0, 0}, dwk1[4] = {0, 0, 0, 0}, dwk2[4] = {0, 0, 0, 0};
     for (int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); item < total; item += (int64_t)gridDim.x * 4) {
-        const int64_t t = item / H;
-        const int h = (int)(item - t * H);
-        const bool isq = h < Hq;
-        const bf16_t* src = qkv + t * ld + (int64_t)h * D;
+        const int64_t t = item / groups;
+        const int h = (int)(item - t * groups) * G::HPW + sub;
+        const bool valid = h < H;
+        const int hh = valid ? h : 0;
+        const bool isq = hh < Hq;
+        const bf16_t* src = qkv + t * ld + (int64_t)hh * D;
         const bf16_t* wgt = isq ? qw : kw;
-        const bf16_t* g = isq ? dq + t * (int64_t)Hq * D + (int64_t)h * D : dk + t * (int64_t)Hkv * D + (int64_t)(h - Hq) * D;
-        const float x1 = bf2f(src[l]), x2 = bf2f(src[l + HALF]);
-        const float w1 = bf2f(wgt[l]), w2 = bf2f(wgt[l + HALF]);
-        const float r = rstd[t * H + h];
-        const int p = pos[t];
-        const float c1 = rbf(cosT[(int64_t)p * D + l]), s1 = rbf(sinT[(int64_t)p * D + l]);
-        const float c2 = rbf(cosT[(int64_t)p * D + l + HALF]), s2 = rbf(sinT[(int64_t)p * D + l + HALF]);
-        const float g1 = bf2f(g[l]), g2 = bf2f(g[l + HALF]);
-        // y1 = c1*n1 - s1*n2 ; y2 = c2*n2 + s2*n1
-        const float dn1 = c1 * g1 + s2 * g2;
-        const float dn2 = c2 * g2 - s1 * g1;
-        const float xh1 = x1 * r, xh2 = x2 * r;
-        float dot = act ? dn1 * w1 * xh1 + dn2 * w2 * xh2 : 0.f;
-        dot = wave_sum(dot) / (float)D;
-        const float dx1 = r * (dn1 * w1 - xh1 * dot), dx2 = r * (dn2 * w2 - xh2 * dot);
-        if (act) {
+        const bf16_t* g = isq ? dq + t * (int64_t)Hq * D + (int64_t)hh * D : dk + t * (int64_t)Hkv * D + (int64_t)(hh - Hq) * D;
+        float x1[4], x2[4], w1[4], w2[4], g1[4], g2[4];
+        unpack4(*reinterpret_cast<const u32x2*>(src + i), x1);
+        unpack4(*reinterpret_cast<const u32x2*>(src + G::HALF + i), x2);
+        unpack4(*reinterpret_cast<const u32x2*>(wgt + i), w1);
+        unpack4(*reinterpret_cast<const u32x2*>(wgt + G::HALF + i), w2);
+        unpack4(*reinterpret_cast<const u32x2*>(g + i), g1);
+        unpack4(*reinterpret_cast<const u32x2*>(g + G::HALF + i), g2);
+        const float r = rstd[t * H + hh];
+        const int64_t p = pos[t];
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(cosT + p * D + i), s1 = *reinterpret_cast<const f32x4*>(sinT + p * D + i);
+        const f32x4 c2 = *reinterpret_cast<const f32x4*>(cosT + p * D + G::HALF + i), s2 = *reinterpret_cast<const f32x4*>(sinT + p * D + G::HALF + i);
+        float dn1[4], dn2[4], xh1[4], xh2[4];
+        float dot = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            // y1 = c1*n1 - s1*n2 ; y2 = c2*n2 + s2*n1
+            dn1[e] = rbf(c1[e]) * g1[e] + rbf(s2[e]) * g2[e];
+            dn2[e] = rbf(c2[e]) * g2[e] - rbf(s1[e]) * g1[e];
+            xh1[e] = x1[e] * r;
+            xh2[e] = x2[e] * r;
+            dot += dn1[e] * w1[e] * xh1[e] + dn2[e] * w2[e] * xh2[e];
+        }
+        dot = head_sum<G::LPH>(dot) / (float)D;
+        if (valid) {
+            float d1[4], d2[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                d1[e] = r * (dn1[e] * w1[e] - xh1[e] * dot);
+                d2[e] = r * (dn2[e] * w2[e] - xh2[e] * dot);
+                if (isq) { dwq1[e] += dn1[e] * xh1[e]; dwq2[e] += dn2[e] * xh2[e]; } else { dwk1[e] += dn1[e] * xh1[e]; dwk2[e] += dn2[e] * xh2[e]; }
+            }
             bf16_t* dst = dqkv + t * ld + (int64_t)h * D;
-            dst[l] = f2bf(dx1);
-            dst[l + HALF] = f2bf(dx2);
-            if (isq) { dwq1 += dn1 * xh1; dwq2 += dn2 * xh2; } else { dwk1 += dn1 * xh1; dwk2 += dn2 * xh2; }
+            *reinterpret_cast<u32x2*>(dst + i) = pack4(d1);
+            *reinterpret_cast<u32x2*>(dst + G::HALF + i) = pack4(d2);
         }
     }
-    if (act) {
-        atomicAdd(&dw_lds[l], dwq1);
-        atomicAdd(&dw_lds[l + HALF], dwq2);
-        atomicAdd(&dw_lds[D + l], dwk1);
-        atomicAdd(&dw_lds[D + l + HALF], dwk2);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        atomicAdd(&dw_lds[i + e], dwq1[e]);
+        atomicAdd(&dw_lds[G::HALF + i + e], dwq2[e]);
+        atomicAdd(&dw_lds[D + i + e], dwk1[e]);
+        atomicAdd(&dw_lds[D + G::HALF + i + e], dwk2[e]);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * D; i += 256) dw_partial[(int64_t)blockIdx.x * 2 * D + i] = dw_lds[i];
+    for (int j = threadIdx.x; j < 2 * D; j += 256) dw_partial[(int64_t)blockIdx.x * 2 * D + j] = dw_lds[j];
 }
 
 // ------------------------------------------------------------------------ ViT LayerNorm (sigma + eps)
@@ -333,8 +421,15 @@ extern "C" int mi355_rmsnorm_bwd(int64_t rows, int width, const void* x, const v
     MI355_REQUIRE(rows > 0 && (width & 7) == 0 && width <= 8192, "mi355_rmsnorm_bwd: bad width %d", width);
     MI355_REQUIRE(x && w && rstd && dy && dx && dw_partial && parts > 0, "mi355_rmsnorm_bwd: null pointer / parts");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(parts), dim3(256), width * sizeof(float), s, rows, width, (const bf16_t*)x,
-                       (const bf16_t*)w, rstd, (const bf16_t*)dy, (const bf16_t*)dres, (bf16_t*)dx, dw_partial);
+    if (width == 1024)
+        hipLaunchKernelGGL(rmsnorm_bwd_rowreg_kernel<2>, dim3(parts), dim3(256), 0, s, rows, width, (const bf16_t*)x,
+                           (const bf16_t*)w, rstd, (const bf16_t*)dy, (const bf16_t*)dres, (bf16_t*)dx, dw_partial);
+    else if (width == 512)
+        hipLaunchKernelGGL(rmsnorm_bwd_rowreg_kernel<1>, dim3(parts), dim3(256), 0, s, rows, width, (const bf16_t*)x,
+                           (const bf16_t*)w, rstd, (const bf16_t*)dy, (const bf16_t*)dres, (bf16_t*)dx, dw_partial);
+    else
+        hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(parts), dim3(256), width * sizeof(float), s, rows, width, (const bf16_t*)x,
+                           (const bf16_t*)w, rstd, (const bf16_t*)dy, (const bf16_t*)dres, (bf16_t*)dx, dw_partial);
     MI355_LAUNCH_CHECK("mi355_rmsnorm_bwd");
     return 0;
 }
@@ -342,7 +437,7 @@ extern "C" int mi355_rmsnorm_bwd(int64_t rows, int width, const void* x, const v
 extern "C" int mi355_reduce_rows_f32(int parts, int64_t n, const float* partial, void* out, int out_dtype, int accumulate,
                                      void* stream) {
     MI355_REQUIRE(parts > 0 && n > 0 && partial && out, "mi355_reduce_rows_f32: bad arguments");
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, parts, n,
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, parts, n,
                        partial, out, out_dtype, accumulate);
     MI355_LAUNCH_CHECK("mi355_reduce_rows_f32");
     return 0;
@@ -353,7 +448,8 @@ extern "C" int mi355_qknorm_rope_fwd(int64_t tokens, int Hq, int Hkv, int D, con
                                      float* rstd, float eps, void* stream) {
     MI355_REQUIRE(D == 128 || D == 64, "mi355_qknorm_rope_fwd: head_dim must be 64 or 128 (got %d)", D);
     MI355_REQUIRE(tokens > 0 && Hq > 0 && Hkv > 0 && qkv && qw && kw && cos && sin && pos && q_out && k_out && rstd, "mi355_qknorm_rope_fwd: bad arguments");
-    const int grid = row_grid(tokens * (Hq + Hkv));
+    const int hpw = D == 128 ? 4 : 8;
+    const int grid = row_grid(tokens * ((Hq + Hkv + hpw - 1) / hpw));
     hipStream_t s = (hipStream_t)stream;
     if (D == 128)
         hipLaunchKernelGGL(qknorm_rope_fwd_kernel<128>, dim3(grid), dim3(256), 0, s, tokens, Hq, Hkv, (const bf16_t*)qkv, (const bf16_t*)qw, (const bf16_t*)kw, cos, sin, pos, (bf16_t*)q_out, (bf16_t*)k_out, rstd, eps);

@@ -1,0 +1,101 @@
+"""world_size-2 data-parallel path on the CPU (gloo): the bucket protocol of llm_quest_amd.ddp.GradSync.
+
+The same code drives RCCL on the GPUs; here the arenas hold CPU tensors, so no HIP kernel is involved -- what is checked
+is the protocol: hooks fire per bucket, every bucket is averaged exactly once per step, tail buckets and never-fired
+owners are flushed in finish_step, parameters are broadcast from rank 0, and the result equals the single-process
+global-batch gradient.
+"""
+
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class _Owner(torch.nn.Module):
+    def __init__(self, seed):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.a = torch.nn.Parameter(torch.randn(16, 8, generator=g))
+        self.b = torch.nn.Parameter(torch.randn(8, generator=g))
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from llm_quest_amd.ddp import GradSync, init_from_env
+    from llm_quest_amd.ops import arena_for
+
+    r, w, _ = init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    owners = [_Owner(100 + rank + i) for i in range(3)]  # different init per rank on purpose
+    tail_owner = _Owner(50 + rank)
+    sync = GradSync(owners, tail_arenas=[arena_for(tail_owner)])
+    sync.broadcast_parameters(owners + [tail_owner])
+    ref0 = _Owner(100)  # rank 0's first owner
+    assert torch.equal(owners[0].a, ref0.a)
+
+    def fake_backward(step):
+        sync.begin_step()
+        for i, m in enumerate(owners[:2]):  # owner 2 never fires -> must be flushed by finish_step
+            ar = arena_for(m)
+            for p in m.parameters():
+                view, acc = ar.grad_target(p)
+                val = torch.full_like(p, float(rank + 1 + i + step))
+                view.copy_(view + val if acc else val)
+            m._grad_ready(m)
+        ar = arena_for(tail_owner)
+        view, acc = ar.grad_target(tail_owner.a)
+        view.copy_(torch.full_like(view, 10.0 * (rank + 1)))
+        sync.finish_step()
+
+    fake_backward(0)
+    expect = lambda i, step: sum(rk + 1 + i + step for rk in range(world)) / world
+    ok = True
+    for i, m in enumerate(owners[:2]):
+        ok &= bool(torch.allclose(m.a.grad, torch.full_like(m.a, expect(i, 0))))
+        ok &= bool(torch.allclose(m.b.grad, torch.full_like(m.b, expect(i, 0))))
+    ok &= owners[2].a.grad is not None and float(owners[2].a.grad.abs().sum()) == 0.0
+    ok &= bool(torch.allclose(tail_owner.a.grad, torch.full_like(tail_owner.a, 10.0 * sum(range(1, world + 1)) / world)))
+    ok &= float(tail_owner.b.grad.abs().sum()) == 0.0
+    # second step after zero_grad(set_to_none=True): buckets are overwritten, not accumulated
+    for m in owners + [tail_owner]:
+        for p in m.parameters():
+            p.grad = None
+    fake_backward(1)
+    ok &= bool(torch.allclose(owners[0].a.grad, torch.full_like(owners[0].a, expect(0, 1))))
+    out.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradsync_world2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]
+
+
+def test_gradsync_single_process_is_a_noop():
+    from llm_quest_amd.ddp import GradSync
+
+    m = _Owner(1)
+    s = GradSync([m])
+    assert s.enabled is False
+    s.begin_step()
+    m._grad_ready(m)
+    s.finish_step()
