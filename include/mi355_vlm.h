@@ -49,10 +49,13 @@ int mi355_abi_version(void);
  * vit_engine.py:43-53, qwen3_model.py:92 and their autograd backward.
  *   out_dtype    MI355_DT_BF16 | MI355_DT_F32 (dtype of C and of `residual`)
  *   bias         fp32 [N] or NULL;  residual  [M,N] with ldr, or NULL (may alias C: accumulate)
+ *   workspace    optional fp32 scratch (16-byte aligned) of workspace_bytes: lets problems with few output tiles
+ *                and a long K (weight gradients) split K over several workgroups (slabs + reduce); NULL = never split.
+ *   tile_hint    0 = choose by shape; 1 = 128x128 tile (4 waves), 2 = 256x256 tile (8 waves)
  * Requirements: K-contiguous dims multiple of 8 elements (16-byte rows); see DESIGN.md.            */
 int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                     int64_t ldb, void* C, int64_t ldc, int out_dtype, const float* bias, const void* residual,
-                    int64_t ldr, int epilogue, void* stream);
+                    int64_t ldr, int epilogue, void* workspace, int64_t workspace_bytes, int tile_hint, void* stream);
 
 /* column sums: out[n] (+)= sum_m X[m,n]  (bias gradients).  X bf16 [M,N] ld=ldx, out fp32 [N]. */
 int mi355_colsum_bf16(int64_t M, int64_t N, const void* X, int64_t ldx, float* out, int accumulate, void* stream);

@@ -1,4 +1,4 @@
-// bf16 MFMA GEMM for gfx950 with fused epilogue (bias / exact GELU / residual-or-accumulate).
+// bf16 MFMA GEMM for gfx950 with fused epilogue (bias / exact GELU / residual-or-accumulate) and split-K.
 //
 // One kernel template covers the three operand forms a Linear layer needs (include/mi355_vlm.h):
 //   NT  y  = x W^T      both operands K-contiguous            -> ds_read_b128 fragments
@@ -6,28 +6,48 @@
 //   TN  dW = dy^T x     A and B K-strided                     -> transposing reads for both
 // so no operand is ever transposed in HBM.
 //
-// Structure (per 256-thread workgroup = 4 waves as 2x2, 128x128 output tile, K-step 64):
+// Structure (tile BM x BN x 64, WM x WN waves, every wave owns (BM/WM) x (BN/WN) outputs as 16x16x32 MFMA tiles):
 //   * HBM -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction), two LDS stages, the
 //     next K-tile's DMA in flight while the current one feeds the MFMAs; one barrier per K-tile.
 //   * The DMA destination is lane-linear, so the bank-conflict swizzle is applied on the per-lane SOURCE
 //     address and again on the fragment read (both-sides rule): row-major-K tiles use 128-B rows with
-//     chunk' = chunk ^ ((row>>1)&7); K-strided tiles use 256-B rows with chunk' = chunk ^ (f(k)<<1).
+//     chunk' = chunk ^ ((row>>1)&7); K-strided tiles use (2*cols)-byte rows with chunk' = chunk ^ (f(k)<<1).
 //   * Out-of-range rows/cols/K are zero-filled by the buffer range check (offset 0x80000000 > num_records),
 //     so any M and any K,N multiple of 8 work without a tail path in the main loop.
-//   * Every wave owns a 64x64 sub-tile = 4x4 mfma_f32_16x16x32_bf16 accumulators (64 VGPRs).
-//   * Epilogue: accumulators -> LDS (fp32) -> row-contiguous 16-B global stores with bias/GELU/residual fused.
+//   * The kernel is LDS-bandwidth-bound at 64x64 per wave (fragment reads + DMA writes ~ MFMA time), so the large
+//     configurations give every wave 128x64 outputs: 25 % fewer fragment bytes and half the DMA bytes per MFMA.
+//   * Epilogue: accumulators -> LDS (fp32, 64x64 at a time per wave) -> row-contiguous 16-B global stores with
+//     bias/GELU/residual fused, or raw fp32 slabs when K is split (few output tiles + long K: weight gradients).
 //   * Workgroup -> tile map: XCD-aware (blocks b and b+8 share an L2) then 8-row super-groups.
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int NTHREADS = 256;
-constexpr int TILE_BYTES = 128 * 64 * 2;        // one operand tile, either orientation: 16 KiB
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;     // A + B
-constexpr int EPI_LD = 68;                      // fp32 row pitch of the epilogue staging (bank-spread, 16-B aligned)
-constexpr int SMEM_BYTES = 4 * 64 * EPI_LD * 4; // 69632 >= 2 stages (65536)
-constexpr unsigned OOB = 0x80000000u;           // beyond num_records (0x7fffffff): load returns zeros
+constexpr int EPI_LD = 68;             // fp32 row pitch of the epilogue staging (bank-spread, 16-B aligned)
+constexpr unsigned OOB = 0x80000000u;  // beyond num_records (0x7fffffff): load returns zeros
+
+// BK_ = K extent of one LDS stage, NS_ = stages of the ring: the DMA of K-tile t+NS-1 is issued while tile t is being
+// multiplied, and the wait in front of the per-tile barrier is a COUNTED vmcnt that leaves the NS-2 youngest tiles in
+// flight (a vmcnt(0) there -- what __syncthreads() emits -- is the ceiling of the simple structure).
+template <int BM_, int BN_, int WM_, int WN_, int BK_, int NS_>
+struct TileCfg {
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = BK_, NS = NS_, NW = WM_ * WN_, NTHREADS = NW * 64;
+    static constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
+    static constexpr int FM = WTM / 16, FN = WTN / 16;  // 16x16 accumulator tiles per wave
+    static constexpr int KK = BK / 32;                  // MFMA k-steps per stage
+    static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    static constexpr int A_PPW = A_BYTES / 1024 / NW, B_PPW = B_BYTES / 1024 / NW;  // DMA pieces per wave per K-tile
+    static constexpr int DMA_PER_TILE = A_PPW + B_PPW;
+    static constexpr int EPI_BYTES = NW * 64 * EPI_LD * 4;
+    static constexpr int SMEM = NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES;
+    static constexpr int MIN_WAVES = (NW == 8) ? 2 : (SMEM <= 80 * 1024 ? 2 : 1);
+    static_assert(BK == 32 || BK == 64, "BK must be 32 or 64");
+    static_assert(WTM % 64 == 0 && WTN % 64 == 0, "wave tile must be a multiple of 64x64");
+    static_assert(A_BYTES % (1024 * NW) == 0 && B_BYTES % (1024 * NW) == 0, "pieces must divide evenly over the waves");
+    static_assert((NS - 2) * DMA_PER_TILE <= 63, "vmcnt field is 6 bits");
+};
+using Cfg128 = TileCfg<128, 128, 2, 2, 64, 2>;      // 68 KiB LDS, 2 workgroups / CU, vmcnt(0) structure
+using Cfg256 = TileCfg<256, 256, 2, 4, 64, 2>;      // 136 KiB LDS, 1 workgroup (8 waves) / CU
 
 struct GemmParams {
     const bf16_t* A;
@@ -37,29 +57,39 @@ struct GemmParams {
     const void* R;
     int64_t M, N, K, lda, ldb, ldc, ldr;
     int tiles_m, tiles_n, epilogue;
+    int ksplit;  // > 1: K is split over ksplit workgroups per tile, each writes an fp32 slab into ws
+    float* ws;   // [ksplit][M][N] fp32
+    int ablate;  // profiling only (tile_hint >> 8): 1 = no DMA after the prologue, 2 = no fragment reads after the first, 4 = no barrier
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 __device__ __forceinline__ int tr_f(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 
-// Per-lane byte offsets (relative to the tile's (row0,k0) corner) of this wave's 4 DMA pieces of one operand tile,
-// plus the K-extent each piece needs for validity.  Non-TR: tile [128 rows][64 k], piece = 8 rows.
-template <bool TR>
-__device__ __forceinline__ void piece_offsets(int wave, int lane, int64_t ld, int64_t rows_left, unsigned (&voff)[4],
-                                              int (&kneed)[4]) {
+// swizzle of a row-major-K image: 128-B rows (BK 64): chunk ^ ((row>>1)&7); 64-B rows (BK 32): chunk ^ ((-(row>>2))&3)
+template <int BKc>
+__device__ __forceinline__ int swz_rowk(int chunk, int row) {
+    return BKc == 64 ? chunk ^ ((row >> 1) & 7) : chunk ^ ((0 - (row >> 2)) & 3);
+}
+
+// Per-lane byte offsets (relative to the tile's corner) of this wave's DMA pieces of one operand tile, plus the
+// K-extent each piece needs for validity.  Non-TR: tile [EXT rows][BK k]; TR: tile [BK k][EXT cols] (2*EXT-byte rows).
+template <bool TR, int EXT, int BKc, int PPW>
+__device__ __forceinline__ void piece_offsets(int wave, int lane, int64_t ld, int64_t ext_left, unsigned (&voff)[PPW], int (&kneed)[PPW]) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int pi = wave * 4 + j;
+    for (int j = 0; j < PPW; ++j) {
+        const int pi = wave * PPW + j;
         if constexpr (!TR) {
-            const int r = 8 * pi + (lane >> 3);
-            const int c = (lane & 7) ^ ((r >> 1) & 7);
-            voff[j] = (r < rows_left) ? (unsigned)(r * ld * 2 + c * 16) : OOB;
+            constexpr int CH = BKc * 2 / 16, RPP = 64 / CH;  // chunks per row, rows per 1-KiB piece
+            const int r = pi * RPP + lane / CH;
+            const int c = swz_rowk<BKc>(lane % CH, r);
+            voff[j] = (r < ext_left) ? (unsigned)(r * ld * 2 + c * 16) : OOB;
             kneed[j] = c * 8;  // valid iff kneed < K - k0
         } else {
-            const int kr = 4 * pi + (lane >> 4);
-            const int c = (lane & 15) ^ (tr_f(kr) << 1);
-            voff[j] = (c * 8 < rows_left) ? (unsigned)(kr * ld * 2 + c * 16) : OOB;  // rows_left = cols left here
+            constexpr int CH = EXT * 2 / 16, RPP = 64 / CH;
+            const int kr = pi * RPP + lane / CH;
+            const int c = (lane % CH) ^ (tr_f(kr) << 1);
+            voff[j] = (c * 8 < ext_left) ? (unsigned)(kr * ld * 2 + c * 16) : OOB;
             kneed[j] = kr;
         }
     }
@@ -71,38 +101,51 @@ __device__ __forceinline__ void dma_piece(const void* base, unsigned voff, char*
 }
 
 // fragment of a row-major-K tile: 16 rows starting at r0, k-step kk (32 wide)
+template <int BKc>
 __device__ __forceinline__ bf16x8 frag_rowk(const char* tile, int r0, int kk, int lane) {
     const int r = r0 + (lane & 15);
     const int c = kk * 4 + (lane >> 4);
-    return *reinterpret_cast<const bf16x8*>(tile + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+    return *reinterpret_cast<const bf16x8*>(tile + r * (BKc * 2) + (swz_rowk<BKc>(c, r) << 4));
 }
 
-// fragment of a K-strided tile [64 k][128 cols]: 16 cols starting at c0, k-step kk, via two transposing reads
+// fragment of a K-strided tile [BK k][EXT cols]: 16 cols starting at c0, k-step kk, via two transposing reads
+template <int EXT>
 __device__ __forceinline__ bf16x8 frag_tr(const char* tile, int c0, int kk, int lane) {
+    constexpr int ROWB = EXT * 2;
     const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
     const int f = q | ((g & 1) << 2);
     const int chunk = ((c0 >> 3) + (p >> 1)) ^ (f << 1);
     const int row = kk * 32 + 8 * g + q;
-    const char* a0 = tile + row * 256 + (chunk << 4) + (p & 1) * 8;
+    const char* a0 = tile + row * ROWB + (chunk << 4) + (p & 1) * 8;
     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a0));
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a0 + 4 * 256));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a0 + 4 * ROWB));
     bf16x8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return r;
 }
 
-template <bool A_TR, bool B_TR, int OUT_DT>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else static_assert(N == 0, "add the immediate");
+}
+
+template <class T, bool A_TR, bool B_TR, int OUT_DT>
+__global__ __launch_bounds__(T::NTHREADS, T::MIN_WAVES) void gemm_bf16_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[T::SMEM];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    // ---- workgroup -> tile: XCD chunking, then 8-row super-groups --------------------------------------
+    // ---- workgroup -> (K split, tile): XCD chunking, then 8-row super-groups ----------------------------
     const int nwg = p.tiles_m * p.tiles_n;
+    const int split = blockIdx.x / nwg;
     int pid;
     {
-        const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        const int b = blockIdx.x - split * nwg, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
         pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     }
     const int GROUP_M = 8;
@@ -111,13 +154,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) {
     const int gsz = min(p.tiles_m - first_m, GROUP_M);
     const int tm = first_m + (pid % in_group) % gsz;
     const int tn = (pid % in_group) / gsz;
-    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+    const int64_t m0 = (int64_t)tm * T::BM, n0 = (int64_t)tn * T::BN;
 
     // ---- DMA plan -------------------------------------------------------------------------------------
-    unsigned voffA[4], voffB[4];
-    int kneedA[4], kneedB[4];
-    piece_offsets<A_TR>(wave, lane, p.lda, p.M - m0, voffA, kneedA);
-    piece_offsets<B_TR>(wave, lane, p.ldb, p.N - n0, voffB, kneedB);
+    unsigned voffA[T::A_PPW], voffB[T::B_PPW];
+    int kneedA[T::A_PPW], kneedB[T::B_PPW];
+    constexpr int BK = T::BK;
+    piece_offsets<A_TR, T::BM, BK, T::A_PPW>(wave, lane, p.lda, p.M - m0, voffA, kneedA);
+    piece_offsets<B_TR, T::BN, BK, T::B_PPW>(wave, lane, p.ldb, p.N - n0, voffB, kneedB);
     const bf16_t* baseA = A_TR ? p.A + m0 : p.A + m0 * p.lda;
     const bf16_t* baseB = B_TR ? p.B + n0 : p.B + n0 * p.ldb;
     const int64_t stepA = A_TR ? (int64_t)BK * p.lda : BK;
@@ -127,128 +171,268 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) {
         const int64_t krem = p.K - (int64_t)t * BK;
         const bf16_t* pa = baseA + t * stepA;
         const bf16_t* pb = baseB + t * stepB;
-        char* dst = smem + stage * STAGE_BYTES + wave * 4096;
+        char* dA = smem + stage * T::STAGE + wave * T::A_PPW * 1024;
+        char* dB = smem + stage * T::STAGE + T::A_BYTES + wave * T::B_PPW * 1024;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dma_piece(pa, kneedA[j] < krem ? voffA[j] : OOB, dst + j * 1024);
+        for (int j = 0; j < T::A_PPW; ++j) dma_piece(pa, kneedA[j] < krem ? voffA[j] : OOB, dA + j * 1024);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dma_piece(pb, kneedB[j] < krem ? voffB[j] : OOB, dst + TILE_BYTES + j * 1024);
+        for (int j = 0; j < T::B_PPW; ++j) dma_piece(pb, kneedB[j] < krem ? voffB[j] : OOB, dB + j * 1024);
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[T::FM][T::FN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < T::FM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < T::FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int wr0 = (wave >> 1) * 64, wc0 = (wave & 1) * 64;
-    const int nt = (int)((p.K + BK - 1) / BK);
+    const int wr0 = (wave / T::WN) * T::WTM, wc0 = (wave % T::WN) * T::WTN;
+    const int nt_all = (int)((p.K + BK - 1) / BK);
+    const int per = (nt_all + p.ksplit - 1) / p.ksplit;
+    const int t0 = split * per;
+    const int nt = min(nt_all, t0 + per);
 
-    issue_tile(0, 0);
-    for (int t = 0; t < nt; ++t) {
-        // tile t landed (every wave drains its own DMA) and everyone is done reading the other stage
-        __syncthreads();
-        if (t + 1 < nt) issue_tile(t + 1, (t + 1) & 1);
-        const char* sA = smem + (t & 1) * STAGE_BYTES;
-        const char* sB = sA + TILE_BYTES;
+    // ---- main loop: 4 phases per K-tile = (k-step kk, half of the wave's rows mh); the fragments of phase p+1 are read
+    // from LDS while the MFMAs of phase p run (two register sets for the A half, two for B), so the matrix pipe is not
+    // idle during fragment reads.  The per-tile barrier sits in front of the LAST phase's MFMA cluster: by then every
+    // read of tile t has been issued (and is waited for), tile t+1's DMA is checked with a counted vmcnt, the freed stage
+    // is refilled and the first fragments of tile t+1 are requested -- all under the remaining MFMAs of tile t.
+    constexpr int HM = T::FM / 2;
+    static_assert(T::KK == 2, "the pipelined loop is written for BK = 64");
+    auto loadA = [&](bf16x8 (&a)[HM], const char* sA, int kk, int mh) {
+        if (p.ablate & 2) return;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = A_TR ? frag_tr(sA, wr0 + i * 16, kk, lane) : frag_rowk(sA, wr0 + i * 16, kk, lane);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = B_TR ? frag_tr(sB, wc0 + j * 16, kk, lane) : frag_rowk(sB, wc0 + j * 16, kk, lane);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < HM; ++i) {
+            const int r0 = wr0 + (mh * HM + i) * 16;
+            a[i] = A_TR ? frag_tr<T::BM>(sA, r0, kk, lane) : frag_rowk<BK>(sA, r0, kk, lane);
         }
+    };
+    auto loadB = [&](bf16x8 (&b)[T::FN], const char* sB, int kk) {
+        if (p.ablate & 2) return;
+#pragma unroll
+        for (int j = 0; j < T::FN; ++j) b[j] = B_TR ? frag_tr<T::BN>(sB, wc0 + j * 16, kk, lane) : frag_rowk<BK>(sB, wc0 + j * 16, kk, lane);
+    };
+    auto mma = [&](const bf16x8 (&a)[HM], const bf16x8 (&b)[T::FN], int mh) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < HM; ++i)
+#pragma unroll
+            for (int j = 0; j < T::FN; ++j)
+                acc[mh * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[mh * HM + i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto wait_tile = [&](int younger) {  // returns once at most min(NS-2, younger) younger tiles of this wave are in flight
+        if (T::NS >= 4 && younger >= 2) wait_vmcnt<2 * T::DMA_PER_TILE>();
+        else if (T::NS >= 3 && younger >= 1) wait_vmcnt<T::DMA_PER_TILE>();
+        else wait_vmcnt<0>();
+    };
+
+#pragma unroll
+    for (int i = 0; i < T::NS - 1; ++i)
+        if (t0 + i < nt) issue_tile(t0 + i, i);
+    bf16x8 aE[HM], aO[HM], b0[T::FN], b1[T::FN];
+#pragma unroll
+    for (int i = 0; i < HM; ++i) aE[i] = aO[i] = (bf16x8){1, 2, 3, 4, 5, 6, 7, 8};
+#pragma unroll
+    for (int j = 0; j < T::FN; ++j) b0[j] = b1[j] = (bf16x8){8, 7, 6, 5, 4, 3, 2, 1};
+    if (t0 < nt) {
+        wait_tile(nt - 1 - t0);
+        __builtin_amdgcn_s_barrier();
+        if (t0 + T::NS - 1 < nt) issue_tile(t0 + T::NS - 1, T::NS - 1);
+        loadB(b0, smem + T::A_BYTES, 0);
+        loadA(aE, smem, 0, 0);
+    }
+    for (int t = t0; t < nt; ++t) {
+        const char* sA = smem + ((t - t0) % T::NS) * T::STAGE;
+        const char* sB = sA + T::A_BYTES;
+        loadA(aO, sA, 0, 1);
+        mma(aE, b0, 0);  // phase 0
+        loadB(b1, sB, 1);
+        loadA(aE, sA, 1, 0);
+        mma(aO, b0, 1);  // phase 1
+        loadA(aO, sA, 1, 1);
+        mma(aE, b1, 0);  // phase 2
+        if (t + 1 < nt) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of tile t are complete ...
+            wait_tile(nt - 2 - t);                              // ... and its share of tile t+1 has landed
+            if (!(p.ablate & 4)) __builtin_amdgcn_s_barrier();  // ... for every wave
+            if (t + T::NS < nt && !(p.ablate & 1)) issue_tile(t + T::NS, (t - t0) % T::NS);
+            const char* nA = smem + ((t + 1 - t0) % T::NS) * T::STAGE;
+            loadB(b0, nA + T::A_BYTES, 0);
+            loadA(aE, nA, 0, 0);
+        }
+        mma(aO, b1, 1);  // phase 3
     }
 
-    // ---- epilogue: acc -> LDS (fp32) -> coalesced rows ---------------------------------------------------
+    // ---- epilogue: acc -> LDS (fp32, 64x64 per wave at a time) -> coalesced rows ---------------------------------
     __syncthreads();
     float* stg = reinterpret_cast<float*>(smem) + wave * 64 * EPI_LD;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int sm = 0; sm < T::WTM / 64; ++sm) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int sn = 0; sn < T::WTN / 64; ++sn) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) stg[(i * 16 + (lane >> 4) * 4 + e) * EPI_LD + j * 16 + (lane & 15)] = acc[i][j][e];
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes are done before it reads them back
-
-    const int64_t gn = n0 + wc0 + (lane & 7) * 8;
-    const bool vec_ok = (gn + 8 <= p.N) && ((p.ldc & 7) == 0) && ((p.ldr & 7) == 0 || p.R == nullptr);
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int tpass = 0; tpass < 8; ++tpass) {
-        const int row = tpass * 8 + (lane >> 3);
-        const int64_t gm = m0 + wr0 + row;
-        if (gm >= p.M || gn >= p.N) continue;
-        float v[8];
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + (lane & 7) * 8);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + (lane & 7) * 8 + 4);
-        v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3];
-        v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
-        const int nvalid = (int)min((int64_t)8, p.N - gn);
-        if (p.bias) {
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (e < nvalid) v[e] += p.bias[gn + e];
-        }
-        if (p.epilogue == MI355_EPI_GELU_ERF) {
+                    for (int e = 0; e < 4; ++e)
+                        stg[(i * 16 + (lane >> 4) * 4 + e) * EPI_LD + j * 16 + (lane & 15)] = acc[sm * 4 + i][sn * 4 + j][e];
+            __builtin_amdgcn_wave_barrier();
+            const int64_t gn = n0 + wc0 + sn * 64 + (lane & 7) * 8;
+            const int64_t gm0 = m0 + wr0 + sm * 64;
+            if (p.ksplit > 1) {  // raw fp32 partial sums; residual / conversion happen in splitk_reduce_kernel
+                if constexpr (OUT_DT == MI355_DT_F32) {
+                    float* slab = p.ws + (int64_t)split * p.M * p.N;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-        }
-        if constexpr (OUT_DT == MI355_DT_BF16) {
-            bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + gm * p.ldc + gn;
-            const bf16_t* r = p.R ? reinterpret_cast<const bf16_t*>(p.R) + gm * p.ldr + gn : nullptr;
-            if (vec_ok) {
-                if (r) {
-                    const u32x4 rv = *reinterpret_cast<const u32x4*>(r);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[2 * e] += __uint_as_float(rv[e] << 16);
-                        v[2 * e + 1] += __uint_as_float(rv[e] & 0xffff0000u);
+                    for (int tpass = 0; tpass < 8; ++tpass) {
+                        const int row = tpass * 8 + (lane >> 3);
+                        const int64_t gm = gm0 + row;
+                        if (gm >= p.M || gn >= p.N) continue;  // N % 8 == 0 is required for split-K
+                        *reinterpret_cast<f32x4*>(slab + gm * p.N + gn) = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + (lane & 7) * 8);
+                        *reinterpret_cast<f32x4*>(slab + gm * p.N + gn + 4) = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + (lane & 7) * 8 + 4);
                     }
                 }
-                u32x4 o;
+            } else {
+                const bool vec_ok = (gn + 8 <= p.N) && ((p.ldc & 7) == 0) && ((p.ldr & 7) == 0 || p.R == nullptr);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
-                *reinterpret_cast<u32x4*>(c) = o;
-            } else {
-                for (int e = 0; e < nvalid; ++e) c[e] = f2bf(v[e] + (r ? bf2f(r[e]) : 0.f));
-            }
-        } else {
-            float* c = reinterpret_cast<float*>(p.C) + gm * p.ldc + gn;
-            const float* r = p.R ? reinterpret_cast<const float*>(p.R) + gm * p.ldr + gn : nullptr;
-            if (vec_ok) {
-                f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-                if (r) {
-                    o0 += *reinterpret_cast<const f32x4*>(r);
-                    o1 += *reinterpret_cast<const f32x4*>(r + 4);
+                for (int tpass = 0; tpass < 8; ++tpass) {
+                    const int row = tpass * 8 + (lane >> 3);
+                    const int64_t gm = gm0 + row;
+                    if (gm >= p.M || gn >= p.N) continue;
+                    float v[8];
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + (lane & 7) * 8);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + (lane & 7) * 8 + 4);
+                    v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3];
+                    v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
+                    const int nvalid = (int)min((int64_t)8, p.N - gn);
+                    if (p.bias) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (e < nvalid) v[e] += p.bias[gn + e];
+                    }
+                    if (p.epilogue == MI355_EPI_GELU_ERF) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+                    }
+                    if constexpr (OUT_DT == MI355_DT_BF16) {
+                        bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + gm * p.ldc + gn;
+                        const bf16_t* r = p.R ? reinterpret_cast<const bf16_t*>(p.R) + gm * p.ldr + gn : nullptr;
+                        if (vec_ok) {
+                            if (r) {
+                                const u32x4 rv = *reinterpret_cast<const u32x4*>(r);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    v[2 * e] += __uint_as_float(rv[e] << 16);
+                                    v[2 * e + 1] += __uint_as_float(rv[e] & 0xffff0000u);
+                                }
+                            }
+                            u32x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+                            *reinterpret_cast<u32x4*>(c) = o;
+                        } else {
+                            for (int e = 0; e < nvalid; ++e) c[e] = f2bf(v[e] + (r ? bf2f(r[e]) : 0.f));
+                        }
+                    } else {
+                        float* c = reinterpret_cast<float*>(p.C) + gm * p.ldc + gn;
+                        const float* r = p.R ? reinterpret_cast<const float*>(p.R) + gm * p.ldr + gn : nullptr;
+                        if (vec_ok) {
+                            f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                            if (r) {
+                                o0 += *reinterpret_cast<const f32x4*>(r);
+                                o1 += *reinterpret_cast<const f32x4*>(r + 4);
+                            }
+                            *reinterpret_cast<f32x4*>(c) = o0;
+                            *reinterpret_cast<f32x4*>(c + 4) = o1;
+                        } else {
+                            for (int e = 0; e < nvalid; ++e) c[e] = v[e] + (r ? r[e] : 0.f);
+                        }
+                    }
                 }
-                *reinterpret_cast<f32x4*>(c) = o0;
-                *reinterpret_cast<f32x4*>(c + 4) = o1;
-            } else {
-                for (int e = 0; e < nvalid; ++e) c[e] = v[e] + (r ? r[e] : 0.f);
             }
+            __builtin_amdgcn_wave_barrier();  // the staging area is rewritten by the next 64x64 sub-block
         }
     }
 }
 
-template <bool A_TR, bool B_TR>
-int launch(const GemmParams& p, int out_dtype, hipStream_t s) {
-    const int grid = p.tiles_m * p.tiles_n;
+// C = sum_s slab[s] (+ R), converted to the output dtype.  4 columns per thread (N % 8 == 0).
+template <int OUT_DT>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(int64_t M, int64_t N, int ksplit, const float* __restrict__ ws,
+                                                            void* __restrict__ C, int64_t ldc, const void* __restrict__ R, int64_t ldr) {
+    const int64_t nv = N >> 2, total = M * nv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / nv, n = (i - m * nv) * 4;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(ws + m * N + n);
+        for (int sidx = 1; sidx < ksplit; ++sidx) acc += *reinterpret_cast<const f32x4*>(ws + ((int64_t)sidx * M + m) * N + n);
+        if constexpr (OUT_DT == MI355_DT_BF16) {
+            bf16_t* c = reinterpret_cast<bf16_t*>(C) + m * ldc + n;
+            if (R) {
+                const bf16_t* r = reinterpret_cast<const bf16_t*>(R) + m * ldr + n;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += bf2f(r[e]);
+            }
+            *reinterpret_cast<u32x2*>(c) = (u32x2){pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3])};
+        } else {
+            float* c = reinterpret_cast<float*>(C) + m * ldc + n;
+            if (R) acc += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(R) + m * ldr + n);
+            *reinterpret_cast<f32x4*>(c) = acc;
+        }
+    }
+}
+
+// K-split heuristic: wgrad-like problems (few output tiles, very long K) leave most CUs idle.
+int choose_ksplit(int64_t tiles, int64_t slots, int64_t K, int64_t M, int64_t N, int epilogue, const float* bias, int64_t ldc, int64_t ldr, int64_t ws_bytes) {
+    if (bias || epilogue != MI355_EPI_NONE || (N & 7) || (ldc & 3) || (ldr & 3)) return 1;
+    const int64_t kt = (K + 63) / 64;
+    if (tiles > slots / 2 || kt < 32) return 1;  // over half the resident slots already: the reduce pass costs more than it buys
+    int64_t ks = (slots + slots / 4 + tiles - 1) / tiles;
+    if (ks > kt / 8) ks = kt / 8;
+    if (ks > 16) ks = 16;
+    while (ks > 1 && ks * M * N * 4 > ws_bytes) --ks;
+    return ks < 2 ? 1 : (int)ks;
+}
+
+template <class T, bool A_TR, bool B_TR>
+int launch(GemmParams p, int out_dtype, void* workspace, int64_t workspace_bytes, hipStream_t s) {
+    p.tiles_m = (int)((p.M + T::BM - 1) / T::BM);
+    p.tiles_n = (int)((p.N + T::BN - 1) / T::BN);
+    const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n;
+    MI355_REQUIRE(tiles < 0x7fffffffLL / 16, "mi355_gemm_bf16: grid too large");
+    constexpr int WG_PER_CU = (T::MIN_WAVES * 256 / T::NTHREADS) > 0 ? (T::MIN_WAVES * 256 / T::NTHREADS) : 1;
+    const int64_t slots = 256 * WG_PER_CU;  // workgroups resident on the chip at once
+    p.ws = (float*)workspace;
+    p.ksplit = workspace ? choose_ksplit(tiles, slots, p.K, p.M, p.N, p.epilogue, p.bias, p.ldc, p.R ? p.ldr : 0, workspace_bytes) : 1;
+    const int grid = (int)(tiles * p.ksplit);
+    if (p.ksplit > 1) {
+        hipLaunchKernelGGL((gemm_bf16_kernel<T, A_TR, B_TR, MI355_DT_F32>), dim3(grid), dim3(T::NTHREADS), 0, s, p);
+        const int64_t work = p.M * (p.N >> 2);
+        const int rgrid = (int)((work + 255) / 256 > 2048 ? 2048 : (work + 255) / 256);
+        if (out_dtype == MI355_DT_BF16)
+            hipLaunchKernelGGL(splitk_reduce_kernel<MI355_DT_BF16>, dim3(rgrid), dim3(256), 0, s, p.M, p.N, p.ksplit, p.ws, p.C, p.ldc, p.R, p.ldr);
+        else
+            hipLaunchKernelGGL(splitk_reduce_kernel<MI355_DT_F32>, dim3(rgrid), dim3(256), 0, s, p.M, p.N, p.ksplit, p.ws, p.C, p.ldc, p.R, p.ldr);
+        MI355_LAUNCH_CHECK("mi355_gemm_bf16(split-K)");
+        return 0;
+    }
     if (out_dtype == MI355_DT_BF16)
-        hipLaunchKernelGGL((gemm_bf16_kernel<A_TR, B_TR, MI355_DT_BF16>), dim3(grid), dim3(NTHREADS), 0, s, p);
+        hipLaunchKernelGGL((gemm_bf16_kernel<T, A_TR, B_TR, MI355_DT_BF16>), dim3(grid), dim3(T::NTHREADS), 0, s, p);
     else
-        hipLaunchKernelGGL((gemm_bf16_kernel<A_TR, B_TR, MI355_DT_F32>), dim3(grid), dim3(NTHREADS), 0, s, p);
+        hipLaunchKernelGGL((gemm_bf16_kernel<T, A_TR, B_TR, MI355_DT_F32>), dim3(grid), dim3(T::NTHREADS), 0, s, p);
     MI355_LAUNCH_CHECK("mi355_gemm_bf16");
     return 0;
 }
 
+template <class T>
+int launch_form(int form, const GemmParams& p, int out_dtype, void* ws, int64_t ws_bytes, hipStream_t s) {
+    switch (form) {
+        case MI355_GEMM_NT: return launch<T, false, false>(p, out_dtype, ws, ws_bytes, s);
+        case MI355_GEMM_NN: return launch<T, false, true>(p, out_dtype, ws, ws_bytes, s);
+        default: return launch<T, true, true>(p, out_dtype, ws, ws_bytes, s);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- colsum
-__global__ __launch_bounds__(256) void colsum_kernel(int64_t M, int64_t N, const bf16_t* X, int64_t ldx, float* out,
-                                                     int accumulate, int rows_per_block) {
+__global__ __launch_bounds__(256) void colsum_kernel(int64_t M, int64_t N, const bf16_t* X, int64_t ldx, float* out, int rows_per_block) {
     // block = 256 threads = 64 columns x 4 row-lanes; grid.x over column groups, grid.y over row slabs
     __shared__ float red[4][64];
     const int col = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -264,14 +448,14 @@ __global__ __launch_bounds__(256) void colsum_kernel(int64_t M, int64_t N, const
         s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
         atomicAdd(out + col, s);
     }
-    (void)accumulate;
 }
 
 }  // namespace
 
 extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                                int64_t ldb, void* C, int64_t ldc, int out_dtype, const float* bias,
-                               const void* residual, int64_t ldr, int epilogue, void* stream) {
+                               const void* residual, int64_t ldr, int epilogue, void* workspace, int64_t workspace_bytes,
+                               int tile_hint, void* stream) {
     MI355_REQUIRE(form >= 0 && form <= 2, "mi355_gemm_bf16: bad form %d", form);
     MI355_REQUIRE(M > 0 && N > 0 && K > 0, "mi355_gemm_bf16: empty problem M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
     MI355_REQUIRE(out_dtype == MI355_DT_BF16 || out_dtype == MI355_DT_F32, "mi355_gemm_bf16: bad out_dtype");
@@ -281,18 +465,30 @@ extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const 
     if (form == MI355_GEMM_NT) MI355_REQUIRE((K & 7) == 0, "mi355_gemm_bf16(NT): K must be a multiple of 8");
     if (form == MI355_GEMM_NN) MI355_REQUIRE((K & 7) == 0 && (N & 7) == 0, "mi355_gemm_bf16(NN): K,N must be multiples of 8");
     if (form == MI355_GEMM_TN) MI355_REQUIRE((M & 7) == 0 && (N & 7) == 0, "mi355_gemm_bf16(TN): M,N must be multiples of 8");
-    // a tile's DMA offsets are 31-bit: 128 rows (or 64 k-rows) of one operand must span < 2 GiB
-    MI355_REQUIRE(lda * 2 * 128 < 0x7fffffffLL && ldb * 2 * 128 < 0x7fffffffLL, "mi355_gemm_bf16: leading dimension too large");
+    // a tile's DMA offsets are 31-bit: 256 rows (or 64 k-rows) of one operand must span < 2 GiB
+    MI355_REQUIRE(lda * 2 * 256 < 0x7fffffffLL && ldb * 2 * 256 < 0x7fffffffLL, "mi355_gemm_bf16: leading dimension too large");
+    MI355_REQUIRE(workspace == nullptr || ((uintptr_t)workspace & 15) == 0, "mi355_gemm_bf16: workspace must be 16-byte aligned");
+    const int ablate = tile_hint >> 8;
+    tile_hint &= 0xff;
+    MI355_REQUIRE(tile_hint >= 0 && tile_hint <= 2, "mi355_gemm_bf16: tile_hint must be 0 (auto), 1 (128x128 tile) or 2 (256x256 tile)");
     GemmParams p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.bias = bias; p.R = residual;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
-    p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN); p.epilogue = epilogue;
-    MI355_REQUIRE((int64_t)p.tiles_m * p.tiles_n < 0x7fffffffLL, "mi355_gemm_bf16: grid too large");
+    p.epilogue = epilogue; p.tiles_m = p.tiles_n = 0; p.ksplit = 1; p.ws = nullptr; p.ablate = ablate;
     hipStream_t s = (hipStream_t)stream;
-    switch (form) {
-        case MI355_GEMM_NT: return launch<false, false>(p, out_dtype, s);
-        case MI355_GEMM_NN: return launch<false, true>(p, out_dtype, s);
-        default: return launch<true, true>(p, out_dtype, s);
+    int cfg = tile_hint;
+    if (cfg == 0) {
+        // measured on MI355X over the VLM step's shapes (tools/gemm_sweep.py): the 8-wave 256x256 tile wins when it still
+        // fills the chip several times over, or when K is so long that the main loop dominates (LM head); short-K forward
+        // projections and anything with few tiles stay on 128x128 (2 workgroups per CU).
+        const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
+        bool big = t256 >= 1536 || (K >= 32768 && t256 >= 192);
+        if (form != MI355_GEMM_NT && t256 >= 640) big = true;
+        cfg = big ? 2 : 1;
+    }
+    switch (cfg) {
+        case 2: return launch_form<Cfg256>(form, p, out_dtype, workspace, workspace_bytes, s);
+        default: return launch_form<Cfg128>(form, p, out_dtype, workspace, workspace_bytes, s);
     }
 }
 
@@ -308,7 +504,7 @@ extern "C" int mi355_colsum_bf16(int64_t M, int64_t N, const void* X, int64_t ld
     }
     const int rows_per_block = 512;
     dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + rows_per_block - 1) / rows_per_block));
-    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, M, N, (const bf16_t*)X, ldx, out, accumulate, rows_per_block);
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, M, N, (const bf16_t*)X, ldx, out, rows_per_block);
     MI355_LAUNCH_CHECK("mi355_colsum_bf16");
     return 0;
 }

@@ -176,19 +176,29 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(int64_t rows, int widt
     for (int i = threadIdx.x; i < width; i += 256) dw_partial[(int64_t)blockIdx.x * width + i] = dw_lds_dyn[i];
 }
 
-// out[n] (+)= sum_p partial[p][n]: 64 columns per block, the 4 waves split the parts
-__global__ __launch_bounds__(256) void reduce_rows_kernel(int parts, int64_t n, const float* __restrict__ partial,
-                                                          void* __restrict__ out, int out_dtype, int accumulate) {
-    __shared__ float red[4][64];
+// out[n] (+)= sum_p partial[p][n]: 64 columns per block, 16 waves split the parts (the loads are the latency: keep many in flight)
+__global__ __launch_bounds__(1024) void reduce_rows_kernel(int parts, int64_t n, const float* __restrict__ partial,
+                                                           void* __restrict__ out, int out_dtype, int accumulate) {
+    __shared__ float red[16][64];
     const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + c;
-    float s = 0.f;
-    if (i < n)
-        for (int p = rl; p < parts; p += 4) s += partial[(int64_t)p * n + i];
-    red[rl][c] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+        int p = rl;
+        for (; p + 48 < parts; p += 64) {
+            s0 += partial[(int64_t)p * n + i];
+            s1 += partial[(int64_t)(p + 16) * n + i];
+            s2 += partial[(int64_t)(p + 32) * n + i];
+            s3 += partial[(int64_t)(p + 48) * n + i];
+        }
+        for (; p < parts; p += 16) s0 += partial[(int64_t)p * n + i];
+    }
+    red[rl][c] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (rl != 0 || i >= n) return;
-    s = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][c];
     if (out_dtype == MI355_DT_BF16) {
         bf16_t* o = reinterpret_cast<bf16_t*>(out);
         if (accumulate) s += bf2f(o[i]);
@@ -437,7 +447,7 @@ extern "C" int mi355_rmsnorm_bwd(int64_t rows, int width, const void* x, const v
 extern "C" int mi355_reduce_rows_f32(int parts, int64_t n, const float* partial, void* out, int out_dtype, int accumulate,
                                      void* stream) {
     MI355_REQUIRE(parts > 0 && n > 0 && partial && out, "mi355_reduce_rows_f32: bad arguments");
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, parts, n,
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, parts, n,
                        partial, out, out_dtype, accumulate);
     MI355_LAUNCH_CHECK("mi355_reduce_rows_f32");
     return 0;

@@ -10,7 +10,7 @@ import torch
 from . import _lib as L
 
 BF16, F32 = torch.bfloat16, torch.float32
-NORM_PARTS = 1024  # max blocks (= partial rows) of the norm backward kernels
+NORM_PARTS = 512  # max blocks (= partial rows) of the norm backward kernels
 
 
 def _rowmajor(t, name):
@@ -18,7 +18,19 @@ def _rowmajor(t, name):
         raise ValueError(f"{name}: expected a 2-D tensor with unit inner stride, got shape {tuple(t.shape)} strides {t.stride()}")
 
 
-def gemm(form, a, b, out=None, out_dtype=BF16, bias=None, residual=None, gelu=False):
+_WS = {}
+WS_BYTES = 512 << 20  # split-K scratch per device (fp32 slabs of the largest weight-gradient GEMM)
+
+
+def _workspace(device):
+    ws = _WS.get(device)
+    if ws is None:
+        ws = torch.empty(WS_BYTES // 4, dtype=F32, device=device)
+        _WS[device] = ws
+    return ws
+
+
+def gemm(form, a, b, out=None, out_dtype=BF16, bias=None, residual=None, gelu=False, allow_split_k=True, tile=0):
     """C = epi(op(A) op(B) + bias) + residual.  form NT: A[M,K] B[N,K]; NN: A[M,K] B[K,N]; TN: A[K,M] B[K,N]."""
     L.require_gpu(a, b, out, bias, residual)
     _rowmajor(a, "A")
@@ -52,6 +64,7 @@ def gemm(form, a, b, out=None, out_dtype=BF16, bias=None, residual=None, gelu=Fa
     L.call(
         "mi355_gemm_bf16", form, M, N, K, L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), L.ptr(out), out.stride(0),
         L.dt_code(out.dtype), L.ptr(bias), L.ptr(residual), ldr, L.EPI_GELU if gelu else L.EPI_NONE,
+        L.ptr(_workspace(a.device)) if allow_split_k else None, WS_BYTES if allow_split_k else 0, tile,
     )
     return out
 

@@ -54,7 +54,7 @@ def test_host_side_validation_rejects_bad_calls_without_touching_the_gpu():
     if not os.path.exists(_lib.LIB_PATH):
         _lib.build()
     lib = _lib.load()
-    rc = lib.mi355_gemm_bf16(7, 1, 1, 8, None, 8, None, 8, None, 8, 0, None, None, 0, 0, None)
+    rc = lib.mi355_gemm_bf16(7, 1, 1, 8, None, 8, None, 8, None, 8, 0, None, None, 0, 0, None, 0, 0, None)
     assert rc != 0 and b"bad form" in lib.mi355_last_error()
     rc = lib.mi355_attn_fwd(1, 4, 2, 1, 96, None, 0, None, 0, None, 0, None, 0, None, None, 1, 1.0, None)
     assert rc != 0 and b"head_dim" in lib.mi355_last_error()

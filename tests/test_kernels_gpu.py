@@ -54,9 +54,10 @@ GEMM_SHAPES = [
 ]
 
 
+@pytest.mark.parametrize("tile", [1, 2])
 @pytest.mark.parametrize("form", ["NT", "NN", "TN"])
 @pytest.mark.parametrize("M,N,K_", GEMM_SHAPES)
-def test_gemm_forms(K, form, M, N, K_):
+def test_gemm_forms(K, form, M, N, K_, tile):
     from llm_quest_amd import _lib as L
 
     if form == "NN" and N % 8:
@@ -68,14 +69,14 @@ def test_gemm_forms(K, form, M, N, K_):
     b = torch.randn(N, K_, generator=g).to(BF16)
     ref = a.float() @ b.float().t()
     if form == "NT":
-        out = K.gemm(L.GEMM_NT, dev(a), dev(b), out_dtype=F32)
+        out = K.gemm(L.GEMM_NT, dev(a), dev(b), out_dtype=F32, tile=tile)
     elif form == "NN":
-        out = K.gemm(L.GEMM_NN, dev(a), dev(b.t().contiguous()), out_dtype=F32)
+        out = K.gemm(L.GEMM_NN, dev(a), dev(b.t().contiguous()), out_dtype=F32, tile=tile)
     else:
-        out = K.gemm(L.GEMM_TN, dev(a.t().contiguous()), dev(b.t().contiguous()), out_dtype=F32)
+        out = K.gemm(L.GEMM_TN, dev(a.t().contiguous()), dev(b.t().contiguous()), out_dtype=F32, tile=tile)
     # fp32 accumulation of exact bf16 products: only summation order differs
     err = rel_l2(out, ref)
-    assert err < 2e-6, f"{form} {M}x{N}x{K_}: rel l2 {err}"
+    assert err < 2e-6, f"{form} {M}x{N}x{K_} tile {tile}: rel l2 {err}"
 
 
 def test_gemm_epilogues(K):
@@ -103,6 +104,29 @@ def test_gemm_epilogues(K):
     wide = dev(torch.randn(M, 2 * K_, generator=g).to(BF16))
     out = K.gemm(L.GEMM_NT, wide[:, K_:], dev(w), out_dtype=F32)
     assert rel_l2(out, wide[:, K_:].float().cpu() @ w.float().t()) < 2e-6
+
+
+def test_gemm_split_k_weight_gradient_shapes(K):
+    """Few output tiles + long K (weight gradients): the K-split path must agree with the unsplit kernel and fp32 math,
+    including accumulation into an existing gradient."""
+    from llm_quest_amd import _lib as L
+
+    g = torch.Generator().manual_seed(77)
+    tokens, n_out, k_in = 5000, 256, 384
+    dy = torch.randn(tokens, n_out, generator=g).to(BF16)
+    x = torch.randn(tokens, k_in, generator=g).to(BF16)
+    ref = dy.float().t() @ x.float()
+    split = K.gemm(L.GEMM_TN, dev(dy), dev(x), out_dtype=F32)
+    plain = K.gemm(L.GEMM_TN, dev(dy), dev(x), out_dtype=F32, allow_split_k=False)
+    assert rel_l2(split, ref) < 2e-6 and rel_l2(plain, ref) < 2e-6
+    grad = dev(torch.randn(n_out, k_in, generator=g).to(BF16))
+    before = grad.float().cpu()
+    K.gemm(L.GEMM_TN, dev(dy), dev(x), out=grad, residual=grad)
+    assert rel_l2(grad, (before + ref).to(BF16)) < 3e-3
+    # NT with a long K and a single tile also splits
+    a = torch.randn(100, 8192, generator=g).to(BF16)
+    b = torch.randn(64, 8192, generator=g).to(BF16)
+    assert rel_l2(K.gemm(L.GEMM_NT, dev(a), dev(b), out_dtype=F32), a.float() @ b.float().t()) < 2e-6
 
 
 def test_colsum(K):
