@@ -75,6 +75,45 @@ __device__ __forceinline__ bf16x8 frag_cols(const char* img, int c0, int k0, int
     return r;
 }
 
+// ---- precomputed per-lane LDS offsets -----------------------------------------------------------------------------
+// The XOR swizzles above defeat the compiler's immediate-offset folding (it re-derives ~6-10 VALU ops per LDS read, and
+// the attention loops were VALU-bound at 18 VALU per MFMA).  Both fragment addresses factor into
+//     row image:  tile_base + r0*ROWB + ( lane_row ^ (ks << 5) )               lane_row = r*ROWB + ((h ^ swz(r)) << 4)
+//     tr  image:  tile_base + k0*ROWB + lane_col[dt]   (+ 8*ROWB second half)   lane_col[dt] = lane part + ((dt ^ x) << 6)
+// with tile_base / r0 / k0 multiples of 4 KiB resp. ROWB (they never touch bits 4..7, so they commute with the XOR).
+template <int D>
+struct LaneOff {
+    int row;
+    int col[Cfg<D>::DT];
+};
+template <int D>
+__device__ __forceinline__ LaneOff<D> lane_offsets(int lane) {
+    using C = Cfg<D>;
+    LaneOff<D> o;
+    const int r = lane & 31, h = lane >> 5;
+    const int sw = D == 128 ? (r & 15) : ((r >> 1) & 7);
+    o.row = r * C::ROWB + ((h ^ sw) << 4);
+    const int g = lane >> 4, q4 = (lane >> 2) & 3, p = lane & 3;
+    const int x = D == 128 ? q4 : ((q4 >> 1) & 1);
+    const int base = (4 * (g >> 1) + q4) * C::ROWB + ((2 * (g & 1) + (p >> 1)) << 4) + (p & 1) * 8;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) o.col[dt] = base + ((dt ^ x) << 6);
+    return o;
+}
+// row-image fragment: vx = (lane_row + image_offset) ^ (ks << 5), imm = r0 * ROWB
+__device__ __forceinline__ bf16x8 lds_frag(const char* smem, int vx, int imm) { return *reinterpret_cast<const bf16x8*>(smem + vx + imm); }
+// tr-image fragment: v = lane_col[dt] + image_offset, imm = k0 * ROWB
+template <int D>
+__device__ __forceinline__ bf16x8 lds_frag_tr(const char* smem, int v, int imm) {
+    const char* a = smem + v + imm;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a + 8 * Cfg<D>::ROWB));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
 // pack accumulator registers 8s..8s+7 to a bf16 B-operand fragment
 __device__ __forceinline__ bf16x8 pack_frag(const f32x16& x, int s) {
     u32x4 o;
@@ -137,13 +176,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int B, int S, int Hq, 
         dma_tile<D, true>(vbase + (int64_t)kt * 64 * ldv, ldv, S - kt * 64, ks_ + C::TILE, wave, lane);
     };
 
+    const LaneOff<D> lo = lane_offsets<D>(lane);
     issue(0, 0);
     for (int kt = 0; kt < ntiles; ++kt) {
         __syncthreads();
         if (kt + 1 < ntiles) issue(kt + 1, (kt + 1) & 1);
-        const char* Ks = smem + (kt & 1) * 2 * C::TILE;
-        const char* Vs = Ks + C::TILE;
-        // key-padding bits of this tile (1 = real token)
+        const int koff = (kt & 1) * 2 * C::TILE, voff = koff + C::TILE;
+        // key-padding bits of this tile (1 = real token); keys beyond S read as padding here and are removed below
         unsigned long long kbits = ~0ull;
         if (key_mask) {
             const int kg = kt * 64 + lane;
@@ -152,6 +191,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int B, int S, int Hq, 
         // a wave whose 32 queries all precede this tile has nothing visible here (unless a row is still fully masked)
         const bool wave_active = !causal || (kt * 64 <= q0 + wave * 32 + 31) || __any(m == MASK_T);
         if (wave_active) {
+            int vkx[C::KS], vv[C::DT];
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks) vkx[ks] = (lo.row + koff) ^ (ks << 5);
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt) vv[dt] = lo.col[dt] + voff;
             f32x16 sacc[2];
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
@@ -159,40 +203,60 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int B, int S, int Hq, 
                 for (int e = 0; e < 16; ++e) sacc[st][e] = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < C::KS; ++ks)
-                    sacc[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(Ks, st * 32, ks, lane), qf[ks], sacc[st], 0, 0, 0);
+                    sacc[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(smem, vkx[ks], st * 32 * C::ROWB), qf[ks], sacc[st], 0, 0, 0);
             }
-            float tmax = -INFINITY;
+            // masks are needed only on the diagonal / tail / padded tiles (wave-uniform test)
+            const bool boundary = (kbits != ~0ull) || (kt * 64 + 64 > S) || (causal && kt * 64 + 63 > q0 + wave * 32);
+            float mnew;
+            if (boundary) {
+                float tmax = -INFINITY;
 #pragma unroll
-            for (int st = 0; st < 2; ++st)
+                for (int st = 0; st < 2; ++st)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int kl = st * 32 + acc_row(e, lane);
-                    const int kg = kt * 64 + kl;
-                    float t = sacc[st][e] * scale_log2;
-                    const bool masked = (causal && kg > qg) || !((kbits >> kl) & 1ull);
-                    t = masked ? MASK_T : t;
-                    t = kg < S ? t : -INFINITY;
-                    sacc[st][e] = t;
-                    tmax = fmaxf(tmax, t);
-                }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float mnew = fmaxf(m, tmax);
-            const float alpha = __builtin_amdgcn_exp2f(m - mnew);
-            m = mnew;
+                    for (int e = 0; e < 16; ++e) {
+                        const int kl = st * 32 + acc_row(e, lane);
+                        const int kg = kt * 64 + kl;
+                        float t = sacc[st][e] * scale_log2;
+                        const bool masked = (causal && kg > qg) || !((kbits >> kl) & 1ull);
+                        t = masked ? MASK_T : t;
+                        t = kg < S ? t : -INFINITY;
+                        sacc[st][e] = t;
+                        tmax = fmaxf(tmax, t);
+                    }
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                mnew = fmaxf(m, tmax);
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) sacc[st][e] = __builtin_amdgcn_exp2f(sacc[st][e] - mnew);
+            } else {
+                float rmax = sacc[0][0];
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) rmax = fmaxf(rmax, sacc[st][e]);
+                rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
+                mnew = fmaxf(m, rmax * scale_log2);
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) sacc[st][e] = __builtin_amdgcn_exp2f(fmaf(sacc[st][e], scale_log2, -mnew));
+            }
             float psum = 0.f;
 #pragma unroll
             for (int st = 0; st < 2; ++st)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float pv = __builtin_amdgcn_exp2f(sacc[st][e] - mnew);
-                    sacc[st][e] = pv;
-                    psum += pv;
-                }
-            l = l * alpha + psum;
+                for (int e = 0; e < 16; ++e) psum += sacc[st][e];
+            if (__any(mnew != m)) {  // the running max moved for some row of this wave: rescale (else alpha == 1 exactly)
+                const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+                l *= alpha;
 #pragma unroll
-            for (int i = 0; i < C::DT; ++i)
+                for (int i = 0; i < C::DT; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
+                    for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
+                m = mnew;
+            }
+            l += psum;
 #pragma unroll
             for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -200,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int B, int S, int Hq, 
                     const bf16x8 pf = pack_frag(sacc[st], s);
 #pragma unroll
                     for (int dt = 0; dt < C::DT; ++dt)
-                        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols<D>(Vs, dt * 32, st * 32 + 16 * s, lane), pf, oacc[dt], 0, 0, 0);
+                        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr<D>(smem, vv[dt], (st * 32 + 16 * s) * C::ROWB), pf, oacc[dt], 0, 0, 0);
                 }
         }
         // reference semantics for rows whose visible keys are all padding: keep going over the causally hidden tiles
@@ -299,13 +363,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(int B, int S, int H
         dma_tile<D, false>(vbase + (int64_t)kt * 64 * ldv, ldv, S - kt * 64, st_ + 2 * C::TILE, wave, lane);
     };
 
+    const LaneOff<D> lo = lane_offsets<D>(lane);
     issue(0, 0);
     for (int kt = 0; kt < ntiles; ++kt) {
         __syncthreads();
         if (kt + 1 < ntiles) issue(kt + 1, (kt + 1) & 1);
-        const char* Kr = smem + (kt & 1) * 3 * C::TILE;
-        const char* Kt = Kr + C::TILE;
-        const char* Vr = Kr + 2 * C::TILE;
+        const int kroff = (kt & 1) * 3 * C::TILE, ktoff = kroff + C::TILE, vroff = kroff + 2 * C::TILE;
         unsigned long long kbits = ~0ull;
         if (key_mask) {
             const int kg = kt * 64 + lane;
@@ -313,6 +376,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(int B, int S, int H
         }
         const bool wave_active = !causal || (kt * 64 <= q0 + wave * 32 + 31);
         if (!wave_active) continue;
+        const bool boundary = (kbits != ~0ull) || (kt * 64 + 64 > S) || (causal && kt * 64 + 63 > q0 + wave * 32);
+        int vkx[C::KS], vvx[C::KS], vkt[C::DT];
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+            vkx[ks] = (lo.row + kroff) ^ (ks << 5);
+            vvx[ks] = (lo.row + vroff) ^ (ks << 5);
+        }
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) vkt[dt] = lo.col[dt] + ktoff;
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             f32x16 sacc, pacc;
@@ -320,23 +392,31 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(int B, int S, int H
             for (int e = 0; e < 16; ++e) { sacc[e] = 0.f; pacc[e] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < C::KS; ++ks) {
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(Kr, st * 32, ks, lane), qf[ks], sacc, 0, 0, 0);
-                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(Vr, st * 32, ks, lane), dof[ks], pacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(smem, vkx[ks], st * 32 * C::ROWB), qf[ks], sacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(smem, vvx[ks], st * 32 * C::ROWB), dof[ks], pacc, 0, 0, 0);
             }
+            if (boundary) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int kl = st * 32 + acc_row(e, lane);
-                const int kg = kt * 64 + kl;
-                const bool masked = (causal && kg > qg) || !((kbits >> kl) & 1ull) || kg >= S;
-                const float p = masked ? 0.f : __builtin_amdgcn_exp2f(sacc[e] * scale_log2 - lse2);
-                sacc[e] = p * (pacc[e] - dlt) * scale;  // dS^T (gradient w.r.t. the raw QK^T product)
+                for (int e = 0; e < 16; ++e) {
+                    const int kl = st * 32 + acc_row(e, lane);
+                    const int kg = kt * 64 + kl;
+                    const bool masked = (causal && kg > qg) || !((kbits >> kl) & 1ull) || kg >= S;
+                    const float p = masked ? 0.f : __builtin_amdgcn_exp2f(fmaf(sacc[e], scale_log2, -lse2));
+                    sacc[e] = p * (pacc[e] - dlt) * scale;  // dS^T (gradient w.r.t. the raw QK^T product)
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(sacc[e], scale_log2, -lse2));
+                    sacc[e] = p * (pacc[e] - dlt) * scale;
+                }
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const bf16x8 dsf = pack_frag(sacc, s);
 #pragma unroll
                 for (int dt = 0; dt < C::DT; ++dt)
-                    dqacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols<D>(Kt, dt * 32, st * 32 + 16 * s, lane), dsf, dqacc[dt], 0, 0, 0);
+                    dqacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr<D>(smem, vkt[dt], (st * 32 + 16 * s) * C::ROWB), dsf, dqacc[dt], 0, 0, 0);
             }
         }
     }
@@ -414,18 +494,29 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
         }
     };
 
+    const LaneOff<D> lo = lane_offsets<D>(lane);
     if (nit > 0) issue(0, 0);
     for (int it = 0; it < nit; ++it) {
         __syncthreads();
         if (it + 1 < nit) issue(it + 1, (it + 1) & 1);
         const int qt = qt0 + it % per_head;
-        const char* Qr = smem + (it & 1) * 4 * C::TILE;
-        const char* Qt = Qr + C::TILE;
-        const char* Or = Qr + 2 * C::TILE;
-        const char* Ot = Qr + 3 * C::TILE;
+        const int qroff = (it & 1) * 4 * C::TILE, qtoff = qroff + C::TILE, oroff = qroff + 2 * C::TILE, otoff = qroff + 3 * C::TILE;
         const float* rc = rowc + (it & 1) * 128;
         // queries of this tile all precede this wave's keys -> nothing visible
         if (causal && qt * 64 + 63 < k0 + wave * 32) continue;
+        // masks only where the tile touches the diagonal, the sequence end, or this wave holds padded / out-of-range keys
+        const bool boundary = (causal && qt * 64 < k0 + wave * 32 + 31) || (qt * 64 + 64 > S) || __any(!kreal);
+        int vqx[C::KS], vox[C::KS], vqt[C::DT], vot[C::DT];
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+            vqx[ks] = (lo.row + qroff) ^ (ks << 5);
+            vox[ks] = (lo.row + oroff) ^ (ks << 5);
+        }
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+            vqt[dt] = lo.col[dt] + qtoff;
+            vot[dt] = lo.col[dt] + otoff;
+        }
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             f32x16 sacc, pacc;
@@ -433,17 +524,34 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
             for (int e = 0; e < 16; ++e) { sacc[e] = 0.f; pacc[e] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < C::KS; ++ks) {
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(Qr, st * 32, ks, lane), kf[ks], sacc, 0, 0, 0);
-                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(Or, st * 32, ks, lane), vf[ks], pacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(smem, vqx[ks], st * 32 * C::ROWB), kf[ks], sacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(smem, vox[ks], st * 32 * C::ROWB), vf[ks], pacc, 0, 0, 0);
             }
+            // per-query constants of the 16 accumulator rows: 4 x 16-byte LDS reads each (rows 8*g4 + 4*h + 0..3)
+            float l2r[16], dlr[16];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int ql = st * 32 + acc_row(e, lane);
-                const int qq = qt * 64 + ql;
-                const bool masked = (causal && kg > qq) || !kreal || qq >= S;
-                const float p = masked ? 0.f : __builtin_amdgcn_exp2f(sacc[e] * scale_log2 - rc[ql]);
-                sacc[e] = p;
-                pacc[e] = p * (pacc[e] - rc[64 + ql]) * scale;
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(rc + st * 32 + 8 * g4 + 4 * (lane >> 5));
+                const f32x4 c = *reinterpret_cast<const f32x4*>(rc + 64 + st * 32 + 8 * g4 + 4 * (lane >> 5));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { l2r[4 * g4 + e] = a[e]; dlr[4 * g4 + e] = c[e]; }
+            }
+            if (boundary) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int qq = qt * 64 + st * 32 + acc_row(e, lane);
+                    const bool masked = (causal && kg > qq) || !kreal || qq >= S;
+                    const float p = masked ? 0.f : __builtin_amdgcn_exp2f(fmaf(sacc[e], scale_log2, -l2r[e]));
+                    sacc[e] = p;
+                    pacc[e] = p * (pacc[e] - dlr[e]) * scale;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(sacc[e], scale_log2, -l2r[e]));
+                    sacc[e] = p;
+                    pacc[e] = p * (pacc[e] - dlr[e]) * scale;
+                }
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -451,8 +559,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
                 const bf16x8 dsf = pack_frag(pacc, s);
 #pragma unroll
                 for (int dt = 0; dt < C::DT; ++dt) {
-                    dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols<D>(Ot, dt * 32, st * 32 + 16 * s, lane), pf, dvacc[dt], 0, 0, 0);
-                    dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols<D>(Qt, dt * 32, st * 32 + 16 * s, lane), dsf, dkacc[dt], 0, 0, 0);
+                    dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr<D>(smem, vot[dt], (st * 32 + 16 * s) * C::ROWB), pf, dvacc[dt], 0, 0, 0);
+                    dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr<D>(smem, vqt[dt], (st * 32 + 16 * s) * C::ROWB), dsf, dkacc[dt], 0, 0, 0);
                 }
             }
         }
