@@ -18,6 +18,9 @@ def _rowmajor(t, name):
         raise ValueError(f"{name}: expected a 2-D tensor with unit inner stride, got shape {tuple(t.shape)} strides {t.stride()}")
 
 
+import os
+
+_TILE_OVERRIDE = int(os.environ.get("MI355_GEMM_TILE", "0"))  # profiling knob: force a GEMM tile configuration
 _WS = {}
 WS_BYTES = 512 << 20  # split-K scratch per device (fp32 slabs of the largest weight-gradient GEMM)
 
@@ -64,7 +67,7 @@ def gemm(form, a, b, out=None, out_dtype=BF16, bias=None, residual=None, gelu=Fa
     L.call(
         "mi355_gemm_bf16", form, M, N, K, L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), L.ptr(out), out.stride(0),
         L.dt_code(out.dtype), L.ptr(bias), L.ptr(residual), ldr, L.EPI_GELU if gelu else L.EPI_NONE,
-        L.ptr(_workspace(a.device)) if allow_split_k else None, WS_BYTES if allow_split_k else 0, tile,
+        L.ptr(_workspace(a.device)) if allow_split_k else None, WS_BYTES if allow_split_k else 0, tile or _TILE_OVERRIDE,
     )
     return out
 

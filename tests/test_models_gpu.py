@@ -252,3 +252,55 @@ def test_lm_engine_loop_on_gpu(golden):
     sch = LearningRateScheduler(opt, total_steps=6, init_lr=1e-5, peak_lr=1e-3, warmup_steps=2, min_lr=1e-4, decay="cosine")
     tr, va = training_eval_loop(data, data[:2], m, opt, 2, sch, eval_freq=2, eval_iter=1, device=torch.device("cuda"), accumulation_steps=2)
     assert len(tr) == len(va) >= 2 and all(torch.isfinite(torch.tensor(tr)))
+
+
+def test_rccl_gradsync_single_rank(golden):
+    """The real RCCL path on one GPU: a 1-rank 'nccl' process group, GradSync forced on, so every bucket goes through
+    all_reduce(AVG) on the communication stream with the event ordering used at N>1.  Gradients must be unchanged."""
+    import os
+
+    import torch.distributed as dist
+
+    from llm_quest_amd import ddp
+    from llm_quest_amd.multimodal.vision_transformer.vit_engine import ViTAdapter
+    from llm_quest_amd.multimodal.vision_transformer.vit_model import ViTModel
+    from llm_quest_amd.multimodal.vlm_engine import vlm_step_loss
+
+    t = golden("vlm_tiny")
+    vit = ViTModel(dict(TINY_VIT))
+    load_into(vit, sub_dict(t, "vit."))
+    vit = vit.cuda().eval()
+    for p in vit.parameters():
+        p.requires_grad = False
+    llm = make_qwen(t, "llm.")
+    ad = ViTAdapter(64, 128, adapter_type="ffn", dtype=BF16)
+    ad.load_state_dict(sub_dict(t, "ad."))
+    ad = ad.cuda().train()
+    img, ids, tm = t["in.image"].cuda(), t["in.ids"].cuda(), t["in.text_mask"].bool().cuda()
+
+    def grads():
+        llm.zero_grad(set_to_none=True)
+        ad.zero_grad(set_to_none=True)
+        loss = vlm_step_loss(vit, llm, ad, img, ids, tm, hf_vit_model=False)
+        return loss
+
+    grads().backward()
+    ref = {n: p.grad.float().clone() for n, p in list(llm.named_parameters()) + list(ad.named_parameters())}
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        sync = ddp.sync_for_vlm(llm, ad)
+        sync.enabled = True  # world size 1: the collectives are identities but run for real
+        sync.broadcast_parameters([llm, ad])
+        loss = grads()
+        sync.begin_step()
+        loss.backward()
+        sync.finish_step()
+        torch.cuda.synchronize()
+        assert len(sync._done) == len(llm.trf_blocks) + 2  # every block, the adapter, the embedding/head arena
+        for n, p in list(llm.named_parameters()) + list(ad.named_parameters()):
+            assert rel_l2(p.grad, ref[n]) < 1e-6, n
+    finally:
+        dist.destroy_process_group()
+        for m in list(llm.trf_blocks) + [ad]:
+            object.__setattr__(m, "_grad_ready", None)
