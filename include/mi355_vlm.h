@@ -57,8 +57,9 @@ int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const void* A, in
                     int64_t ldb, void* C, int64_t ldc, int out_dtype, const float* bias, const void* residual,
                     int64_t ldr, int epilogue, void* workspace, int64_t workspace_bytes, int tile_hint, void* stream);
 
-/* column sums: out[n] (+)= sum_m X[m,n]  (bias gradients).  X bf16 [M,N] ld=ldx, out fp32 [N]. */
-int mi355_colsum_bf16(int64_t M, int64_t N, const void* X, int64_t ldx, float* out, int accumulate, void* stream);
+/* column sums: out[n] (+)= sum_m X[m,n]  (bias / cls-token / pos-embedding gradients).  X bf16 or fp32 [M,N] ld=ldx,
+ * out fp32 [N]. */
+int mi355_colsum(int64_t M, int64_t N, const void* X, int x_dtype, int64_t ldx, float* out, int accumulate, void* stream);
 
 /* RMSNorm, fp32 math, rows of `width` (PytorchRMSNorm, qwen3_attention.py:19-29): y = x*rsqrt(mean(x^2)+eps)*w.
  * x,y,w bf16; rstd fp32 [rows] saved for backward. */
@@ -135,6 +136,12 @@ int mi355_patchify(int B, int C, int H, int W, int P, const float* img, void* ro
  * y bf16 or fp32; saves mean/rsig fp32 [rows] if non-NULL. */
 int mi355_layernorm_fwd(int64_t rows, int width, const float* x, const float* scale, const float* shift, void* y,
                         int y_dtype, float* mean, float* rsig, float eps, void* stream);
+
+/* backward of the same LayerNorm: dy bf16 or fp32; dx fp32 (+ dres, the residual-stream gradient); per-block partials
+ * [parts][2*width] = (dscale | dshift), summed by mi355_reduce_rows_f32. */
+int mi355_layernorm_bwd(int64_t rows, int width, const float* x, const float* scale, const float* mean, const float* rsig,
+                        const void* dy, int dy_dtype, const float* dres, float* dx, float* dparam_partial, int parts,
+                        float eps, void* stream);
 
 /* dtype conversion / elementwise helpers */
 int mi355_cast(int64_t n, const void* src, int src_dtype, void* dst, int dst_dtype, void* stream);

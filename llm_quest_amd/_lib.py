@@ -24,7 +24,7 @@ _P, _I, _L, _F = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float
 # name -> argtypes; every entry point returns int.  Must list exactly what include/mi355_vlm.h declares.
 SIGNATURES = {
     "mi355_gemm_bf16": [_I, _L, _L, _L, _P, _L, _P, _L, _P, _L, _I, _P, _P, _L, _I, _P, _L, _I, _P],
-    "mi355_colsum_bf16": [_L, _L, _P, _L, _P, _I, _P],
+    "mi355_colsum": [_L, _L, _P, _I, _L, _P, _I, _P],
     "mi355_rmsnorm_fwd": [_L, _I, _P, _P, _P, _P, _F, _P],
     "mi355_rmsnorm_bwd": [_L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "mi355_reduce_rows_f32": [_I, _L, _P, _P, _I, _I, _P],
@@ -41,6 +41,7 @@ SIGNATURES = {
     "mi355_copy2d": [_L, _L, _P, _L, _P, _L, _P],
     "mi355_patchify": [_I, _I, _I, _I, _I, _P, _P, _I, _P],
     "mi355_layernorm_fwd": [_L, _I, _P, _P, _P, _P, _I, _P, _P, _F, _P],
+    "mi355_layernorm_bwd": [_L, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _F, _P],
     "mi355_cast": [_L, _P, _I, _P, _I, _P],
     "mi355_vit_embed_assemble": [_I, _I, _I, _P, _P, _P, _P, _P],
     "mi355_sumsq": [_L, _P, _I, _P, _P],

@@ -432,7 +432,8 @@ int launch_form(int form, const GemmParams& p, int out_dtype, void* ws, int64_t 
 }
 
 // ---------------------------------------------------------------------------------------------- colsum
-__global__ __launch_bounds__(256) void colsum_kernel(int64_t M, int64_t N, const bf16_t* X, int64_t ldx, float* out, int rows_per_block) {
+template <int DT>
+__global__ __launch_bounds__(256) void colsum_kernel(int64_t M, int64_t N, const void* Xv, int64_t ldx, float* out, int rows_per_block) {
     // block = 256 threads = 64 columns x 4 row-lanes; grid.x over column groups, grid.y over row slabs
     __shared__ float red[4][64];
     const int col = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -441,7 +442,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(int64_t M, int64_t N, const
     const int64_t r1 = min(M, r0 + rows_per_block);
     float s = 0.f;
     if (col < N)
-        for (int64_t r = r0 + rl; r < r1; r += 4) s += bf2f(X[r * ldx + col]);
+        for (int64_t r = r0 + rl; r < r1; r += 4)
+            s += DT == MI355_DT_BF16 ? bf2f(reinterpret_cast<const bf16_t*>(Xv)[r * ldx + col]) : reinterpret_cast<const float*>(Xv)[r * ldx + col];
     red[rl][threadIdx.x & 63] = s;
     __syncthreads();
     if (rl == 0 && col < N) {
@@ -492,19 +494,22 @@ extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const 
     }
 }
 
-extern "C" int mi355_colsum_bf16(int64_t M, int64_t N, const void* X, int64_t ldx, float* out, int accumulate,
-                                 void* stream) {
-    MI355_REQUIRE(M > 0 && N > 0 && X && out, "mi355_colsum_bf16: bad arguments");
+extern "C" int mi355_colsum(int64_t M, int64_t N, const void* X, int x_dtype, int64_t ldx, float* out, int accumulate,
+                            void* stream) {
+    MI355_REQUIRE(M > 0 && N > 0 && X && out, "mi355_colsum: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     if (!accumulate) {
         if (hipMemsetAsync(out, 0, N * sizeof(float), s) != hipSuccess) {
-            mi355_set_error("mi355_colsum_bf16: memset failed");
+            mi355_set_error("mi355_colsum: memset failed");
             return 2;
         }
     }
     const int rows_per_block = 512;
     dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + rows_per_block - 1) / rows_per_block));
-    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, M, N, (const bf16_t*)X, ldx, out, rows_per_block);
-    MI355_LAUNCH_CHECK("mi355_colsum_bf16");
+    if (x_dtype == MI355_DT_BF16)
+        hipLaunchKernelGGL(colsum_kernel<MI355_DT_BF16>, grid, dim3(256), 0, s, M, N, X, ldx, out, rows_per_block);
+    else
+        hipLaunchKernelGGL(colsum_kernel<MI355_DT_F32>, grid, dim3(256), 0, s, M, N, X, ldx, out, rows_per_block);
+    MI355_LAUNCH_CHECK("mi355_colsum");
     return 0;
 }

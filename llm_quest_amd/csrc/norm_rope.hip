@@ -405,6 +405,48 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int64_t rows, int wi
     }
 }
 
+// backward of y = scale*n + shift, n = (x-mean)*rsig, rsig = 1/(sigma+eps):
+//   dn = dy*scale;  dx = rsig * (dn - mean(dn) - n * mean(dn*n) * (1/rsig)/(1/rsig - eps)) (+ dres)
+//   dscale = sum_rows dy*n, dshift = sum_rows dy   (per-block partials [parts][2*width], LDS-merged)
+template <int DY_DT>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int width, const float* __restrict__ x,
+                                                            const float* __restrict__ scale, const float* __restrict__ mean,
+                                                            const float* __restrict__ rsig, const void* __restrict__ dy,
+                                                            const float* __restrict__ dres, float* __restrict__ dx,
+                                                            float* __restrict__ dparam_partial, float eps) {
+    extern __shared__ __attribute__((aligned(16))) float dp_lds[];  // [2*width]
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 2 * width; i += 256) dp_lds[i] = 0.f;
+    __syncthreads();
+    auto load_dy = [&](int64_t row, int c) -> float {
+        if (DY_DT == MI355_DT_BF16) return bf2f(reinterpret_cast<const bf16_t*>(dy)[row * width + c]);
+        return reinterpret_cast<const float*>(dy)[row * width + c];
+    };
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+        const float mu = mean[row], rs = rsig[row];
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = lane; c < width; c += 64) {
+            const float n = (x[row * width + c] - mu) * rs;
+            const float g = load_dy(row, c);
+            const float dn = g * scale[c];
+            s1 += dn;
+            s2 += dn * n;
+            atomicAdd(&dp_lds[c], g * n);
+            atomicAdd(&dp_lds[width + c], g);
+        }
+        s1 = wave_sum(s1) / (float)width;
+        s2 = wave_sum(s2) / (float)width;
+        const float s_over_sigma = (1.0f / rs) / (1.0f / rs - eps);
+        for (int c = lane; c < width; c += 64) {
+            const float n = (x[row * width + c] - mu) * rs;
+            const float dn = load_dy(row, c) * scale[c];
+            dx[row * width + c] = rs * (dn - s1 - n * s2 * s_over_sigma) + (dres ? dres[row * width + c] : 0.f);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * width; i += 256) dparam_partial[(int64_t)blockIdx.x * 2 * width + i] = dp_lds[i];
+}
+
 inline int row_grid(int64_t rows) {
     int64_t g = (rows + 3) / 4;
     return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -494,5 +536,19 @@ extern "C" int mi355_layernorm_fwd(int64_t rows, int width, const float* x, cons
     else
         hipLaunchKernelGGL(layernorm_fwd_kernel<MI355_DT_F32>, dim3(grid), dim3(256), 0, s, rows, width, x, scale, shift, y, mean, rsig, eps);
     MI355_LAUNCH_CHECK("mi355_layernorm_fwd");
+    return 0;
+}
+
+extern "C" int mi355_layernorm_bwd(int64_t rows, int width, const float* x, const float* scale, const float* mean, const float* rsig,
+                                   const void* dy, int dy_dtype, const float* dres, float* dx, float* dparam_partial, int parts,
+                                   float eps, void* stream) {
+    MI355_REQUIRE(rows > 0 && width > 0 && width <= 8192 && parts > 0, "mi355_layernorm_bwd: bad shape");
+    MI355_REQUIRE(x && scale && mean && rsig && dy && dx && dparam_partial, "mi355_layernorm_bwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (dy_dtype == MI355_DT_BF16)
+        hipLaunchKernelGGL(layernorm_bwd_kernel<MI355_DT_BF16>, dim3(parts), dim3(256), 2 * width * sizeof(float), s, rows, width, x, scale, mean, rsig, dy, dres, dx, dparam_partial, eps);
+    else
+        hipLaunchKernelGGL(layernorm_bwd_kernel<MI355_DT_F32>, dim3(parts), dim3(256), 2 * width * sizeof(float), s, rows, width, x, scale, mean, rsig, dy, dres, dx, dparam_partial, eps);
+    MI355_LAUNCH_CHECK("mi355_layernorm_bwd");
     return 0;
 }

@@ -16,9 +16,40 @@ def _cross_entropy(logits2d, targets):
     """CE with ignore_index=-100: HIP kernel for bf16 device logits, torch for host tensors (CPU plumbing config)."""
     if logits2d.is_cuda and logits2d.dtype == torch.bfloat16:
         t = targets.reshape(-1).contiguous()
-        lg = logits2d if logits2d.stride(-1) == 1 else logits2d.contiguous()
+        lg = logits2d if (logits2d.stride(-1) == 1 and logits2d.stride(0) % 8 == 0) else _pad_rows(logits2d)
         return ops.CrossEntropyFn.apply(lg, t).to(logits2d.dtype)  # the reference returns the loss in the logits dtype
+    if logits2d.is_cuda and logits2d.dtype == torch.float32 and not logits2d.requires_grad:
+        from . import kernels as K  # eval-mode fp32 logits (e.g. the ViT classifier head): evaluate through the bf16 CE kernel
+
+        return _cross_entropy(K.cast(logits2d.contiguous(), torch.bfloat16), targets).float()
     return torch.nn.functional.cross_entropy(logits2d, targets)
+
+
+class _PadRowsFn(torch.autograd.Function):
+    """Copy [rows, V] into a buffer whose row pitch is a multiple of 8 elements (16-byte rows for the CE kernel)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        from . import kernels as K
+
+        rows, v = x.shape
+        pitch = (v + 7) // 8 * 8
+        buf = torch.empty((rows, pitch), dtype=x.dtype, device=x.device)
+        K.copy2d(x if x.stride(-1) == 1 else x.contiguous(), buf[:, :v])
+        ctx.v = v
+        return buf[:, :v]
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import kernels as K
+
+        out = torch.empty((g.shape[0], ctx.v), dtype=g.dtype, device=g.device)
+        K.copy2d(g if g.stride(-1) == 1 else g.contiguous(), out)
+        return out
+
+
+def _pad_rows(x):
+    return _PadRowsFn.apply(x)
 
 
 def global_loss(logits, y, model=None, classification=False):

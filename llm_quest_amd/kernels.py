@@ -73,11 +73,14 @@ def gemm(form, a, b, out=None, out_dtype=BF16, bias=None, residual=None, gelu=Fa
 
 
 def colsum(x, out=None, accumulate=False):
-    L.require_gpu(x)
+    """out[n] (+)= sum_m x[m, n]; x bf16 or fp32 (row-strided views allowed), out fp32."""
+    L.require_gpu(x, out)
     _rowmajor(x, "X")
     if out is None:
         out = torch.empty(x.shape[1], dtype=F32, device=x.device)
-    L.call("mi355_colsum_bf16", x.shape[0], x.shape[1], L.ptr(x), x.stride(0), L.ptr(out), int(accumulate))
+    if out.dtype != F32 or out.numel() != x.shape[1] or not out.is_contiguous():
+        raise ValueError("colsum: out must be contiguous fp32 [N]")
+    L.call("mi355_colsum", x.shape[0], x.shape[1], L.ptr(x), L.dt_code(x.dtype), x.stride(0), L.ptr(out), int(accumulate))
     return out
 
 
@@ -206,9 +209,8 @@ def cross_entropy(logits2d, targets, want_grad, grad_scale=None, inplace=True):
     loss_rows = torch.empty(rows, dtype=F32, device=logits2d.device)
     dl = None
     if want_grad:
-        dl = logits2d if inplace else torch.empty_like(logits2d)
-        if dl.stride(0) != logits2d.stride(0):
-            raise ValueError("cross_entropy: dlogits must share the logits row pitch")
+        # the gradient shares the logits' row pitch (the kernel addresses both with one leading dimension)
+        dl = logits2d if inplace else torch.empty_strided(tuple(logits2d.shape), logits2d.stride(), dtype=logits2d.dtype, device=logits2d.device)
     L.call("mi355_cross_entropy", rows, V, L.ptr(logits2d), logits2d.stride(0), L.ptr(targets), L.ptr(loss_rows), L.ptr(dl), L.ptr(grad_scale))
     return loss_rows, dl
 
@@ -337,3 +339,30 @@ def gelu_bwd(x, dy):
     dx = torch.empty_like(x)
     L.call("mi355_gelu_bwd", x.numel(), L.ptr(x), L.ptr(dy), L.ptr(dx))
     return dx
+
+
+def layernorm_bwd(x2d, scale, mean, rsig, dy, dres=None, eps=1e-5, dscale_out=None, dshift_out=None, accumulate=False):
+    """Returns dx fp32 (+ dres).  dscale/dshift go to the given fp32 destinations (optionally accumulated) or new tensors."""
+    L.require_gpu(x2d, dy, dres)
+    rows, width = x2d.shape
+    if x2d.dtype != F32 or not x2d.is_contiguous() or not dy.is_contiguous() or dy.shape != x2d.shape:
+        raise ValueError("layernorm_bwd: x fp32 contiguous, dy contiguous of the same shape")
+    if dres is not None and (dres.dtype != F32 or not dres.is_contiguous() or dres.shape != x2d.shape):
+        raise ValueError("layernorm_bwd: dres must be contiguous fp32 like x")
+    dx = torch.empty_like(x2d)
+    parts = min(256, (rows + 3) // 4)
+    part = torch.empty((parts, 2 * width), dtype=F32, device=x2d.device)
+    L.call("mi355_layernorm_bwd", rows, width, L.ptr(x2d), L.ptr(scale), L.ptr(mean), L.ptr(rsig), L.ptr(dy), L.dt_code(dy.dtype), L.ptr(dres), L.ptr(dx), L.ptr(part), parts, eps)
+    both = torch.empty(2 * width, dtype=F32, device=x2d.device)
+    L.call("mi355_reduce_rows_f32", parts, 2 * width, L.ptr(part), L.ptr(both), L.DT_F32, 0)
+    outs = []
+    for src, dst in ((both[:width], dscale_out), (both[width:], dshift_out)):
+        if dst is None:
+            outs.append(src)
+        else:
+            if accumulate:
+                dst.add_(src) if not dst.is_cuda else L.call("mi355_reduce_rows_f32", 1, width, L.ptr(src.contiguous()), L.ptr(dst), L.DT_F32, 1)
+            else:
+                L.call("mi355_reduce_rows_f32", 1, width, L.ptr(src.contiguous()), L.ptr(dst), L.DT_F32, 0)
+            outs.append(dst)
+    return dx, outs[0], outs[1]

@@ -104,9 +104,37 @@ class ViTAdapter(torch.nn.Module):
 
 
 def vit_training_eval_loop(train_loader, val_loader, model, optimizer, num_epoch, lr_scheduler, eval_freq, eval_iter, device, use_amp=True):
-    """Signature of the reference loop (vit_engine.py:62-147).  Training the ViT needs its backward kernels, which are
-    not part of this round (the VLM step keeps the ViT frozen); evaluation helpers below work."""
-    raise NotImplementedError("ViT training (BASELINE config 2) needs the ViT backward kernels: planned, see DESIGN.md 'next'")
+    """ViT train/eval loop with LR schedule, clip(1.0) and per-epoch accuracy (reference: vit_engine.py:62-147).
+
+    The HIP ViT always computes with bf16 MFMA operands over fp32 master weights -- exactly what ``use_amp=True`` asks
+    of autocast upstream -- so ``use_amp`` is accepted for API parity and does not change the kernels.
+    """
+    from llm_quest_amd.engine import _cross_entropy, clip_grad_norm_
+
+    step = 0
+    train_losses, val_losses, train_accus, val_accus = [], [], [], []
+    for epoch in range(1, num_epoch + 1):
+        model.train()
+        for input_batch, targets in train_loader:
+            input_batch, targets = input_batch.to(device), targets.to(device)
+            logits = model(input_batch)
+            loss = _cross_entropy(logits, targets)
+            optimizer.zero_grad()
+            loss.backward()
+            clip_grad_norm_(model.parameters(), max_norm=1)
+            lr_scheduler.step(step)
+            optimizer.step()
+            step += 1
+            if step == 1 or step % eval_freq == 0:
+                tr, va = ViT.evaluate(train_loader, val_loader, model, eval_iter, device)
+                train_losses.append(tr)
+                val_losses.append(va)
+                print(f"Epoch: {epoch}, Step: {step}", f"Train loss: {tr:.5f}, Val loss: {va:.5f}", f"lr: {lr_scheduler.current_lr:.1e}")
+    # accuracy once after the last epoch, as upstream (its block sits outside the epoch loop)
+    train_accus.append(ViT.accuracy_loader(train_loader, model, device))
+    val_accus.append(ViT.accuracy_loader(val_loader, model, device))
+    print(f"training accu epoch {num_epoch}: {train_accus[-1]*100:.4f}%", f"validation accu epoch {num_epoch}: {val_accus[-1]*100:.4f}%")
+    return train_losses, val_losses, train_accus, val_accus
 
 
 class ViT:
@@ -138,7 +166,9 @@ class ViT:
         for i, (x, y) in enumerate(dataloader):
             if i >= n:
                 break
-            tot += float(torch.nn.functional.cross_entropy(model(x.to(device)).float(), y.to(device)))
+            from llm_quest_amd.engine import _cross_entropy
+
+            tot += float(_cross_entropy(model(x.to(device)), y.to(device)))
         return tot / n
 
     @staticmethod

@@ -59,7 +59,11 @@ class ViTModel(nn.Module):
 
     def forward(self, x, output_hidden_states=False):
         L.require_gpu(x)
-        refuse_training(self, "ViTModel")
+        from llm_quest_amd.multimodal.vision_transformer import vit_train
+
+        if vit_train.needs_training_path(self):
+            # trainable ViT (BASELINE config 2): one autograd node, bf16 logits as under the reference's autocast
+            return vit_train.run_train(self, x, output_hidden_states)
         if self.training and self.dropout.p > 0:
             raise NotImplementedError("dropout is not implemented on the HIP path; use eval() or drop_rate=0")
         b = x.shape[0]

@@ -1,0 +1,203 @@
+"""ViT forward+backward on HIP kernels (BASELINE config 2: ViT-Base/16 fwd+bwd in bf16).
+
+Dtype flow = the reference under ``torch.autocast(bf16)``: fp32 master parameters and fp32 residual
+stream, bf16 MFMA operands (weights cast once per step, LayerNorm outputs written as bf16), bf16 logits.  The whole
+encoder is ONE autograd node: forward keeps what backward needs (28 KB per token per layer), backward runs the dgrad /
+wgrad GEMMs, flash-attention backward (non-causal, D=64), exact-GELU and LayerNorm(sigma+eps) backward kernels and writes
+every parameter gradient (fp32) straight into ``p.grad``.
+"""
+
+import torch
+
+from llm_quest_amd import _lib as L
+from llm_quest_amd import kernels as K
+from llm_quest_amd.multimodal.vision_transformer.vit_attention import bf16_cached, f32_cat_cached
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+# ------------------------------------------------------------------------------------------- gradient sinks
+def _grad_buf(p):
+    """(destination fp32 tensor, accumulate?) for parameter p; attaches a fresh .grad when there is none."""
+    if p.grad is None:
+        p.grad = torch.empty_like(p)
+        return p.grad, False
+    return p.grad, True
+
+
+def _acc(p, g):
+    """p.grad (+)= g  (g: contiguous fp32 with p.numel() elements)."""
+    if not p.requires_grad:
+        return
+    dst, acc = _grad_buf(p)
+    L.call("mi355_reduce_rows_f32", 1, p.numel(), L.ptr(g), L.ptr(dst), L.DT_F32, int(acc))
+
+
+def _wgrad(p, dy, x):
+    """p.grad[N,K] (+)= dy^T x  (TN GEMM, fp32 output)."""
+    if not p.requires_grad:
+        return
+    dst, acc = _grad_buf(p)
+    view = dst.view(dy.shape[1], x.shape[1])
+    K.gemm(L.GEMM_TN, dy, x, out=view, residual=view if acc else None)
+
+
+def _bgrad(p, dy):
+    if p is None or not p.requires_grad:
+        return
+    dst, acc = _grad_buf(p)
+    K.colsum(dy, out=dst.view(-1), accumulate=acc)
+
+
+def _ln_bwd(ln, x2d, mean, rsig, dy, dres):
+    dx, dsc, dsh = K.layernorm_bwd(x2d, ln.scale.detach(), mean, rsig, dy, dres=dres, eps=ln.eps)
+    _acc(ln.scale, dsc.contiguous())
+    _acc(ln.shift, dsh.contiguous())
+    return dx
+
+
+# ------------------------------------------------------------------------------------------- forward
+def vit_forward_train(m, img, output_hidden_states):
+    pe = m.patch_embedding
+    B = img.shape[0]
+    S, d = pe.num_patches + 1, m.pos_embedding.shape[-1]
+    if m.training and m.dropout.p > 0:
+        raise NotImplementedError("dropout is not implemented on the HIP path; train with drop_rate=0 (SURVEY.md section 7, hard parts)")
+    rows = K.patchify(img.contiguous().to(F32), pe.patch_size, out_dtype=BF16)
+    wconv = bf16_cached(pe, "wconv", [pe.conv_proj.weight])
+    proj = K.gemm(L.GEMM_NT, rows, wconv, bias=pe.conv_proj.bias.detach(), out_dtype=F32)
+    x = K.vit_embed_assemble(proj, pe.cls_token.detach().reshape(-1).contiguous(), m.pos_embedding.detach().reshape(S, d).contiguous(), B, S, d).view(B * S, d)
+    saved_blocks = []
+    for blk in m.transformer_blocks:
+        att, ffn = blk.att, blk.ffn
+        H, Dh = att.num_heads, att.head_dim
+        h1, mean1, rsig1 = K.layernorm_fwd(x, blk.ln_1.scale.detach(), blk.ln_1.shift.detach(), out_dtype=BF16, eps=blk.ln_1.eps, want_stats=True)
+        wqkv = bf16_cached(att, "wqkv", [att.w_queries.weight, att.w_keys.weight, att.w_values.weight])
+        bqkv = f32_cat_cached(att, "bqkv", [att.w_queries.bias, att.w_keys.bias, att.w_values.bias]) if att.w_queries.bias is not None else None
+        qkv = K.gemm(L.GEMM_NT, h1, wqkv, bias=bqkv)
+        ctx, lse = K.attn_fwd(qkv[:, :d], qkv[:, d : 2 * d], qkv[:, 2 * d :], B, S, H, H, Dh, key_mask=None, causal=False, scale=att.att_scaling)
+        wo = bf16_cached(att, "wo", [att.out_proj.weight])
+        x2 = K.gemm(L.GEMM_NT, ctx, wo, bias=att.out_proj.bias.detach(), residual=x, out_dtype=F32)
+        h2, mean2, rsig2 = K.layernorm_fwd(x2, blk.ln_2.scale.detach(), blk.ln_2.shift.detach(), out_dtype=BF16, eps=blk.ln_2.eps, want_stats=True)
+        w1 = bf16_cached(ffn, "w1", [ffn.layers[0].weight])
+        y1 = K.gemm(L.GEMM_NT, h2, w1, bias=ffn.layers[0].bias.detach())
+        f = K.gelu_fwd(y1)
+        w2 = bf16_cached(ffn, "w2", [ffn.layers[2].weight])
+        x3 = K.gemm(L.GEMM_NT, f, w2, bias=ffn.layers[2].bias.detach(), residual=x2, out_dtype=F32)
+        saved_blocks.append((x, mean1, rsig1, h1, qkv, ctx, lse, x2, mean2, rsig2, h2, y1, f))
+        x = x3
+    ln = m.final_ln
+    if output_hidden_states:
+        out, meanf, rsigf = K.layernorm_fwd(x, ln.scale.detach(), ln.shift.detach(), out_dtype=F32, eps=ln.eps, want_stats=True)
+        tail = ("hidden", x, meanf, rsigf)
+        out = out.view(B, S, d)
+    else:
+        cls_rows = torch.empty((B, d), dtype=F32, device=x.device)
+        K.copy2d(x.view(B, S * d)[:, :d], cls_rows)
+        cls_n, meanf, rsigf = K.layernorm_fwd(cls_rows, ln.scale.detach(), ln.shift.detach(), out_dtype=BF16, eps=ln.eps, want_stats=True)
+        wc = bf16_cached(m, "wcls", [m.classifier.weight])
+        out = K.gemm(L.GEMM_NT, cls_n, wc, bias=m.classifier.bias.detach(), out_dtype=BF16)
+        tail = ("logits", cls_rows, meanf, rsigf, cls_n)
+    return out, (rows, saved_blocks, tail, (B, S, d))
+
+
+# ------------------------------------------------------------------------------------------- backward
+def vit_backward(m, saved, dout):
+    rows, saved_blocks, tail, (B, S, d) = saved
+    pe = m.patch_embedding
+    ln = m.final_ln
+    if tail[0] == "hidden":
+        _, xl, meanf, rsigf = tail
+        g = dout.reshape(B * S, d)
+        g = g if g.is_contiguous() else g.contiguous()
+        dx = _ln_bwd(ln, xl, meanf, rsigf, g if g.dtype in (F32, BF16) else g.to(F32), None)
+    else:
+        _, cls_rows, meanf, rsigf, cls_n = tail
+        dlog = dout.contiguous()
+        dlog = dlog if dlog.dtype == BF16 else K.cast(dlog, BF16)
+        wc = bf16_cached(m, "wcls", [m.classifier.weight])
+        ncls = dlog.shape[1]
+        if ncls % 8:  # the dgrad / wgrad GEMMs need 16-byte rows: pad the class dimension with zero columns
+            pad = (ncls + 7) // 8 * 8
+            dl_p = torch.zeros((B, pad), dtype=BF16, device=dlog.device)
+            K.copy2d(dlog, dl_p[:, :ncls])
+            wc_p = torch.zeros((pad, d), dtype=BF16, device=dlog.device)
+            K.copy2d(wc, wc_p[:ncls])
+        else:
+            dl_p, wc_p = dlog, wc
+        dcls_n = K.gemm(L.GEMM_NN, dl_p, wc_p)
+        if m.classifier.weight.requires_grad:
+            gw = K.gemm(L.GEMM_TN, dl_p, cls_n, out_dtype=F32)  # [pad, d]
+            _acc(m.classifier.weight, gw[:ncls].contiguous())
+        _bgrad(m.classifier.bias, dlog)
+        dcls = _ln_bwd(ln, cls_rows, meanf, rsigf, dcls_n, None)
+        dx = torch.zeros((B * S, d), dtype=F32, device=dcls.device)
+        K.copy2d(dcls, dx.view(B, S * d)[:, :d])
+    for blk, sv in zip(reversed(m.transformer_blocks), reversed(saved_blocks)):
+        x, mean1, rsig1, h1, qkv, ctx, lse, x2, mean2, rsig2, h2, y1, f = sv
+        att, ffn = blk.att, blk.ffn
+        H, Dh = att.num_heads, att.head_dim
+        # ---- FFN half
+        dx3b = K.cast(dx, BF16)
+        df = K.gemm(L.GEMM_NN, dx3b, bf16_cached(ffn, "w2", [ffn.layers[2].weight]))
+        _wgrad(ffn.layers[2].weight, dx3b, f)
+        _bgrad(ffn.layers[2].bias, dx3b)
+        dy1 = K.gelu_bwd(y1, df)
+        dh2 = K.gemm(L.GEMM_NN, dy1, bf16_cached(ffn, "w1", [ffn.layers[0].weight]))
+        _wgrad(ffn.layers[0].weight, dy1, h2)
+        _bgrad(ffn.layers[0].bias, dy1)
+        dx2 = _ln_bwd(blk.ln_2, x2, mean2, rsig2, dh2, dx)
+        # ---- attention half
+        dx2b = K.cast(dx2, BF16)
+        dctx = K.gemm(L.GEMM_NN, dx2b, bf16_cached(att, "wo", [att.out_proj.weight]))
+        _wgrad(att.out_proj.weight, dx2b, ctx)
+        _bgrad(att.out_proj.bias, dx2b)
+        dqkv = torch.empty_like(qkv)
+        K.attn_bwd(qkv[:, :d], qkv[:, d : 2 * d], qkv[:, 2 * d :], ctx, dctx, lse, B, S, H, H, Dh,
+                   dqkv[:, :d], dqkv[:, d : 2 * d], dqkv[:, 2 * d :], key_mask=None, causal=False, scale=att.att_scaling)
+        wqkv = bf16_cached(att, "wqkv", [att.w_queries.weight, att.w_keys.weight, att.w_values.weight])
+        dh1 = K.gemm(L.GEMM_NN, dqkv, wqkv)
+        gw = K.gemm(L.GEMM_TN, dqkv, h1, out_dtype=F32)  # [3d, d] fused, then split over the three parameters
+        for i, lin in enumerate((att.w_queries, att.w_keys, att.w_values)):
+            _acc(lin.weight, gw[i * d : (i + 1) * d])
+        if att.w_queries.bias is not None:
+            gb = K.colsum(dqkv)
+            for i, lin in enumerate((att.w_queries, att.w_keys, att.w_values)):
+                _acc(lin.bias, gb[i * d : (i + 1) * d])
+        dx = _ln_bwd(blk.ln_1, x, mean1, rsig1, dh1, dx2)
+    # ---- embedding: pos / cls sums over the batch, patch projection wgrad
+    gpos = K.colsum(dx.view(B, S * d))  # sum_b dh[b, s, :]
+    _acc(m.pos_embedding, gpos)
+    _acc(pe.cls_token, gpos[:d].contiguous())
+    npatch = S - 1
+    dproj = torch.empty((B, npatch * d), dtype=F32, device=dx.device)
+    K.copy2d(dx.view(B, S * d)[:, d:], dproj)
+    dproj_b = K.cast(dproj, BF16).view(B * npatch, d)
+    _wgrad(pe.conv_proj.weight, dproj_b, rows)
+    _bgrad(pe.conv_proj.bias, dproj_b)
+
+
+class ViTTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, model, output_hidden_states, *params):
+        out, saved = vit_forward_train(model, img, output_hidden_states)
+        ctx.model, ctx.saved = model, saved
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if ctx.saved is None:
+            raise RuntimeError("ViTTrainFn: backward called twice")
+        vit_backward(ctx.model, ctx.saved, dout)
+        ctx.saved = None
+        return (None, None, None) + (None,) * len(ctx.model._param_list)
+
+
+def needs_training_path(model):
+    return torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
+
+
+def run_train(model, img, output_hidden_states):
+    if not hasattr(model, "_param_list"):
+        object.__setattr__(model, "_param_list", list(model.parameters()))
+    return ViTTrainFn.apply(img, model, output_hidden_states, *model._param_list)
