@@ -48,6 +48,7 @@ struct TileCfg {
 };
 using Cfg128 = TileCfg<128, 128, 2, 2, 64, 2>;      // 68 KiB LDS, 2 workgroups / CU, vmcnt(0) structure
 using Cfg256 = TileCfg<256, 256, 2, 4, 64, 2>;      // 136 KiB LDS, 1 workgroup (8 waves) / CU
+using Cfg256a = TileCfg<256, 256, 2, 4, 32, 4>;     // 136 KiB LDS, 4-stage ring, alternating wave groups
 
 struct GemmParams {
     const bf16_t* A;
@@ -191,6 +192,80 @@ __global__ __launch_bounds__(T::NTHREADS, T::MIN_WAVES) void gemm_bf16_kernel(Ge
     const int t0 = split * per;
     const int nt = min(nt_all, t0 + per);
 
+    bool extra_barrier = false;
+    if constexpr (T::BK == 32) {
+        // ---- alternating-group loop (8 waves, BK = 32, NS-stage ring).  Waves 4-7 run ONE barrier behind waves 0-3, so on
+        // every SIMD one wave is in its 16-MFMA cluster while its partner is in the load segment (fragment reads, two
+        // LDS-DMA issues, waits).  A phase = { load segment ; lgkmcnt(0) ; s_barrier ; 16 MFMAs ; s_barrier }, two phases per
+        // K-tile (row halves mh = 0, 1).  Hazards: a wave's reads of tile t are complete before the barrier that precedes
+        // its last MFMA cluster of that tile, and the slot is refilled (tile t+NS) only after that wave group's following
+        // barrier, which the other group reaches after completing ITS reads; tile t+1 is waited for (counted vmcnt) in
+        // phase 1 of tile t, a full cluster + barrier before anyone reads it.
+        static_assert(T::NW == 8 && T::KK == 1 && T::NS >= 3 && T::A_PPW == 2 && T::B_PPW == 2, "alternating loop: 8 waves, 2+2 DMA pieces per tile");
+        constexpr int HM = T::FM / 2;
+        const bool late = wave >= 4;  // wave-uniform (readfirstlane above)
+#pragma unroll
+        for (int i = 0; i < T::NS - 1; ++i)
+            if (t0 + i < nt) issue_tile(t0 + i, i);
+        if (t0 < nt) {
+            const int younger = nt - 1 - t0;
+            if (younger >= 2) wait_vmcnt<8>(); else if (younger >= 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();  // tile t0 landed for every wave
+        if (late) __builtin_amdgcn_s_barrier();
+        bf16x8 a[HM], b[T::FN];
+        for (int t = t0; t < nt; ++t) {
+            const char* sA = smem + ((t - t0) % T::NS) * T::STAGE;
+            const char* sB = sA + T::A_BYTES;
+            const int nxt = t + T::NS - 1;
+            const int nst = (nxt - t0) % T::NS;
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                // -------- load segment
+                if (ph == 0) {
+#pragma unroll
+                    for (int j = 0; j < T::FN; ++j) b[j] = B_TR ? frag_tr<T::BN>(sB, wc0 + j * 16, 0, lane) : frag_rowk<BK>(sB, wc0 + j * 16, 0, lane);
+                }
+#pragma unroll
+                for (int i = 0; i < HM; ++i) {
+                    const int r0 = wr0 + (ph * HM + i) * 16;
+                    a[i] = A_TR ? frag_tr<T::BM>(sA, r0, 0, lane) : frag_rowk<BK>(sA, r0, 0, lane);
+                }
+                if (nxt < nt) {  // two of this wave's four DMA pieces of tile t+NS-1 per phase: A pieces, then B pieces
+                    const int64_t krem = p.K - (int64_t)nxt * BK;
+                    if (ph == 0) {
+                        const bf16_t* pa = baseA + nxt * stepA;
+                        char* dA = smem + nst * T::STAGE + wave * T::A_PPW * 1024;
+#pragma unroll
+                        for (int j = 0; j < T::A_PPW; ++j) dma_piece(pa, kneedA[j] < krem ? voffA[j] : OOB, dA + j * 1024);
+                    } else {
+                        const bf16_t* pb = baseB + nxt * stepB;
+                        char* dB = smem + nst * T::STAGE + T::A_BYTES + wave * T::B_PPW * 1024;
+#pragma unroll
+                        for (int j = 0; j < T::B_PPW; ++j) dma_piece(pb, kneedB[j] < krem ? voffB[j] : OOB, dB + j * 1024);
+                    }
+                }
+                if (ph == 1 && t + 1 < nt) {  // this wave's share of tile t+1 has landed (tiles t+2.. may stay in flight)
+                    const int younger = min(nt - 1, t + T::NS - 1) - (t + 1);
+                    if (younger >= 2) wait_vmcnt<8>(); else if (younger >= 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                // -------- MFMA cluster
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < HM; ++i)
+#pragma unroll
+                    for (int j = 0; j < T::FN; ++j)
+                        acc[ph * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[ph * HM + i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+        extra_barrier = !late;  // the early group balances the late group's extra barrier
+    } else {
     // ---- main loop: 4 phases per K-tile = (k-step kk, half of the wave's rows mh); the fragments of phase p+1 are read
     // from LDS while the MFMAs of phase p run (two register sets for the A half, two for B), so the matrix pipe is not
     // idle during fragment reads.  The per-tile barrier sits in front of the LAST phase's MFMA cluster: by then every
@@ -263,6 +338,8 @@ __global__ __launch_bounds__(T::NTHREADS, T::MIN_WAVES) void gemm_bf16_kernel(Ge
         mma(aO, b1, 1);  // phase 3
     }
 
+    }
+    if (extra_barrier) __builtin_amdgcn_s_barrier();
     // ---- epilogue: acc -> LDS (fp32, 64x64 per wave at a time) -> coalesced rows ---------------------------------
     __syncthreads();
     float* stg = reinterpret_cast<float*>(smem) + wave * 64 * EPI_LD;
@@ -472,7 +549,7 @@ extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const 
     MI355_REQUIRE(workspace == nullptr || ((uintptr_t)workspace & 15) == 0, "mi355_gemm_bf16: workspace must be 16-byte aligned");
     const int ablate = tile_hint >> 8;
     tile_hint &= 0xff;
-    MI355_REQUIRE(tile_hint >= 0 && tile_hint <= 2, "mi355_gemm_bf16: tile_hint must be 0 (auto), 1 (128x128 tile) or 2 (256x256 tile)");
+    MI355_REQUIRE(tile_hint >= 0 && tile_hint <= 3, "mi355_gemm_bf16: tile_hint must be 0 (auto), 1 (128x128), 2 (256x256) or 3 (256x256, alternating wave groups)");
     GemmParams p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.bias = bias; p.R = residual;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
@@ -480,16 +557,16 @@ extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const 
     hipStream_t s = (hipStream_t)stream;
     int cfg = tile_hint;
     if (cfg == 0) {
-        // measured on MI355X over the VLM step's shapes (tools/gemm_sweep.py): the 8-wave 256x256 tile wins when it still
-        // fills the chip several times over, or when K is so long that the main loop dominates (LM head); short-K forward
-        // projections and anything with few tiles stay on 128x128 (2 workgroups per CU).
-        const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
-        bool big = t256 >= 1536 || (K >= 32768 && t256 >= 192);
-        if (form != MI355_GEMM_NT && t256 >= 640) big = true;
-        cfg = big ? 2 : 1;
+        // measured on MI355X over the VLM step's shapes (tools/gemm_sweep.py): the alternating-group 256x256 kernel wins for
+        // forward / dgrad shapes and for the large weight gradients; small weight gradients (few tiles, K = tokens) do
+        // better on 128x128 tiles with split-K; tiny problems stay on 128x128.
+        if (M < 256 || N < 256) cfg = 1;
+        else if (form == MI355_GEMM_TN) cfg = (M * N > 5 * 1024 * 1024) ? 3 : 1;
+        else cfg = 3;
     }
     switch (cfg) {
         case 2: return launch_form<Cfg256>(form, p, out_dtype, workspace, workspace_bytes, s);
+        case 3: return launch_form<Cfg256a>(form, p, out_dtype, workspace, workspace_bytes, s);
         default: return launch_form<Cfg128>(form, p, out_dtype, workspace, workspace_bytes, s);
     }
 }

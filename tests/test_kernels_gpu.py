@@ -54,7 +54,7 @@ GEMM_SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("tile", [1, 2])
+@pytest.mark.parametrize("tile", [1, 2, 3])
 @pytest.mark.parametrize("form", ["NT", "NN", "TN"])
 @pytest.mark.parametrize("M,N,K_", GEMM_SHAPES)
 def test_gemm_forms(K, form, M, N, K_, tile):

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from llm_quest_amd import _lib as L, kernels as K
 
-ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=32); ap.add_argument("--tiles", default="1,2"); ap.add_argument("--only", default=""); args = ap.parse_args()
+ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=32); ap.add_argument("--tiles", default="1,2,3"); ap.add_argument("--only", default=""); args = ap.parse_args()
 TILES = [int(x) for x in args.tiles.split(",")]
 M, Mh = args.batch * 709, args.batch * 512
 dev = "cuda"
