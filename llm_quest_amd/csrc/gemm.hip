@@ -222,16 +222,18 @@ __global__ __launch_bounds__(T::NTHREADS, T::MIN_WAVES) void gemm_bf16_kernel(Ge
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph) {
                 // -------- load segment
-                if (ph == 0) {
+                if (!(p.ablate & 2) || t == t0) {
+                    if (ph == 0) {
 #pragma unroll
-                    for (int j = 0; j < T::FN; ++j) b[j] = B_TR ? frag_tr<T::BN>(sB, wc0 + j * 16, 0, lane) : frag_rowk<BK>(sB, wc0 + j * 16, 0, lane);
-                }
+                        for (int j = 0; j < T::FN; ++j) b[j] = B_TR ? frag_tr<T::BN>(sB, wc0 + j * 16, 0, lane) : frag_rowk<BK>(sB, wc0 + j * 16, 0, lane);
+                    }
 #pragma unroll
-                for (int i = 0; i < HM; ++i) {
-                    const int r0 = wr0 + (ph * HM + i) * 16;
-                    a[i] = A_TR ? frag_tr<T::BM>(sA, r0, 0, lane) : frag_rowk<BK>(sA, r0, 0, lane);
+                    for (int i = 0; i < HM; ++i) {
+                        const int r0 = wr0 + (ph * HM + i) * 16;
+                        a[i] = A_TR ? frag_tr<T::BM>(sA, r0, 0, lane) : frag_rowk<BK>(sA, r0, 0, lane);
+                    }
                 }
-                if (nxt < nt) {  // two of this wave's four DMA pieces of tile t+NS-1 per phase: A pieces, then B pieces
+                if (nxt < nt && !(p.ablate & 1)) {  // two of this wave's four DMA pieces of tile t+NS-1 per phase: A pieces, then B pieces
                     const int64_t krem = p.K - (int64_t)nxt * BK;
                     if (ph == 0) {
                         const bf16_t* pa = baseA + nxt * stepA;
@@ -261,10 +263,10 @@ __global__ __launch_bounds__(T::NTHREADS, T::MIN_WAVES) void gemm_bf16_kernel(Ge
                         acc[ph * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[ph * HM + i][j], 0, 0, 0);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
+                if (!(p.ablate & 4)) __builtin_amdgcn_s_barrier();
             }
         }
-        extra_barrier = !late;  // the early group balances the late group's extra barrier
+        extra_barrier = !late && !(p.ablate & 4);  // the early group balances the late group's extra barrier
     } else {
     // ---- main loop: 4 phases per K-tile = (k-step kk, half of the wave's rows mh); the fragments of phase p+1 are read
     // from LDS while the MFMAs of phase p run (two register sets for the A half, two for B), so the matrix pipe is not
