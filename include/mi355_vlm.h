@@ -76,7 +76,8 @@ int mi355_reduce_rows_f32(int parts, int64_t n, const float* partial, void* out,
 /* Fused per-head QK-RMSNorm + RoPE on the token-major QKV projection (qwen3_attention.py:99-115,
  * common/rope.py:180-243).  qkv bf16 [tokens, (Hq+2Hkv)*D] (q heads, then k heads, then v heads);
  * writes q_out [tokens,Hq*D], k_out [tokens,Hkv*D] bf16 and rstd fp32 [tokens, Hq+Hkv].
- * cos/sin fp32 [ctx, D] (cast to bf16 before use, as the reference does); pos int32 [tokens] = row of cos/sin. */
+ * cos/sin fp32 [ctx, D] (cast to bf16 before use, as the reference does); pos int32 [tokens] = row of cos/sin.
+ * qw == kw == NULL: RoPE only, no normalisation (Qwen3.5 vision attention with 2-D axial tables, rope.py:485-500). */
 int mi355_qknorm_rope_fwd(int64_t tokens, int Hq, int Hkv, int D, const void* qkv, const void* qw, const void* kw,
                           const float* cos, const float* sin, const int32_t* pos, void* q_out, void* k_out,
                           float* rstd, float eps, void* stream);
@@ -90,9 +91,10 @@ int mi355_qknorm_rope_bwd(int64_t tokens, int Hq, int Hkv, int D, const void* qk
 int mi355_swiglu_fwd(int64_t tokens, int F, const void* gu, void* a, void* stream);
 int mi355_swiglu_bwd(int64_t tokens, int F, const void* gu, const void* da, void* dgu, void* stream);
 
-/* Exact (erf) GELU on a bf16 tensor and its backward (nn.GELU() in ViTAdapter, vit_engine.py:50). n % 8 == 0. */
-int mi355_gelu_fwd(int64_t n, const void* x, void* y, void* stream);
-int mi355_gelu_bwd(int64_t n, const void* x, const void* dy, void* dx, void* stream);
+/* GELU on a bf16 tensor and its backward, n % 8 == 0.  kind 0: exact erf (nn.GELU() in ViTAdapter, vit_engine.py:50;
+ * ViTMergeAdapter, qwen3_5_vision_model.py:408); kind 1: tanh approximation (Qwen3_5VisionFFN, qwen3_5_vision_model.py:122). */
+int mi355_gelu_fwd(int64_t n, const void* x, void* y, int kind, void* stream);
+int mi355_gelu_bwd(int64_t n, const void* x, const void* dy, void* dx, int kind, void* stream);
 
 /* Flash-style attention, token-major operands, never materialising SxS (replaces qwen3_attention.py:121-146,
  * vit_attention.py:74-86).  q [B*S, Hq*D] ld=ldq, k/v [B*S, Hkv*D] ld=ldk/ldv, o [B*S, Hq*D] ld=ldo, bf16;
@@ -132,16 +134,30 @@ int mi355_copy2d(int64_t rows, int64_t width_bytes, const void* src, int64_t src
  * [B*gh*gw, C*P*P] with K ordered (c,i,j); patches row-major over (ph,pw). */
 int mi355_patchify(int B, int C, int H, int W, int P, const float* img, void* rows, int out_dtype, void* stream);
 
-/* ViT LayerNorm with eps added to sigma (vit_transformer_block.py:12-31): x fp32 [rows,width];
- * y bf16 or fp32; saves mean/rsig fp32 [rows] if non-NULL. */
+/* 3-D patch gather for Conv3d(k = s = (TP,P,P)) (qwen3_5_vision_model.py:79-107): img fp32 (B,C,T,H,W) -> rows
+ * [B*(T/TP)*gh*gw, C*TP*P*P], tokens ordered (t',ph,pw), K ordered (c,dt,i,j); bit-exact index map. */
+int mi355_patchify3d(int B, int C, int T, int H, int W, int P, int TP, const float* img, void* rows, int out_dtype, void* stream);
+/* ViTMergeAdapter m x m spatial merge (qwen3_5_vision_model.py:421-424), a bit-exact row permutation:
+ * merged[(f,bh,bw)][(i,j,:)] = x[(f, bh*m+i, bw*m+j)][:]; inverse != 0 applies the inverse map (backward). */
+int mi355_merge_patches(int64_t frames, int gh, int gw, int m, int64_t row_bytes, const void* src, void* dst, int inverse, void* stream);
+/* masked_scatter of vision rows into the embedded token sequence, row-major fill (qwen3_5_vlm_model.py:206-211).
+ * forward  (backward=0): out_a[t] = mask[t] ? b[slot[t]] : a[t]            (a = token embeddings, b = vision rows)
+ * backward (backward=1): out_a[t] = mask[t] ? 0 : a[t];  out_b[slot[t]] = a[t] where mask[t]   (a = grad of the fused rows)
+ * slot[t] = number of set mask entries before t (int32, computed by the caller). */
+int mi355_scatter_rows(int64_t tokens, int64_t row_bytes, const uint8_t* mask, const int32_t* slot, const void* a, const void* b,
+                       void* out_a, void* out_b, int backward, void* stream);
+
+/* LayerNorm on fp32 rows.  mode 0: the reference's ViT/GPT LayerNorm, eps ADDED TO sigma (vit_transformer_block.py:12-31);
+ * mode 1: nn.LayerNorm, eps inside the square root (Qwen3.5 vision blocks, qwen3_5_vision_model.py:213-214,406).
+ * y bf16 or fp32; saves mean / 1/(sigma-term) fp32 [rows] if non-NULL. */
 int mi355_layernorm_fwd(int64_t rows, int width, const float* x, const float* scale, const float* shift, void* y,
-                        int y_dtype, float* mean, float* rsig, float eps, void* stream);
+                        int y_dtype, float* mean, float* rsig, float eps, int mode, void* stream);
 
 /* backward of the same LayerNorm: dy bf16 or fp32; dx fp32 (+ dres, the residual-stream gradient); per-block partials
  * [parts][2*width] = (dscale | dshift), summed by mi355_reduce_rows_f32. */
 int mi355_layernorm_bwd(int64_t rows, int width, const float* x, const float* scale, const float* mean, const float* rsig,
                         const void* dy, int dy_dtype, const float* dres, float* dx, float* dparam_partial, int parts,
-                        float eps, void* stream);
+                        float eps, int mode, void* stream);
 
 /* dtype conversion / elementwise helpers */
 int mi355_cast(int64_t n, const void* src, int src_dtype, void* dst, int dst_dtype, void* stream);

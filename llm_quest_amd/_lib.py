@@ -40,16 +40,19 @@ SIGNATURES = {
     "mi355_embedding_bwd": [_L, _I, _L, _P, _P, _L, _P, _P],
     "mi355_copy2d": [_L, _L, _P, _L, _P, _L, _P],
     "mi355_patchify": [_I, _I, _I, _I, _I, _P, _P, _I, _P],
-    "mi355_layernorm_fwd": [_L, _I, _P, _P, _P, _P, _I, _P, _P, _F, _P],
-    "mi355_layernorm_bwd": [_L, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _F, _P],
+    "mi355_layernorm_fwd": [_L, _I, _P, _P, _P, _P, _I, _P, _P, _F, _I, _P],
+    "mi355_layernorm_bwd": [_L, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _F, _I, _P],
     "mi355_cast": [_L, _P, _I, _P, _I, _P],
     "mi355_vit_embed_assemble": [_I, _I, _I, _P, _P, _P, _P, _P],
     "mi355_sumsq": [_L, _P, _I, _P, _P],
     "mi355_clip_scale": [_L, _P, _I, _P, _F, _P],
     "mi355_add_f32_to_bf16": [_L, _P, _P, _P, _P],
     "mi355_scale_bf16": [_L, _P, _P, _P, _P],
-    "mi355_gelu_fwd": [_L, _P, _P, _P],
-    "mi355_gelu_bwd": [_L, _P, _P, _P, _P],
+    "mi355_gelu_fwd": [_L, _P, _P, _I, _P],
+    "mi355_gelu_bwd": [_L, _P, _P, _P, _I, _P],
+    "mi355_patchify3d": [_I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
+    "mi355_merge_patches": [_L, _I, _I, _I, _L, _P, _P, _I, _P],
+    "mi355_scatter_rows": [_L, _L, _P, _P, _P, _P, _P, _P, _I, _P],
 }
 
 _lib = None

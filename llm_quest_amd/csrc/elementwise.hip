@@ -79,16 +79,35 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(int64_t tokens, int F, 
 
 // ------------------------------------------------------------------------------------------------ GELU (erf)
 // nn.GELU() on a bf16 tensor (ViTAdapter, vit_engine.py:50): a = bf16(gelu(x));  backward dx = da * gelu'(x)
+// KIND 0: exact erf GELU (nn.GELU());  KIND 1: tanh approximation (nn.GELU(approximate="tanh"), qwen3_5_vision_model.py:122)
+template <int KIND>
+__device__ __forceinline__ float gelu_val(float x) {
+    if (KIND == 0) return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(u));
+}
+template <int KIND>
+__device__ __forceinline__ float gelu_grad(float x) {
+    if (KIND == 0) {
+        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+        return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+    }
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    const float th = tanhf(u);
+    return 0.5f * (1.0f + th) + 0.5f * x * (1.0f - th * th) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
+}
+template <int KIND>
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(int64_t n, const bf16_t* __restrict__ x, bf16_t* __restrict__ y) {
     const int64_t nv = n >> 3;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
         float v[8];
         unpack8(*reinterpret_cast<const u32x4*>(x + i * 8), v);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] * 0.5f * (1.0f + erff(v[e] * 0.70710678118654752440f));
+        for (int e = 0; e < 8; ++e) v[e] = gelu_val<KIND>(v[e]);
         *reinterpret_cast<u32x4*>(y + i * 8) = pack8(v);
     }
 }
+template <int KIND>
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(int64_t n, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx) {
     const int64_t nv = n >> 3;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
@@ -96,12 +115,75 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(int64_t n, const bf16_t* 
         unpack8(*reinterpret_cast<const u32x4*>(x + i * 8), v);
         unpack8(*reinterpret_cast<const u32x4*>(dy + i * 8), g);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float cdf = 0.5f * (1.0f + erff(v[e] * 0.70710678118654752440f));
-            const float pdf = 0.3989422804014327f * __expf(-0.5f * v[e] * v[e]);
-            g[e] *= cdf + v[e] * pdf;
-        }
+        for (int e = 0; e < 8; ++e) g[e] *= gelu_grad<KIND>(v[e]);
         *reinterpret_cast<u32x4*>(dx + i * 8) = pack8(g);
+    }
+}
+
+// 3-D patch gather for Conv3d(k = s = (TP, P, P)) (qwen3_5_vision_model.py:79-107): tokens ordered (t', ph, pw), K ordered (c, dt, i, j)
+template <int OUT_DT>
+__global__ __launch_bounds__(256) void patchify3d_kernel(int B, int C, int T, int H, int W, int P, int TP, const float* __restrict__ img, void* __restrict__ rows) {
+    const int gh = H / P, gw = W / P, gt = T / TP, K = C * TP * P * P, pv = P >> 2;
+    const int64_t total = (int64_t)B * C * T * H * gw * pv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t r = i;  // (b, c, t, y, pw, jv): consecutive threads read consecutive image addresses
+        const int jv = (int)(r % pv); r /= pv;
+        const int pw = (int)(r % gw); r /= gw;
+        const int y = (int)(r % H); r /= H;
+        const int t = (int)(r % T); r /= T;
+        const int c = (int)(r % C); r /= C;
+        const int b = (int)r;
+        const int ph = y / P, ii = y - ph * P, tq = t / TP, dt = t - tq * TP;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(img + ((((int64_t)b * C + c) * T + t) * H + y) * W + pw * P + jv * 4);
+        const int64_t orow = (((int64_t)b * gt + tq) * gh + ph) * gw + pw;
+        const int k = ((c * TP + dt) * P + ii) * P + jv * 4;
+        if constexpr (OUT_DT == MI355_DT_BF16) {
+            u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(rows) + orow * K + k) = pk;
+        } else {
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(rows) + orow * K + k) = v;
+        }
+    }
+}
+
+// ViTMergeAdapter permute (qwen3_5_vision_model.py:421-424): merged[(b,t,bh,bw)][(i,j,:)] <-> x[(b,t,bh*m+i,bw*m+j)][:]
+// 16-byte chunks; inverse = the same map with src/dst swapped (backward).
+__global__ __launch_bounds__(256) void merge_patches_kernel(int64_t frames, int gh, int gw, int m, int row_bytes, const char* __restrict__ src,
+                                                            char* __restrict__ dst, int inverse) {
+    const int cv = row_bytes >> 4;
+    const int64_t total = frames * gh * gw * cv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % cv);
+        int64_t r = i / cv;  // index of the un-merged patch row (frame, y, x)
+        const int x = (int)(r % gw); const int y = (int)((r / gw) % gh); const int64_t f = r / ((int64_t)gh * gw);
+        const int bh = y / m, ii = y - bh * m, bw = x / m, jj = x - bw * m;
+        const int64_t mrow = (f * (gh / m) + bh) * (gw / m) + bw;          // merged token
+        const int64_t moff = (mrow * m * m + ii * m + jj) * (int64_t)row_bytes + c * 16;  // inside it: (i, j, :)
+        const int64_t xoff = r * (int64_t)row_bytes + c * 16;
+        if (inverse) *reinterpret_cast<u32x4*>(dst + xoff) = *reinterpret_cast<const u32x4*>(src + moff);
+        else *reinterpret_cast<u32x4*>(dst + moff) = *reinterpret_cast<const u32x4*>(src + xoff);
+    }
+}
+
+// masked_scatter of vision rows into the embedded sequence (qwen3_5_vlm_model.py:209-211), row-major fill order:
+//   forward : out[t] = mask[t] ? vis[slot[t]] : emb[t]
+//   backward: d_emb[t] = mask[t] ? 0 : g[t];   d_vis[slot[t]] = g[t] where mask[t]
+__global__ __launch_bounds__(256) void scatter_rows_kernel(int64_t tokens, int row_bytes, const uint8_t* __restrict__ mask, const int32_t* __restrict__ slot,
+                                                           const char* __restrict__ a, const char* __restrict__ b, char* __restrict__ out_a, char* __restrict__ out_b, int backward) {
+    const int cv = row_bytes >> 4;
+    const int64_t total = tokens * cv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t t = i / cv;
+        const int64_t c = (i - t * cv) * 16;
+        const bool mk = mask[t] != 0;
+        if (!backward) {  // a = emb, b = vis, out_a = fused
+            const char* src = mk ? b + (int64_t)slot[t] * row_bytes : a + t * row_bytes;
+            *reinterpret_cast<u32x4*>(out_a + t * row_bytes + c) = *reinterpret_cast<const u32x4*>(src + c);
+        } else {          // a = grad of fused, out_a = d_emb, out_b = d_vis
+            const u32x4 g = *reinterpret_cast<const u32x4*>(a + t * row_bytes + c);
+            *reinterpret_cast<u32x4*>(out_a + t * row_bytes + c) = mk ? (u32x4){0, 0, 0, 0} : g;
+            if (mk) *reinterpret_cast<u32x4*>(out_b + (int64_t)slot[t] * row_bytes + c) = g;
+        }
     }
 }
 
@@ -365,16 +447,49 @@ extern "C" int mi355_swiglu_bwd(int64_t tokens, int F, const void* gu, const voi
     return 0;
 }
 
-extern "C" int mi355_gelu_fwd(int64_t n, const void* x, void* y, void* stream) {
-    MI355_REQUIRE(n > 0 && (n & 7) == 0 && x && y, "mi355_gelu_fwd: n must be a positive multiple of 8");
-    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid_for(n >> 3, 256)), dim3(256), 0, STREAM, n, (const bf16_t*)x, (bf16_t*)y);
+extern "C" int mi355_gelu_fwd(int64_t n, const void* x, void* y, int kind, void* stream) {
+    MI355_REQUIRE(n > 0 && (n & 7) == 0 && x && y && (kind == 0 || kind == 1), "mi355_gelu_fwd: n must be a positive multiple of 8, kind 0 (erf) or 1 (tanh)");
+    if (kind == 0) hipLaunchKernelGGL(gelu_fwd_kernel<0>, dim3(grid_for(n >> 3, 256)), dim3(256), 0, STREAM, n, (const bf16_t*)x, (bf16_t*)y);
+    else hipLaunchKernelGGL(gelu_fwd_kernel<1>, dim3(grid_for(n >> 3, 256)), dim3(256), 0, STREAM, n, (const bf16_t*)x, (bf16_t*)y);
     MI355_LAUNCH_CHECK("mi355_gelu_fwd");
     return 0;
 }
-extern "C" int mi355_gelu_bwd(int64_t n, const void* x, const void* dy, void* dx, void* stream) {
-    MI355_REQUIRE(n > 0 && (n & 7) == 0 && x && dy && dx, "mi355_gelu_bwd: n must be a positive multiple of 8");
-    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n >> 3, 256)), dim3(256), 0, STREAM, n, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx);
+extern "C" int mi355_gelu_bwd(int64_t n, const void* x, const void* dy, void* dx, int kind, void* stream) {
+    MI355_REQUIRE(n > 0 && (n & 7) == 0 && x && dy && dx && (kind == 0 || kind == 1), "mi355_gelu_bwd: n must be a positive multiple of 8, kind 0 or 1");
+    if (kind == 0) hipLaunchKernelGGL(gelu_bwd_kernel<0>, dim3(grid_for(n >> 3, 256)), dim3(256), 0, STREAM, n, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx);
+    else hipLaunchKernelGGL(gelu_bwd_kernel<1>, dim3(grid_for(n >> 3, 256)), dim3(256), 0, STREAM, n, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx);
     MI355_LAUNCH_CHECK("mi355_gelu_bwd");
+    return 0;
+}
+
+extern "C" int mi355_patchify3d(int B, int C, int T, int H, int W, int P, int TP, const float* img, void* rows, int out_dtype, void* stream) {
+    MI355_REQUIRE(B > 0 && C > 0 && T > 0 && P > 0 && TP > 0 && (P & 3) == 0 && H % P == 0 && W % P == 0 && T % TP == 0 && img && rows,
+                  "mi355_patchify3d: patch size must be a multiple of 4 and divide H, W; TP must divide T");
+    MI355_REQUIRE(((uintptr_t)img & 15) == 0, "mi355_patchify3d: image must be 16-byte aligned");
+    const int64_t work = (int64_t)B * C * T * H * (W / 4);
+    if (out_dtype == MI355_DT_BF16)
+        hipLaunchKernelGGL(patchify3d_kernel<MI355_DT_BF16>, dim3(grid_for(work, 256)), dim3(256), 0, STREAM, B, C, T, H, W, P, TP, img, rows);
+    else
+        hipLaunchKernelGGL(patchify3d_kernel<MI355_DT_F32>, dim3(grid_for(work, 256)), dim3(256), 0, STREAM, B, C, T, H, W, P, TP, img, rows);
+    MI355_LAUNCH_CHECK("mi355_patchify3d");
+    return 0;
+}
+
+extern "C" int mi355_merge_patches(int64_t frames, int gh, int gw, int m, int64_t row_bytes, const void* src, void* dst, int inverse, void* stream) {
+    MI355_REQUIRE(frames > 0 && gh > 0 && gw > 0 && m > 0 && gh % m == 0 && gw % m == 0 && row_bytes > 0 && (row_bytes & 15) == 0 && src && dst,
+                  "mi355_merge_patches: merge size must divide the patch grid; rows must be multiples of 16 bytes");
+    hipLaunchKernelGGL(merge_patches_kernel, dim3(grid_for(frames * gh * gw * (row_bytes >> 4), 256)), dim3(256), 0, STREAM, frames, gh, gw, m, (int)row_bytes, (const char*)src, (char*)dst, inverse);
+    MI355_LAUNCH_CHECK("mi355_merge_patches");
+    return 0;
+}
+
+extern "C" int mi355_scatter_rows(int64_t tokens, int64_t row_bytes, const uint8_t* mask, const int32_t* slot, const void* a, const void* b,
+                                  void* out_a, void* out_b, int backward, void* stream) {
+    MI355_REQUIRE(tokens > 0 && row_bytes > 0 && (row_bytes & 15) == 0 && mask && slot && a && out_a, "mi355_scatter_rows: bad arguments (rows must be multiples of 16 bytes)");
+    MI355_REQUIRE(backward ? out_b != nullptr : b != nullptr, "mi355_scatter_rows: missing vision-row buffer");
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid_for(tokens * (row_bytes >> 4), 256)), dim3(256), 0, STREAM, tokens, (int)row_bytes, mask, slot,
+                       (const char*)a, (const char*)b, (char*)out_a, (char*)out_b, backward);
+    MI355_LAUNCH_CHECK("mi355_scatter_rows");
     return 0;
 }
 

@@ -254,16 +254,20 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(int64_t tokens, in
         const int hh = valid ? h : 0;
         const bf16_t* src = qkv + t * ld + (int64_t)hh * D;
         const bf16_t* wgt = hh < Hq ? qw : kw;
-        float x1[4], x2[4], w1[4], w2[4];
+        const bool norm = qw != nullptr;  // qw == kw == NULL: RoPE only (Qwen3.5 vision attention, qwen3_5_vision_model.py:176-177)
+        float x1[4], x2[4], w1[4] = {1.f, 1.f, 1.f, 1.f}, w2[4] = {1.f, 1.f, 1.f, 1.f};
         unpack4(*reinterpret_cast<const u32x2*>(src + i), x1);
         unpack4(*reinterpret_cast<const u32x2*>(src + G::HALF + i), x2);
-        unpack4(*reinterpret_cast<const u32x2*>(wgt + i), w1);
-        unpack4(*reinterpret_cast<const u32x2*>(wgt + G::HALF + i), w2);
-        float ss = 0.f;
+        float r = 1.0f;
+        if (norm) {
+            unpack4(*reinterpret_cast<const u32x2*>(wgt + i), w1);
+            unpack4(*reinterpret_cast<const u32x2*>(wgt + G::HALF + i), w2);
+            float ss = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ss += x1[e] * x1[e] + x2[e] * x2[e];
-        ss = head_sum<G::LPH>(ss);
-        const float r = rsqrtf(ss / (float)D + eps);
+            for (int e = 0; e < 4; ++e) ss += x1[e] * x1[e] + x2[e] * x2[e];
+            ss = head_sum<G::LPH>(ss);
+            r = rsqrtf(ss / (float)D + eps);
+        }
         const int64_t p = pos[t];
         const f32x4 c1 = *reinterpret_cast<const f32x4*>(cosT + p * D + i), s1 = *reinterpret_cast<const f32x4*>(sinT + p * D + i);
         const f32x4 c2 = *reinterpret_cast<const f32x4*>(cosT + p * D + G::HALF + i), s2 = *reinterpret_cast<const f32x4*>(sinT + p * D + G::HALF + i);
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(int64_t tokens, in
             bf16_t* dst = h < Hq ? qo + t * (int64_t)Hq * D + (int64_t)h * D : ko + t * (int64_t)Hkv * D + (int64_t)(h - Hq) * D;
             *reinterpret_cast<u32x2*>(dst + i) = pack4(y1);
             *reinterpret_cast<u32x2*>(dst + G::HALF + i) = pack4(y2);
-            if (i == 0) rstd[t * H + h] = r;
+            if (i == 0 && rstd) rstd[t * H + h] = r;
         }
     }
 }
@@ -308,17 +312,20 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(int64_t tokens, in
         const bool valid = h < H;
         const int hh = valid ? h : 0;
         const bool isq = hh < Hq;
+        const bool norm = qw != nullptr;
         const bf16_t* src = qkv + t * ld + (int64_t)hh * D;
         const bf16_t* wgt = isq ? qw : kw;
         const bf16_t* g = isq ? dq + t * (int64_t)Hq * D + (int64_t)hh * D : dk + t * (int64_t)Hkv * D + (int64_t)(hh - Hq) * D;
-        float x1[4], x2[4], w1[4], w2[4], g1[4], g2[4];
-        unpack4(*reinterpret_cast<const u32x2*>(src + i), x1);
-        unpack4(*reinterpret_cast<const u32x2*>(src + G::HALF + i), x2);
-        unpack4(*reinterpret_cast<const u32x2*>(wgt + i), w1);
-        unpack4(*reinterpret_cast<const u32x2*>(wgt + G::HALF + i), w2);
+        float x1[4] = {0, 0, 0, 0}, x2[4] = {0, 0, 0, 0}, w1[4] = {1.f, 1.f, 1.f, 1.f}, w2[4] = {1.f, 1.f, 1.f, 1.f}, g1[4], g2[4];
+        if (norm) {
+            unpack4(*reinterpret_cast<const u32x2*>(src + i), x1);
+            unpack4(*reinterpret_cast<const u32x2*>(src + G::HALF + i), x2);
+            unpack4(*reinterpret_cast<const u32x2*>(wgt + i), w1);
+            unpack4(*reinterpret_cast<const u32x2*>(wgt + G::HALF + i), w2);
+        }
         unpack4(*reinterpret_cast<const u32x2*>(g + i), g1);
         unpack4(*reinterpret_cast<const u32x2*>(g + G::HALF + i), g2);
-        const float r = rstd[t * H + hh];
+        const float r = norm ? rstd[t * H + hh] : 1.0f;
         const int64_t p = pos[t];
         const f32x4 c1 = *reinterpret_cast<const f32x4*>(cosT + p * D + i), s1 = *reinterpret_cast<const f32x4*>(sinT + p * D + i);
         const f32x4 c2 = *reinterpret_cast<const f32x4*>(cosT + p * D + G::HALF + i), s2 = *reinterpret_cast<const f32x4*>(sinT + p * D + G::HALF + i);
@@ -338,8 +345,8 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(int64_t tokens, in
             float d1[4], d2[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                d1[e] = r * (dn1[e] * w1[e] - xh1[e] * dot);
-                d2[e] = r * (dn2[e] * w2[e] - xh2[e] * dot);
+                d1[e] = norm ? r * (dn1[e] * w1[e] - xh1[e] * dot) : dn1[e];
+                d2[e] = norm ? r * (dn2[e] * w2[e] - xh2[e] * dot) : dn2[e];
                 if (isq) { dwq1[e] += dn1[e] * xh1[e]; dwq2[e] += dn2[e] * xh2[e]; } else { dwk1[e] += dn1[e] * xh1[e]; dwk2[e] += dn2[e] * xh2[e]; }
             }
             bf16_t* dst = dqkv + t * ld + (int64_t)h * D;
@@ -364,7 +371,7 @@ template <int OUT_DT>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int64_t rows, int width, const float* __restrict__ x,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             void* __restrict__ y, float* __restrict__ mean_out,
-                                                            float* __restrict__ rsig_out, float eps) {
+                                                            float* __restrict__ rsig_out, float eps, int mode) {
     const int lane = threadIdx.x & 63;
     const int nvec = width >> 2;
     const int64_t row0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -382,8 +389,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int64_t rows, int wi
 #pragma unroll
             for (int e = 0; e < 4; ++e) ss += (v[e] - mu) * (v[e] - mu);
         }
-        const float sd = sqrtf(wave_sum(ss) / (float)width);
-        const float inv = 1.0f / (sd + eps);
+        const float var = wave_sum(ss) / (float)width;
+        // mode 0: ViT/GPT LayerNorm of the reference, eps added to sigma; mode 1: nn.LayerNorm, eps inside the square root
+        const float inv = mode == 0 ? 1.0f / (sqrtf(var) + eps) : rsqrtf(var + eps);
         if (lane == 0) {
             if (mean_out) mean_out[row] = mu;
             if (rsig_out) rsig_out[row] = inv;
@@ -413,7 +421,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int wi
                                                             const float* __restrict__ scale, const float* __restrict__ mean,
                                                             const float* __restrict__ rsig, const void* __restrict__ dy,
                                                             const float* __restrict__ dres, float* __restrict__ dx,
-                                                            float* __restrict__ dparam_partial, float eps) {
+                                                            float* __restrict__ dparam_partial, float eps, int mode) {
     extern __shared__ __attribute__((aligned(16))) float dp_lds[];  // [2*width]
     const int lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < 2 * width; i += 256) dp_lds[i] = 0.f;
@@ -436,7 +444,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int wi
         }
         s1 = wave_sum(s1) / (float)width;
         s2 = wave_sum(s2) / (float)width;
-        const float s_over_sigma = (1.0f / rs) / (1.0f / rs - eps);
+        const float s_over_sigma = mode == 0 ? (1.0f / rs) / (1.0f / rs - eps) : 1.0f;
         for (int c = lane; c < width; c += 64) {
             const float n = (x[row * width + c] - mu) * rs;
             const float dn = load_dy(row, c) * scale[c];
@@ -499,7 +507,8 @@ extern "C" int mi355_qknorm_rope_fwd(int64_t tokens, int Hq, int Hkv, int D, con
                                      const float* cos, const float* sin, const int32_t* pos, void* q_out, void* k_out,
                                      float* rstd, float eps, void* stream) {
     MI355_REQUIRE(D == 128 || D == 64, "mi355_qknorm_rope_fwd: head_dim must be 64 or 128 (got %d)", D);
-    MI355_REQUIRE(tokens > 0 && Hq > 0 && Hkv > 0 && qkv && qw && kw && cos && sin && pos && q_out && k_out && rstd, "mi355_qknorm_rope_fwd: bad arguments");
+    MI355_REQUIRE(tokens > 0 && Hq > 0 && Hkv > 0 && qkv && cos && sin && pos && q_out && k_out, "mi355_qknorm_rope_fwd: bad arguments");
+    MI355_REQUIRE((qw == nullptr) == (kw == nullptr) && (qw == nullptr || rstd != nullptr), "mi355_qknorm_rope_fwd: pass both norm weights (and rstd) or neither (RoPE only)");
     const int hpw = D == 128 ? 4 : 8;
     const int grid = row_grid(tokens * ((Hq + Hkv + hpw - 1) / hpw));
     hipStream_t s = (hipStream_t)stream;
@@ -515,7 +524,8 @@ extern "C" int mi355_qknorm_rope_bwd(int64_t tokens, int Hq, int Hkv, int D, con
                                      const float* cos, const float* sin, const int32_t* pos, const float* rstd,
                                      const void* dq, const void* dk, void* dqkv, float* dw_partial, int parts, void* stream) {
     MI355_REQUIRE(D == 128 || D == 64, "mi355_qknorm_rope_bwd: head_dim must be 64 or 128 (got %d)", D);
-    MI355_REQUIRE(tokens > 0 && parts > 0 && qkv && qw && kw && cos && sin && pos && rstd && dq && dk && dqkv && dw_partial, "mi355_qknorm_rope_bwd: bad arguments");
+    MI355_REQUIRE(tokens > 0 && parts > 0 && qkv && cos && sin && pos && dq && dk && dqkv && dw_partial, "mi355_qknorm_rope_bwd: bad arguments");
+    MI355_REQUIRE((qw == nullptr) == (kw == nullptr) && (qw == nullptr || rstd != nullptr), "mi355_qknorm_rope_bwd: pass both norm weights (and rstd) or neither (RoPE only)");
     hipStream_t s = (hipStream_t)stream;
     if (D == 128)
         hipLaunchKernelGGL(qknorm_rope_bwd_kernel<128>, dim3(parts), dim3(256), 0, s, tokens, Hq, Hkv, (const bf16_t*)qkv, (const bf16_t*)qw, (const bf16_t*)kw, cos, sin, pos, rstd, (const bf16_t*)dq, (const bf16_t*)dk, (bf16_t*)dqkv, dw_partial);
@@ -526,29 +536,29 @@ extern "C" int mi355_qknorm_rope_bwd(int64_t tokens, int Hq, int Hkv, int D, con
 }
 
 extern "C" int mi355_layernorm_fwd(int64_t rows, int width, const float* x, const float* scale, const float* shift, void* y,
-                                   int y_dtype, float* mean, float* rsig, float eps, void* stream) {
+                                   int y_dtype, float* mean, float* rsig, float eps, int mode, void* stream) {
     MI355_REQUIRE(rows > 0 && width > 0 && (width & 3) == 0, "mi355_layernorm_fwd: width must be a multiple of 4 (got %d)", width);
     MI355_REQUIRE(x && scale && shift && y, "mi355_layernorm_fwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const int grid = row_grid(rows);
     if (y_dtype == MI355_DT_BF16)
-        hipLaunchKernelGGL(layernorm_fwd_kernel<MI355_DT_BF16>, dim3(grid), dim3(256), 0, s, rows, width, x, scale, shift, y, mean, rsig, eps);
+        hipLaunchKernelGGL(layernorm_fwd_kernel<MI355_DT_BF16>, dim3(grid), dim3(256), 0, s, rows, width, x, scale, shift, y, mean, rsig, eps, mode);
     else
-        hipLaunchKernelGGL(layernorm_fwd_kernel<MI355_DT_F32>, dim3(grid), dim3(256), 0, s, rows, width, x, scale, shift, y, mean, rsig, eps);
+        hipLaunchKernelGGL(layernorm_fwd_kernel<MI355_DT_F32>, dim3(grid), dim3(256), 0, s, rows, width, x, scale, shift, y, mean, rsig, eps, mode);
     MI355_LAUNCH_CHECK("mi355_layernorm_fwd");
     return 0;
 }
 
 extern "C" int mi355_layernorm_bwd(int64_t rows, int width, const float* x, const float* scale, const float* mean, const float* rsig,
                                    const void* dy, int dy_dtype, const float* dres, float* dx, float* dparam_partial, int parts,
-                                   float eps, void* stream) {
+                                   float eps, int mode, void* stream) {
     MI355_REQUIRE(rows > 0 && width > 0 && width <= 8192 && parts > 0, "mi355_layernorm_bwd: bad shape");
     MI355_REQUIRE(x && scale && mean && rsig && dy && dx && dparam_partial, "mi355_layernorm_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     if (dy_dtype == MI355_DT_BF16)
-        hipLaunchKernelGGL(layernorm_bwd_kernel<MI355_DT_BF16>, dim3(parts), dim3(256), 2 * width * sizeof(float), s, rows, width, x, scale, mean, rsig, dy, dres, dx, dparam_partial, eps);
+        hipLaunchKernelGGL(layernorm_bwd_kernel<MI355_DT_BF16>, dim3(parts), dim3(256), 2 * width * sizeof(float), s, rows, width, x, scale, mean, rsig, dy, dres, dx, dparam_partial, eps, mode);
     else
-        hipLaunchKernelGGL(layernorm_bwd_kernel<MI355_DT_F32>, dim3(parts), dim3(256), 2 * width * sizeof(float), s, rows, width, x, scale, mean, rsig, dy, dres, dx, dparam_partial, eps);
+        hipLaunchKernelGGL(layernorm_bwd_kernel<MI355_DT_F32>, dim3(parts), dim3(256), 2 * width * sizeof(float), s, rows, width, x, scale, mean, rsig, dy, dres, dx, dparam_partial, eps, mode);
     MI355_LAUNCH_CHECK("mi355_layernorm_bwd");
     return 0;
 }

@@ -112,6 +112,7 @@ def rmsnorm_bwd(x2d, w, rstd, dy, dres=None, dw_out=None, dw_accumulate=False):
 
 
 def qknorm_rope_fwd(qkv, qw, kw, cos, sin, pos, Hq, Hkv, D, eps=1e-6):
+    """qw = kw = None: RoPE only (no per-head normalisation); rstd is then None."""
     L.require_gpu(qkv, qw, kw, cos, sin, pos)
     tokens = qkv.shape[0]
     if not (qkv.is_contiguous() and qkv.dtype == BF16 and qkv.shape[1] == (Hq + 2 * Hkv) * D):
@@ -122,7 +123,7 @@ def qknorm_rope_fwd(qkv, qw, kw, cos, sin, pos, Hq, Hkv, D, eps=1e-6):
         raise ValueError("qknorm_rope_fwd: pos must be contiguous int32 [tokens]")
     q = torch.empty((tokens, Hq * D), dtype=BF16, device=qkv.device)
     k = torch.empty((tokens, Hkv * D), dtype=BF16, device=qkv.device)
-    rstd = torch.empty((tokens, Hq + Hkv), dtype=F32, device=qkv.device)
+    rstd = torch.empty((tokens, Hq + Hkv), dtype=F32, device=qkv.device) if qw is not None else None
     L.call("mi355_qknorm_rope_fwd", tokens, Hq, Hkv, D, L.ptr(qkv), L.ptr(qw), L.ptr(kw), L.ptr(cos), L.ptr(sin), L.ptr(pos), L.ptr(q), L.ptr(k), L.ptr(rstd), eps)
     return q, k, rstd
 
@@ -265,7 +266,7 @@ def patchify(img, patch, out_dtype=BF16):
     return rows
 
 
-def layernorm_fwd(x2d, scale, shift, out_dtype=BF16, eps=1e-5, want_stats=False):
+def layernorm_fwd(x2d, scale, shift, out_dtype=BF16, eps=1e-5, want_stats=False, mode=0):
     L.require_gpu(x2d, scale, shift)
     if x2d.dtype != F32 or not x2d.is_contiguous() or scale.dtype != F32 or shift.dtype != F32:
         raise ValueError("layernorm_fwd: x/scale/shift must be fp32, x contiguous")
@@ -274,7 +275,7 @@ def layernorm_fwd(x2d, scale, shift, out_dtype=BF16, eps=1e-5, want_stats=False)
     if want_stats:
         mean = torch.empty(x2d.shape[0], dtype=F32, device=x2d.device)
         rsig = torch.empty_like(mean)
-    L.call("mi355_layernorm_fwd", x2d.shape[0], x2d.shape[1], L.ptr(x2d), L.ptr(scale), L.ptr(shift), L.ptr(y), L.dt_code(out_dtype), L.ptr(mean), L.ptr(rsig), eps)
+    L.call("mi355_layernorm_fwd", x2d.shape[0], x2d.shape[1], L.ptr(x2d), L.ptr(scale), L.ptr(shift), L.ptr(y), L.dt_code(out_dtype), L.ptr(mean), L.ptr(rsig), eps, mode)
     return (y, mean, rsig) if want_stats else y
 
 
@@ -323,25 +324,25 @@ def scale_bf16(x, scale_f32, out=None):
     return out
 
 
-def gelu_fwd(x):
+def gelu_fwd(x, tanh=False):
     L.require_gpu(x)
     if x.dtype != BF16 or not x.is_contiguous() or x.numel() % 8:
         raise ValueError("gelu_fwd: contiguous bf16 with numel % 8 == 0")
     y = torch.empty_like(x)
-    L.call("mi355_gelu_fwd", x.numel(), L.ptr(x), L.ptr(y))
+    L.call("mi355_gelu_fwd", x.numel(), L.ptr(x), L.ptr(y), 1 if tanh else 0)
     return y
 
 
-def gelu_bwd(x, dy):
+def gelu_bwd(x, dy, tanh=False):
     L.require_gpu(x, dy)
     if dy.dtype != BF16 or not dy.is_contiguous() or dy.shape != x.shape:
         raise ValueError("gelu_bwd: dy must be contiguous bf16 like x")
     dx = torch.empty_like(x)
-    L.call("mi355_gelu_bwd", x.numel(), L.ptr(x), L.ptr(dy), L.ptr(dx))
+    L.call("mi355_gelu_bwd", x.numel(), L.ptr(x), L.ptr(dy), L.ptr(dx), 1 if tanh else 0)
     return dx
 
 
-def layernorm_bwd(x2d, scale, mean, rsig, dy, dres=None, eps=1e-5, dscale_out=None, dshift_out=None, accumulate=False):
+def layernorm_bwd(x2d, scale, mean, rsig, dy, dres=None, eps=1e-5, dscale_out=None, dshift_out=None, accumulate=False, mode=0):
     """Returns dx fp32 (+ dres).  dscale/dshift go to the given fp32 destinations (optionally accumulated) or new tensors."""
     L.require_gpu(x2d, dy, dres)
     rows, width = x2d.shape
@@ -352,7 +353,7 @@ def layernorm_bwd(x2d, scale, mean, rsig, dy, dres=None, eps=1e-5, dscale_out=No
     dx = torch.empty_like(x2d)
     parts = min(256, (rows + 3) // 4)
     part = torch.empty((parts, 2 * width), dtype=F32, device=x2d.device)
-    L.call("mi355_layernorm_bwd", rows, width, L.ptr(x2d), L.ptr(scale), L.ptr(mean), L.ptr(rsig), L.ptr(dy), L.dt_code(dy.dtype), L.ptr(dres), L.ptr(dx), L.ptr(part), parts, eps)
+    L.call("mi355_layernorm_bwd", rows, width, L.ptr(x2d), L.ptr(scale), L.ptr(mean), L.ptr(rsig), L.ptr(dy), L.dt_code(dy.dtype), L.ptr(dres), L.ptr(dx), L.ptr(part), parts, eps, mode)
     both = torch.empty(2 * width, dtype=F32, device=x2d.device)
     L.call("mi355_reduce_rows_f32", parts, 2 * width, L.ptr(part), L.ptr(both), L.DT_F32, 0)
     outs = []
@@ -366,3 +367,54 @@ def layernorm_bwd(x2d, scale, mean, rsig, dy, dres=None, eps=1e-5, dscale_out=No
                 L.call("mi355_reduce_rows_f32", 1, width, L.ptr(src.contiguous()), L.ptr(dst), L.DT_F32, 0)
             outs.append(dst)
     return dx, outs[0], outs[1]
+
+
+def patchify3d(video, patch, tpatch, out_dtype=BF16):
+    """video fp32 (B,C,T,H,W) -> rows [B*(T/tpatch)*gh*gw, C*tpatch*patch*patch] (Conv3d patch order)."""
+    L.require_gpu(video)
+    if video.dtype != F32 or video.dim() != 5 or not video.is_contiguous():
+        raise ValueError("patchify3d: video must be contiguous fp32 (B,C,T,H,W)")
+    B, C, T, H, W = video.shape
+    rows = torch.empty((B * (T // tpatch) * (H // patch) * (W // patch), C * tpatch * patch * patch), dtype=out_dtype, device=video.device)
+    L.call("mi355_patchify3d", B, C, T, H, W, patch, tpatch, L.ptr(video), L.ptr(rows), L.dt_code(out_dtype))
+    return rows
+
+
+def merge_patches(x2d, frames, gh, gw, m, inverse=False):
+    """m x m spatial merge of patch rows [frames*gh*gw, d] -> [frames*(gh/m)*(gw/m), m*m*d] (or its inverse)."""
+    L.require_gpu(x2d)
+    if not x2d.is_contiguous():
+        raise ValueError("merge_patches: contiguous rows required")
+    es = x2d.element_size()
+    if not inverse:
+        if x2d.shape[0] != frames * gh * gw:
+            raise ValueError("merge_patches: row count != frames*gh*gw")
+        d = x2d.shape[1]
+        out = torch.empty((frames * (gh // m) * (gw // m), m * m * d), dtype=x2d.dtype, device=x2d.device)
+    else:
+        d = x2d.shape[1] // (m * m)
+        if x2d.shape[0] != frames * (gh // m) * (gw // m):
+            raise ValueError("merge_patches(inverse): row count != frames*(gh/m)*(gw/m)")
+        out = torch.empty((frames * gh * gw, d), dtype=x2d.dtype, device=x2d.device)
+    L.call("mi355_merge_patches", frames, gh, gw, m, d * es, L.ptr(x2d), L.ptr(out), int(inverse))
+    return out
+
+
+def scatter_rows_fwd(emb2d, vis2d, mask_u8, slot_i32):
+    L.require_gpu(emb2d, vis2d, mask_u8, slot_i32)
+    if not (emb2d.is_contiguous() and vis2d.is_contiguous() and emb2d.dtype == vis2d.dtype and emb2d.shape[1] == vis2d.shape[1]):
+        raise ValueError("scatter_rows_fwd: contiguous rows of equal width and dtype required")
+    if not (mask_u8.dtype == torch.uint8 and slot_i32.dtype == torch.int32 and mask_u8.numel() == emb2d.shape[0] == slot_i32.numel()):
+        raise ValueError("scatter_rows_fwd: mask uint8 [tokens], slot int32 [tokens]")
+    out = torch.empty_like(emb2d)
+    L.call("mi355_scatter_rows", emb2d.shape[0], emb2d.shape[1] * emb2d.element_size(), L.ptr(mask_u8), L.ptr(slot_i32), L.ptr(emb2d), L.ptr(vis2d), L.ptr(out), None, 0)
+    return out
+
+
+def scatter_rows_bwd(g2d, n_vis_rows, mask_u8, slot_i32):
+    L.require_gpu(g2d, mask_u8, slot_i32)
+    g2d = g2d if g2d.is_contiguous() else g2d.contiguous()
+    d_emb = torch.empty_like(g2d)
+    d_vis = torch.zeros((n_vis_rows, g2d.shape[1]), dtype=g2d.dtype, device=g2d.device)
+    L.call("mi355_scatter_rows", g2d.shape[0], g2d.shape[1] * g2d.element_size(), L.ptr(mask_u8), L.ptr(slot_i32), L.ptr(g2d), None, L.ptr(d_emb), L.ptr(d_vis), 1)
+    return d_emb, d_vis

@@ -43,6 +43,10 @@ TINY_VIT = dict(
     img_width=32, img_height=32, patch_size=8, num_channels=3, emb_dim=64, n_layers=2, n_heads=1,
     drop_rate=0.0, qkv_bias=True, num_classes=10,
 )
+TINY_Q35_VISION = dict(
+    vision_n_layers=2, vision_emb_dim=128, vision_hidden_dim=256, vision_num_heads=2, llm_d_in=128, in_channels=3, patch_size=8,
+    spatial_merge_size=2, temporal_patch_size=2, num_position_embeddings=64, img_width=32, img_height=32, vision_rope_base=10_000,
+)
 TINY_GPT = dict(vocab_size=256, context_length=32, emb_dim=64, n_heads=2, n_layers=2, drop_rate=0.0, qkv_bias=True)
 
 
@@ -290,6 +294,63 @@ def gen_gpt(out):
     _save(os.path.join(out, "gpt2_tiny.safetensors"), t, "tiny GPT-2 forward (config-1 plumbing)")
 
 
+def gen_qwen35(out):
+    import types
+
+    from llm_quest.common.rope import VisionRoPE
+    from llm_quest.qwen.qwen3_5.qwen3_5_vision_model import PatchEmbedding3D, Qwen3_5VisionModel, ViTMergeAdapter
+    from llm_quest.qwen.qwen3_5.qwen3_5_vlm_model import Qwen3_5VLM
+
+    t = {}
+    torch.manual_seed(SEED)
+    # --- index fixtures: Conv3d patch order via an identity projection on an arange clip
+    c, frames, hw, p, tp = 3, 4, 16, 4, 2
+    k = c * tp * p * p
+    pe = PatchEmbedding3D(hw, hw, c, k, p, tp)
+    with torch.no_grad():
+        pe.conv_proj.weight.copy_(torch.eye(k).view(k, c, tp, p, p))
+        pe.conv_proj.bias.zero_()
+        clip = torch.arange(c * frames * hw * hw, dtype=torch.float32).view(1, c, frames, hw, hw)
+        t["patch3d.gather"] = pe(clip)[0].to(torch.int32)
+    # --- merge permutation on an arange grid (LayerNorm made an identity)
+    ma = ViTMergeAdapter(8, 8, n_height_patches=4, n_width_patches=6, spatial_merge_size=2)
+    x = torch.arange(2 * 24, dtype=torch.float32).view(1, 48, 1).expand(1, 48, 8).contiguous()
+    xv = x.view(1, 2, 2, 2, 3, 2, 8).permute(0, 1, 2, 4, 3, 5, 6).contiguous().view(1, -1, 32)
+    t["merge.rows"] = xv[0, :, ::8].to(torch.int32)  # source patch row of each of the 4 merged slots
+    # --- 2-D RoPE tables
+    cos, sin = VisionRoPE.compute_angles_2d(base=10_000, head_dim=64, height_patches=4, width_patches=4)
+    t["vrope.cos"], t["vrope.sin"] = cos, sin
+    # --- 3-D position ids: 5 text + 8 image (2 frames x 2x2 merged) + 4 text, and a text-only row
+    stub = types.SimpleNamespace(image_token_id=999, merge_size=2)
+    ids = torch.tensor([[1, 2, 3, 4, 5] + [999] * 8 + [6, 7, 8, 9], [1] * 17])
+    feeds = torch.tensor([[2, 4, 4]])
+    t["pos3d.ids"] = ids
+    t["pos3d.out"] = Qwen3_5VLM.compute_3d_position_ids(stub, ids, feeds)
+    t["pos3d.text_only"] = Qwen3_5VLM.compute_3d_position_ids(stub, ids, None).contiguous()
+    # --- masked_scatter fusion
+    emb = torch.randn(2, 17, 16).to(torch.bfloat16)
+    vis = torch.randn(1, 8, 16)
+    mask = ids == 999
+    t["scatter.emb"], t["scatter.vis"] = emb, vis
+    t["scatter.out"] = emb.masked_scatter(mask.unsqueeze(-1).expand_as(emb), vis.to(emb.dtype))
+    # --- tiny vision tower: forward + all gradients (fp32, as the reference constructs it)
+    vm = Qwen3_5VisionModel(dict(TINY_Q35_VISION)).train()
+    with torch.no_grad():  # nn.LayerNorm / biases start at trivial values; perturb them so the test sees them
+        for n_, p_ in vm.named_parameters():
+            if n_.endswith("bias") or "norm" in n_:
+                p_.add_(0.05 * torch.randn_like(p_))
+    pix = torch.randn(2, 3, 4, 32, 32)
+    outv = vm(pix)
+    g = torch.randn_like(outv)
+    outv.backward(g)
+    for k_, v_ in vm.state_dict().items():
+        t["vis.sd." + k_] = v_
+    t["vis.in"], t["vis.out"], t["vis.gout"] = pix, outv, g
+    for n_, p_ in vm.named_parameters():
+        t["vis.grad." + n_] = p_.grad
+    _save(os.path.join(out, "qwen35_vision_tiny.safetensors"), t, "Qwen3.5 vision tower (tiny) + wrapper index fixtures")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -299,7 +360,10 @@ def main():
     sys.path.insert(0, args.ref)
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
-    for fn in (gen_index, gen_ops, gen_qwen, gen_vit, gen_vlm, gen_gpt):
+    only = os.environ.get("GOLDEN_ONLY")
+    for fn in (gen_index, gen_ops, gen_qwen, gen_vit, gen_vlm, gen_gpt, gen_qwen35):
+        if only and fn.__name__ != only:
+            continue
         fn(args.out)
 
 

@@ -199,3 +199,35 @@ def test_gpt2_tiny(golden):
         close(models.gpt2_forward(sd, TINY_GPT, t["in.ids"]), t["out.logits"], atol=1e-5)
         close(models.gpt2_forward(sd, TINY_GPT, t["in.ids"], key_mask=t["in.key_mask"].bool()), t["out.logits_masked"], atol=1e-5)
         close(t["out.logits_embedded"], t["out.logits"], atol=1e-5)
+
+
+# ------------------------------------------------------------------ Qwen3.5 (config 5) vision side + wrapper index ops
+def test_qwen35_index_ops(golden):
+    from oracle import qwen3_5 as q35
+
+    t = golden("qwen35_vision_tiny")
+    assert np.array_equal(q35.patch3d_gather_index(3, 4, 16, 16, 4, 2), t["patch3d.gather"].numpy().astype(np.int64))
+    assert np.array_equal(q35.merge_row_source(2, 4, 6, 2), t["merge.rows"].numpy().astype(np.int64))
+    cos, sin = q35.vision_rope_tables_2d(10_000, 64, 4, 4)
+    assert torch.equal(cos, t["vrope.cos"]) and torch.equal(sin, t["vrope.sin"])
+    ids = t["pos3d.ids"].numpy()
+    assert np.array_equal(q35.position_ids_3d(ids, [[2, 4, 4]], 999, 2), t["pos3d.out"].numpy())
+    assert np.array_equal(q35.position_ids_3d(ids, None, 999, 2), t["pos3d.text_only"].numpy())
+    fused = q35.masked_scatter_rows(t["scatter.emb"], t["pos3d.ids"] == 999, t["scatter.vis"])
+    assert torch.equal(fused, t["scatter.out"])
+
+
+def test_qwen35_vision_tower(golden):
+    from oracle import qwen3_5 as q35
+    from oracle.gen_golden import TINY_Q35_VISION
+
+    t = golden("qwen35_vision_tiny")
+    sd = {k: v.clone().requires_grad_(True) for k, v in sub_dict(t, "vis.sd.").items()}
+    out = q35.vision35_forward(sd, TINY_Q35_VISION, t["vis.in"])
+    close(out, t["vis.out"], atol=2e-5)
+    out.backward(t["vis.gout"])
+    for k, g in sub_dict(t, "vis.grad.").items():
+        if k == "pos_embed.weight":  # only the first gh*gw rows are used
+            close(sd[k].grad, g, rtol=1e-4, atol=2e-5)
+        else:
+            close(sd[k].grad, g, rtol=1e-4, atol=2e-5)
