@@ -51,11 +51,25 @@ int mi355_abi_version(void);
  *   bias         fp32 [N] or NULL;  residual  [M,N] with ldr, or NULL (may alias C: accumulate)
  *   workspace    optional fp32 scratch (16-byte aligned) of workspace_bytes: lets problems with few output tiles
  *                and a long K (weight gradients) split K over several workgroups (slabs + reduce); NULL = never split.
- *   tile_hint    0 = choose by shape; 1 = 128x128 tile (4 waves), 2 = 256x256 tile (8 waves)
+ *   tile_hint    0 = choose by shape; 1 = 128x128 tile (4 waves), 2 = 256x256 tile (8 waves), 3 = 256x256, alternating wave groups
  * Requirements: K-contiguous dims multiple of 8 elements (16-byte rows); see DESIGN.md.            */
 int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                     int64_t ldb, void* C, int64_t ldc, int out_dtype, const float* bias, const void* residual,
                     int64_t ldr, int epilogue, void* workspace, int64_t workspace_bytes, int tile_hint, void* stream);
+
+/* Several independent GEMMs of ONE operand form in one launch, no bias / epilogue / K split.  Replaces the weight-gradient
+ * half of autograd's backward for the Linear layers of one transformer block (qwen3_transformer_block.py:48-53,84-99,
+ * qwen3_attention.py:91-93,148 and the ViT equivalents): each dW = dY^T X alone has fewer output tiles than the chip has
+ * CUs, the block's four together fill it.  `residual` may alias C (gradient accumulation).  count <= 8.
+ *   tile_hint  0 = choose by total tile count; 1 = 128x128; 3 = 256x256                                              */
+typedef struct mi355_gemm_problem {
+    int64_t M, N, K;
+    const void* A; int64_t lda;
+    const void* B; int64_t ldb;
+    void* C; int64_t ldc;
+    const void* residual; int64_t ldr;
+} mi355_gemm_problem;
+int mi355_gemm_bf16_grouped(int form, int count, const mi355_gemm_problem* problems, int out_dtype, int tile_hint, void* stream);
 
 /* column sums: out[n] (+)= sum_m X[m,n]  (bias / cls-token / pos-embedding gradients).  X bf16 or fp32 [M,N] ld=ldx,
  * out fp32 [N]. */

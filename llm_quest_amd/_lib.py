@@ -24,6 +24,7 @@ _P, _I, _L, _F = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float
 # name -> argtypes; every entry point returns int.  Must list exactly what include/mi355_vlm.h declares.
 SIGNATURES = {
     "mi355_gemm_bf16": [_I, _L, _L, _L, _P, _L, _P, _L, _P, _L, _I, _P, _P, _L, _I, _P, _L, _I, _P],
+    "mi355_gemm_bf16_grouped": [_I, _I, _P, _I, _I, _P],
     "mi355_colsum": [_L, _L, _P, _I, _L, _P, _I, _P],
     "mi355_rmsnorm_fwd": [_L, _I, _P, _P, _P, _P, _F, _P],
     "mi355_rmsnorm_bwd": [_L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
@@ -89,6 +90,13 @@ def load():
         fn.restype = ctypes.c_int
     _lib = lib
     return lib
+
+
+class GemmProblem(_c.Structure):
+    """struct mi355_gemm_problem (include/mi355_vlm.h)."""
+
+    _fields_ = [("M", _L), ("N", _L), ("K", _L), ("A", _P), ("lda", _L), ("B", _P), ("ldb", _L), ("C", _P), ("ldc", _L),
+                ("residual", _P), ("ldr", _L)]
 
 
 def ptr(t):

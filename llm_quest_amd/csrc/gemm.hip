@@ -135,20 +135,19 @@ __device__ __forceinline__ void wait_vmcnt() {
     else static_assert(N == 0, "add the immediate");
 }
 
+// position b of a round-robin-over-XCDs numbering -> position in a numbering where each XCD owns one contiguous chunk
+__device__ __forceinline__ int xcd_chunked(int b, int n) {
+    const int xcd = b & 7, q = n >> 3, r = n & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+// One output tile (and one K split) of one problem.  `pid` = tile index in XCD-chunked order, `split` = K-split index.
 template <class T, bool A_TR, bool B_TR, int OUT_DT>
-__global__ __launch_bounds__(T::NTHREADS, T::MIN_WAVES) void gemm_bf16_kernel(GemmParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[T::SMEM];
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, const int split, char* smem) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    // ---- workgroup -> (K split, tile): XCD chunking, then 8-row super-groups ----------------------------
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int split = blockIdx.x / nwg;
-    int pid;
-    {
-        const int b = blockIdx.x - split * nwg, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-    }
+    // ---- tile index -> (tm, tn): 8-row super-groups ----------------------------------------------------
     const int GROUP_M = 8;
     const int in_group = GROUP_M * p.tiles_n;
     const int first_m = (pid / in_group) * GROUP_M;
@@ -251,9 +250,12 @@ __global__ __launch_bounds__(T::NTHREADS, T::MIN_WAVES) void gemm_bf16_kernel(Ge
                     const int younger = min(nt - 1, t + T::NS - 1) - (t + 1);
                     if (younger >= 2) wait_vmcnt<8>(); else if (younger >= 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const bool wait_late = (p.ablate & 8) || ((p.ablate & 16) && ph == 0);
+                if (!wait_late) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
+                if (wait_late) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
                 // -------- MFMA cluster
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -434,6 +436,36 @@ __global__ __launch_bounds__(T::NTHREADS, T::MIN_WAVES) void gemm_bf16_kernel(Ge
     }
 }
 
+template <class T, bool A_TR, bool B_TR, int OUT_DT>
+__global__ __launch_bounds__(T::NTHREADS, T::MIN_WAVES) void gemm_bf16_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[T::SMEM];
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int split = blockIdx.x / nwg;
+    gemm_tile<T, A_TR, B_TR, OUT_DT>(p, xcd_chunked(blockIdx.x - split * nwg, nwg), split, smem);
+}
+
+// Several independent problems of one operand form in ONE launch (the four weight gradients of a transformer block:
+// each alone has fewer output tiles than the chip has CUs, together they fill it).  The concatenated tile list is cut
+// into one contiguous chunk per XCD, so the tiles that share operand panels stay behind one L2.
+constexpr int MAX_GROUP = 8;
+struct GroupTable {
+    GemmParams g[MAX_GROUP];
+    int start[MAX_GROUP + 1];  // first tile of each problem in the concatenated list
+    int count;
+};
+
+template <class T, bool A_TR, bool B_TR, int OUT_DT>
+__global__ __launch_bounds__(T::NTHREADS, T::MIN_WAVES) void gemm_grouped_kernel(GroupTable tbl) {
+    __shared__ __attribute__((aligned(16))) char smem[T::SMEM];
+    const int v = xcd_chunked(blockIdx.x, tbl.start[tbl.count]);
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_GROUP; ++i)
+        if (i < tbl.count && v >= tbl.start[i]) g = i;
+    const GemmParams p = tbl.g[g];
+    gemm_tile<T, A_TR, B_TR, OUT_DT>(p, v - tbl.start[g], 0, smem);
+}
+
 // C = sum_s slab[s] (+ R), converted to the output dtype.  4 columns per thread (N % 8 == 0).
 template <int OUT_DT>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(int64_t M, int64_t N, int ksplit, const float* __restrict__ ws,
@@ -510,6 +542,48 @@ int launch_form(int form, const GemmParams& p, int out_dtype, void* ws, int64_t 
     }
 }
 
+template <class T, bool A_TR, bool B_TR>
+int launch_grouped(GroupTable& tbl, int out_dtype, hipStream_t s) {
+    int64_t total = 0;
+    for (int i = 0; i < tbl.count; ++i) {
+        GemmParams& p = tbl.g[i];
+        p.tiles_m = (int)((p.M + T::BM - 1) / T::BM);
+        p.tiles_n = (int)((p.N + T::BN - 1) / T::BN);
+        tbl.start[i] = (int)total;
+        total += (int64_t)p.tiles_m * p.tiles_n;
+        MI355_REQUIRE(total < 0x7fffffffLL / 16, "mi355_gemm_bf16_grouped: grid too large");
+    }
+    for (int i = tbl.count; i <= MAX_GROUP; ++i) tbl.start[i] = (int)total;
+    if (out_dtype == MI355_DT_BF16)
+        hipLaunchKernelGGL((gemm_grouped_kernel<T, A_TR, B_TR, MI355_DT_BF16>), dim3((unsigned)total), dim3(T::NTHREADS), 0, s, tbl);
+    else
+        hipLaunchKernelGGL((gemm_grouped_kernel<T, A_TR, B_TR, MI355_DT_F32>), dim3((unsigned)total), dim3(T::NTHREADS), 0, s, tbl);
+    MI355_LAUNCH_CHECK("mi355_gemm_bf16_grouped");
+    return 0;
+}
+
+template <class T>
+int launch_grouped_form(int form, GroupTable& tbl, int out_dtype, hipStream_t s) {
+    switch (form) {
+        case MI355_GEMM_NT: return launch_grouped<T, false, false>(tbl, out_dtype, s);
+        case MI355_GEMM_NN: return launch_grouped<T, false, true>(tbl, out_dtype, s);
+        default: return launch_grouped<T, true, true>(tbl, out_dtype, s);
+    }
+}
+
+int check_operands(const char* who, int form, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, const void* C) {
+    MI355_REQUIRE(M > 0 && N > 0 && K > 0, "%s: empty problem M=%ld N=%ld K=%ld", who, (long)M, (long)N, (long)K);
+    MI355_REQUIRE(A && B && C, "%s: null operand", who);
+    MI355_REQUIRE((lda & 7) == 0 && (ldb & 7) == 0, "%s: lda/ldb must be multiples of 8 (16-byte rows)", who);
+    MI355_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "%s: A/B must be 16-byte aligned", who);
+    if (form == MI355_GEMM_NT) MI355_REQUIRE((K & 7) == 0, "%s(NT): K must be a multiple of 8", who);
+    if (form == MI355_GEMM_NN) MI355_REQUIRE((K & 7) == 0 && (N & 7) == 0, "%s(NN): K,N must be multiples of 8", who);
+    if (form == MI355_GEMM_TN) MI355_REQUIRE((M & 7) == 0 && (N & 7) == 0, "%s(TN): M,N must be multiples of 8", who);
+    // a tile's DMA offsets are 31-bit: 256 rows (or 64 k-rows) of one operand must span < 2 GiB
+    MI355_REQUIRE(lda * 2 * 256 < 0x7fffffffLL && ldb * 2 * 256 < 0x7fffffffLL, "%s: leading dimension too large", who);
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------- colsum
 template <int DT>
 __global__ __launch_bounds__(256) void colsum_kernel(int64_t M, int64_t N, const void* Xv, int64_t ldx, float* out, int rows_per_block) {
@@ -538,16 +612,8 @@ extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const 
                                const void* residual, int64_t ldr, int epilogue, void* workspace, int64_t workspace_bytes,
                                int tile_hint, void* stream) {
     MI355_REQUIRE(form >= 0 && form <= 2, "mi355_gemm_bf16: bad form %d", form);
-    MI355_REQUIRE(M > 0 && N > 0 && K > 0, "mi355_gemm_bf16: empty problem M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
     MI355_REQUIRE(out_dtype == MI355_DT_BF16 || out_dtype == MI355_DT_F32, "mi355_gemm_bf16: bad out_dtype");
-    MI355_REQUIRE(A && B && C, "mi355_gemm_bf16: null operand");
-    MI355_REQUIRE((lda & 7) == 0 && (ldb & 7) == 0, "mi355_gemm_bf16: lda/ldb must be multiples of 8 (16-byte rows)");
-    MI355_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "mi355_gemm_bf16: A/B must be 16-byte aligned");
-    if (form == MI355_GEMM_NT) MI355_REQUIRE((K & 7) == 0, "mi355_gemm_bf16(NT): K must be a multiple of 8");
-    if (form == MI355_GEMM_NN) MI355_REQUIRE((K & 7) == 0 && (N & 7) == 0, "mi355_gemm_bf16(NN): K,N must be multiples of 8");
-    if (form == MI355_GEMM_TN) MI355_REQUIRE((M & 7) == 0 && (N & 7) == 0, "mi355_gemm_bf16(TN): M,N must be multiples of 8");
-    // a tile's DMA offsets are 31-bit: 256 rows (or 64 k-rows) of one operand must span < 2 GiB
-    MI355_REQUIRE(lda * 2 * 256 < 0x7fffffffLL && ldb * 2 * 256 < 0x7fffffffLL, "mi355_gemm_bf16: leading dimension too large");
+    if (int rc = check_operands("mi355_gemm_bf16", form, M, N, K, A, lda, B, ldb, C)) return rc;
     MI355_REQUIRE(workspace == nullptr || ((uintptr_t)workspace & 15) == 0, "mi355_gemm_bf16: workspace must be 16-byte aligned");
     const int ablate = tile_hint >> 8;
     tile_hint &= 0xff;
@@ -571,6 +637,34 @@ extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const 
         case 3: return launch_form<Cfg256a>(form, p, out_dtype, workspace, workspace_bytes, s);
         default: return launch_form<Cfg128>(form, p, out_dtype, workspace, workspace_bytes, s);
     }
+}
+
+extern "C" int mi355_gemm_bf16_grouped(int form, int count, const mi355_gemm_problem* problems, int out_dtype, int tile_hint,
+                                       void* stream) {
+    MI355_REQUIRE(form >= 0 && form <= 2, "mi355_gemm_bf16_grouped: bad form %d", form);
+    MI355_REQUIRE(count >= 1 && count <= MAX_GROUP && problems, "mi355_gemm_bf16_grouped: count must be 1..%d", MAX_GROUP);
+    MI355_REQUIRE(out_dtype == MI355_DT_BF16 || out_dtype == MI355_DT_F32, "mi355_gemm_bf16_grouped: bad out_dtype");
+    MI355_REQUIRE(tile_hint == 0 || tile_hint == 1 || tile_hint == 3, "mi355_gemm_bf16_grouped: tile_hint must be 0 (auto), 1 (128x128) or 3 (256x256)");
+    GroupTable tbl;
+    tbl.count = count;
+    int64_t tiles256 = 0;
+    bool small = false;
+    for (int i = 0; i < count; ++i) {
+        const mi355_gemm_problem& q = problems[i];
+        if (int rc = check_operands("mi355_gemm_bf16_grouped", form, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C)) return rc;
+        GemmParams& p = tbl.g[i];
+        p.A = (const bf16_t*)q.A; p.B = (const bf16_t*)q.B; p.C = q.C; p.bias = nullptr; p.R = q.residual;
+        p.M = q.M; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc; p.ldr = q.ldr;
+        p.epilogue = MI355_EPI_NONE; p.tiles_m = p.tiles_n = 0; p.ksplit = 1; p.ws = nullptr; p.ablate = 0;
+        tiles256 += ((q.M + 255) / 256) * ((q.N + 255) / 256);
+        small |= q.M < 256 || q.N < 256;
+    }
+    for (int i = count; i < MAX_GROUP; ++i) tbl.g[i] = tbl.g[0];
+    // 256x256 tiles (one workgroup per CU) once they cover most of the chip; otherwise 128x128 (two per CU, 4x the tiles)
+    const int cfg = tile_hint ? tile_hint : ((small || tiles256 < 160) ? 1 : 3);
+    hipStream_t s = (hipStream_t)stream;
+    if (cfg == 3) return launch_grouped_form<Cfg256a>(form, tbl, out_dtype, s);
+    return launch_grouped_form<Cfg128>(form, tbl, out_dtype, s);
 }
 
 extern "C" int mi355_colsum(int64_t M, int64_t N, const void* X, int x_dtype, int64_t ldx, float* out, int accumulate,

@@ -72,6 +72,45 @@ def gemm(form, a, b, out=None, out_dtype=BF16, bias=None, residual=None, gelu=Fa
     return out
 
 
+def gemm_grouped(form, problems, tile=0):
+    """One launch for several independent GEMMs of one form: problems = [(a, b, out, residual_or_None), ...] (<= 8, same
+    output dtype, outputs preallocated).  Used for the weight gradients of a transformer block."""
+    import ctypes as _c
+
+    if not problems:
+        return
+    if len(problems) > 8:
+        for i in range(0, len(problems), 8):
+            gemm_grouped(form, problems[i : i + 8], tile)
+        return
+    table = (L.GemmProblem * len(problems))()
+    odt = problems[0][2].dtype
+    for q, (a, b, out, residual) in zip(table, problems):
+        L.require_gpu(a, b, out, residual)
+        _rowmajor(a, "A")
+        _rowmajor(b, "B")
+        _rowmajor(out, "C")
+        if a.dtype != BF16 or b.dtype != BF16:
+            raise TypeError("gemm operands must be bf16")
+        if form == L.GEMM_NT:
+            (M, Kd), (N, K2) = a.shape, b.shape
+        elif form == L.GEMM_NN:
+            (M, Kd), (K2, N) = a.shape, b.shape
+        else:
+            (Kd, M), (K2, N) = a.shape, b.shape
+        if Kd != K2 or tuple(out.shape) != (M, N) or out.dtype != odt:
+            raise ValueError(f"gemm_grouped: inconsistent problem {tuple(a.shape)} x {tuple(b.shape)} -> {tuple(out.shape)} {out.dtype}")
+        q.M, q.N, q.K = M, N, Kd
+        q.A, q.lda, q.B, q.ldb, q.C, q.ldc = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0)
+        q.residual, q.ldr = None, 0
+        if residual is not None:
+            _rowmajor(residual, "residual")
+            if residual.dtype != odt or tuple(residual.shape) != (M, N):
+                raise ValueError("gemm_grouped: residual must match the output's shape and dtype")
+            q.residual, q.ldr = residual.data_ptr(), residual.stride(0)
+    L.call("mi355_gemm_bf16_grouped", form, len(problems), _c.cast(table, _c.c_void_p), L.dt_code(odt), tile)
+
+
 def colsum(x, out=None, accumulate=False):
     """out[n] (+)= sum_m x[m, n]; x bf16 or fp32 (row-strided views allowed), out fp32."""
     L.require_gpu(x, out)

@@ -11,6 +11,7 @@ import torch
 
 from llm_quest_amd import _lib as L
 from llm_quest_amd import kernels as K
+from llm_quest_amd import ops
 from llm_quest_amd.multimodal.vision_transformer.vit_attention import bf16_cached, f32_cat_cached
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -33,12 +34,16 @@ def _acc(p, g):
     L.call("mi355_reduce_rows_f32", 1, p.numel(), L.ptr(g), L.ptr(dst), L.DT_F32, int(acc))
 
 
-def _wgrad(p, dy, x):
-    """p.grad[N,K] (+)= dy^T x  (TN GEMM, fp32 output)."""
+def _wgrad(p, dy, x, defer=None):
+    """p.grad[N,K] (+)= dy^T x  (TN GEMM, fp32 output).  With ``defer`` (a list) the problem is recorded for one grouped
+    launch per block (``ops._flush_wgrads``)."""
     if not p.requires_grad:
         return
     dst, acc = _grad_buf(p)
     view = dst.view(dy.shape[1], x.shape[1])
+    if defer is not None and ops.GROUP_WGRADS:
+        defer.append((dy, x, view, view if acc else None))
+        return
     K.gemm(L.GEMM_TN, dy, x, out=view, residual=view if acc else None)
 
 
@@ -137,34 +142,35 @@ def vit_backward(m, saved, dout):
         x, mean1, rsig1, h1, qkv, ctx, lse, x2, mean2, rsig2, h2, y1, f = sv
         att, ffn = blk.att, blk.ffn
         H, Dh = att.num_heads, att.head_dim
+        wg = []  # this block's six weight gradients, one grouped launch
         # ---- FFN half
         dx3b = K.cast(dx, BF16)
         df = K.gemm(L.GEMM_NN, dx3b, bf16_cached(ffn, "w2", [ffn.layers[2].weight]))
-        _wgrad(ffn.layers[2].weight, dx3b, f)
+        _wgrad(ffn.layers[2].weight, dx3b, f, wg)
         _bgrad(ffn.layers[2].bias, dx3b)
         dy1 = K.gelu_bwd(y1, df)
         dh2 = K.gemm(L.GEMM_NN, dy1, bf16_cached(ffn, "w1", [ffn.layers[0].weight]))
-        _wgrad(ffn.layers[0].weight, dy1, h2)
+        _wgrad(ffn.layers[0].weight, dy1, h2, wg)
         _bgrad(ffn.layers[0].bias, dy1)
         dx2 = _ln_bwd(blk.ln_2, x2, mean2, rsig2, dh2, dx)
         # ---- attention half
         dx2b = K.cast(dx2, BF16)
         dctx = K.gemm(L.GEMM_NN, dx2b, bf16_cached(att, "wo", [att.out_proj.weight]))
-        _wgrad(att.out_proj.weight, dx2b, ctx)
+        _wgrad(att.out_proj.weight, dx2b, ctx, wg)
         _bgrad(att.out_proj.bias, dx2b)
         dqkv = torch.empty_like(qkv)
         K.attn_bwd(qkv[:, :d], qkv[:, d : 2 * d], qkv[:, 2 * d :], ctx, dctx, lse, B, S, H, H, Dh,
                    dqkv[:, :d], dqkv[:, d : 2 * d], dqkv[:, 2 * d :], key_mask=None, causal=False, scale=att.att_scaling)
         wqkv = bf16_cached(att, "wqkv", [att.w_queries.weight, att.w_keys.weight, att.w_values.weight])
         dh1 = K.gemm(L.GEMM_NN, dqkv, wqkv)
-        gw = K.gemm(L.GEMM_TN, dqkv, h1, out_dtype=F32)  # [3d, d] fused, then split over the three parameters
         for i, lin in enumerate((att.w_queries, att.w_keys, att.w_values)):
-            _acc(lin.weight, gw[i * d : (i + 1) * d])
+            _wgrad(lin.weight, dqkv[:, i * d : (i + 1) * d], h1, wg)
         if att.w_queries.bias is not None:
             gb = K.colsum(dqkv)
             for i, lin in enumerate((att.w_queries, att.w_keys, att.w_values)):
                 _acc(lin.bias, gb[i * d : (i + 1) * d])
         dx = _ln_bwd(blk.ln_1, x, mean1, rsig1, dh1, dx2)
+        ops._flush_wgrads(wg)
     # ---- embedding: pos / cls sums over the batch, patch projection wgrad
     gpos = K.colsum(dx.view(B, S * d))  # sum_b dh[b, s, :]
     _acc(m.pos_embedding, gpos)

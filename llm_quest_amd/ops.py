@@ -10,6 +10,8 @@ Design (MI355X-first):
     bucket's all-reduce can start on the communication stream while earlier blocks are still in backward.
 """
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -33,12 +35,29 @@ def arena_for(module):
     return ar
 
 
-def _wgrad(arena, first, last, dy, x):
-    """dW[first..last] (+)= dy^T x, written into the arena gradient (TN GEMM)."""
+GROUP_WGRADS = os.environ.get("MI355_GROUP_WGRADS", "1") != "0"  # 0: one launch per weight gradient (A/B measurements)
+
+
+def _wgrad(arena, first, last, dy, x, defer=None):
+    """dW[first..last] (+)= dy^T x, written into the arena gradient (TN GEMM).  With `defer` (a list) the problem is only
+    recorded: the caller flushes the list with ONE grouped launch (``_flush_wgrads``) once the block's backward is done."""
     if not first.requires_grad:
         return
     view, acc = arena.grad_target(first, last)
+    if defer is not None and GROUP_WGRADS:
+        defer.append((dy, x, view, view if acc else None))
+        return
     K.gemm(L.GEMM_TN, dy, x, out=view, residual=view if acc else None)
+
+
+def _flush_wgrads(defer):
+    """The weight gradients of one block, each too small to fill the chip, as one grouped TN launch per output dtype."""
+    by_dtype = {}
+    for q in defer:
+        by_dtype.setdefault(q[2].dtype, []).append(q)
+    for qs in by_dtype.values():
+        K.gemm_grouped(L.GEMM_TN, qs)
+    defer.clear()
 
 
 def _vecgrad(arena, p):
@@ -92,7 +111,7 @@ def attention_forward(att, arena, h1, rt):
     return ctx, (qkv, q, k, rstd, lse)
 
 
-def attention_backward(att, arena, h1, ctx, saved, dctx, rt):
+def attention_backward(att, arena, h1, ctx, saved, dctx, rt, defer=None):
     """Returns dh1 [M,d]; writes the QKV / QK-norm weight gradients."""
     Hq, Hkv, D = att.num_heads, att.num_kv_groups, att.head_dim
     qkv, q, k, rstd, lse = saved
@@ -108,7 +127,7 @@ def attention_backward(att, arena, h1, ctx, saved, dctx, rt):
             K.add_f32_to_bf16(g.contiguous(), view if acc else None, view)
     wqkv = arena.fused(att.w_queries.weight, att.w_values.weight)
     dh1 = K.gemm(L.GEMM_NN, dqkv, wqkv)
-    _wgrad(arena, att.w_queries.weight, att.w_values.weight, dqkv, h1)
+    _wgrad(arena, att.w_queries.weight, att.w_values.weight, dqkv, h1, defer)
     return dh1
 
 
@@ -133,23 +152,24 @@ def block_backward(blk, saved, dx3, rt):
     att, ffn = blk.att, blk.ffn
     F_ = ffn.lin1.weight.shape[0]
     x, h1, rstd1, ctx, att_saved, x2, h2, rstd2, gu, a = saved
+    wg = []  # the four weight-gradient GEMMs run as one grouped launch at the end (their operands stay alive until then)
     # ---- FFN half
     da = K.gemm(L.GEMM_NN, dx3, ffn.lin2.weight)
-    _wgrad(arena, ffn.lin2.weight, None, dx3, a)
+    _wgrad(arena, ffn.lin2.weight, None, dx3, a, wg)
     dgu = K.swiglu_bwd(gu, da, F_)
     del da
     wgu = arena.fused(ffn.lin1.weight, ffn.lin_gate.weight)
     dh2 = K.gemm(L.GEMM_NN, dgu, wgu)
-    _wgrad(arena, ffn.lin1.weight, ffn.lin_gate.weight, dgu, h2)
-    del dgu
+    _wgrad(arena, ffn.lin1.weight, ffn.lin_gate.weight, dgu, h2, wg)
     gview, gacc = _vecgrad(arena, blk.norm2.weight)
     dx2, _ = K.rmsnorm_bwd(x2, blk.norm2.weight, rstd2, dh2, dres=dx3, dw_out=gview, dw_accumulate=gacc)
     # ---- attention half
     dctx = K.gemm(L.GEMM_NN, dx2, att.out_proj.weight)
-    _wgrad(arena, att.out_proj.weight, None, dx2, ctx)
-    dh1 = attention_backward(att, arena, h1, ctx, att_saved, dctx, rt)
+    _wgrad(arena, att.out_proj.weight, None, dx2, ctx, wg)
+    dh1 = attention_backward(att, arena, h1, ctx, att_saved, dctx, rt, wg)
     gview, gacc = _vecgrad(arena, blk.norm1.weight)
     dx, _ = K.rmsnorm_bwd(x, blk.norm1.weight, rstd1, dh1, dres=dx2, dw_out=gview, dw_accumulate=gacc)
+    _flush_wgrads(wg)
     hook = getattr(blk, "_grad_ready", None)
     if hook is not None:
         hook(blk)

@@ -17,6 +17,7 @@ import torch.nn as nn
 
 from llm_quest_amd import _lib as L
 from llm_quest_amd import kernels as K
+from llm_quest_amd import ops
 from llm_quest_amd.multimodal.vision_transformer.vit_attention import bf16_cached
 from llm_quest_amd.multimodal.vision_transformer.vit_train import _acc, _bgrad, _wgrad
 
@@ -158,27 +159,29 @@ def _backward(m, saved_all, dout):
     dx = _ln_bwd(ma.norm, xl, meanm, rsigm, dhn, None)
     for blk, sv in zip(reversed(m.blocks), reversed(saved)):
         x, mean1, rsig1, h1, qkv, q, k, ctx, lse, x2, mean2, rsig2, h2, y1, f = sv
+        wg = []  # this block's four weight gradients, one grouped launch
         dx3b = K.cast(dx, BF16)
         df = K.gemm(L.GEMM_NN, dx3b, bf16_cached(blk.ffn, "w2", [blk.ffn.lin2.weight]))
-        _wgrad(blk.ffn.lin2.weight, dx3b, f)
+        _wgrad(blk.ffn.lin2.weight, dx3b, f, wg)
         _bgrad(blk.ffn.lin2.bias, dx3b)
         dy1 = K.gelu_bwd(y1, df, tanh=True)
         dh2 = K.gemm(L.GEMM_NN, dy1, bf16_cached(blk.ffn, "w1", [blk.ffn.lin1.weight]))
-        _wgrad(blk.ffn.lin1.weight, dy1, h2)
+        _wgrad(blk.ffn.lin1.weight, dy1, h2, wg)
         _bgrad(blk.ffn.lin1.bias, dy1)
         dx2 = _ln_bwd(blk.norm2, x2, mean2, rsig2, dh2, dx)
         dx2b = K.cast(dx2, BF16)
         dctx = K.gemm(L.GEMM_NN, dx2b, bf16_cached(blk.att, "wo", [blk.att.proj.weight]))
-        _wgrad(blk.att.proj.weight, dx2b, ctx)
+        _wgrad(blk.att.proj.weight, dx2b, ctx, wg)
         _bgrad(blk.att.proj.bias, dx2b)
         dqkv = torch.empty_like(qkv)
         dq, dk = torch.empty_like(q), torch.empty_like(k)
         K.attn_bwd(q, k, qkv[:, 2 * d :], ctx, dctx, lse, B, S, H_, H_, Dh, dq, dk, dqkv[:, 2 * d :], key_mask=None, causal=False, scale=Dh**-0.5)
         K.qknorm_rope_bwd(qkv, None, None, m.cos, m.sin, tok_pos, None, dq, dk, dqkv, H_, H_, Dh)  # RoPE^T only
         dh1 = K.gemm(L.GEMM_NN, dqkv, bf16_cached(blk.att, "wqkv", [blk.att.qkv.weight]))
-        _wgrad(blk.att.qkv.weight, dqkv, h1)
+        _wgrad(blk.att.qkv.weight, dqkv, h1, wg)
         _bgrad(blk.att.qkv.bias, dqkv)
         dx = _ln_bwd(blk.norm1, x, mean1, rsig1, dh1, dx2)
+        ops._flush_wgrads(wg)
     # patch projection + positional embedding (summed over batch and frames)
     pe = m.patch_embed
     nsp = m.n_spatial_patches

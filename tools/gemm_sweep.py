@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from llm_quest_amd import _lib as L, kernels as K
 
-ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=32); ap.add_argument("--tiles", default="1,2,3"); ap.add_argument("--only", default=""); args = ap.parse_args()
+ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=32); ap.add_argument("--tiles", default="1,2,3"); ap.add_argument("--only", default=""); ap.add_argument("--lib", action="store_true"); args = ap.parse_args()
 TILES = [int(x) for x in args.tiles.split(",")]
 M, Mh = args.batch * 709, args.batch * 512
 dev = "cuda"
@@ -37,5 +37,14 @@ for name, form, sa, sb in shapes:
         e.record(); torch.cuda.synchronize()
         ms = s.elapsed_time(e) / 5
         res.append(f"t{tile:#x}: {ms*1e3:7.1f} us {flops/ms/1e9:7.1f} TF")
+    if args.lib:  # calibration only: what the vendor library reaches on the same operands
+        fn = {L.GEMM_NT: lambda: a @ b.t(), L.GEMM_NN: lambda: a @ b, L.GEMM_TN: lambda: a.t() @ b}[form]
+        for _ in range(3): o2 = fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(5): o2 = fn()
+        e.record(); torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / 5
+        res.append(f"lib: {ms*1e3:7.1f} us {flops/ms/1e9:7.1f} TF"); del o2
     print(f"{name:22s} " + " | ".join(res), flush=True)
     del a, b, out
