@@ -11,7 +11,7 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355vlm.so")
+LIB_PATH = os.environ.get("MI355_LIB_PATH") or os.path.join(_HERE, "libmi355vlm.so")  # override: profiling builds only
 CSRC = os.path.join(_HERE, "csrc")
 
 DT_BF16, DT_F32 = 0, 1

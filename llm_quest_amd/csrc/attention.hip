@@ -11,6 +11,8 @@
 // Masking follows the reference (qwen3_attention.py:130-142): masked scores take a FINITE fill value, so a row
 // whose visible keys are all masked degenerates to uniform attention over all S keys exactly as upstream; keys
 // beyond S do not exist and get -inf.  Scores stay in fp32 (the reference rounds them to bf16 twice).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -133,6 +135,82 @@ __device__ __forceinline__ void load_rows_frag(const bf16_t* base, int64_t ld, i
     }
 }
 
+// ---- registers owned by name in the accumulator file -----------------------------------------------------------------
+// The backward kernels need > 256 registers per lane.  Two things hipcc (ROCm 7.2) does with that were the whole cost of the
+// first version of these kernels: (1) it homes loop-carried MFMA accumulators in VGPRs and copies all 16 registers of a tile
+// into and out of the AGPRs around every MFMA (840 v_accvgpr_* per loop trip of the dK/dV pass); (2) it issues each LDS
+// fragment read immediately in front of the MFMA that consumes it, so with one wave per SIMD every MFMA waits a full LDS
+// latency (~10k cycles per trip for 2k cycles of MFMA).  So here:
+//   * dK^T / dV^T / dQ^T tiles and the register-resident B operands (K, V resp. Q, dO rows) are literal AGPRs at the TOP of
+//     the accumulator file, a[256-OWNED ...], touched only by the statements below.  Every statement lists the whole owned
+//     range as clobbered: that reserves it in the kernel descriptor and keeps compiler values that live across a statement
+//     out of it; hipcc allocates AGPRs for its own purposes from a0 upward and stays below (tools/audit_agpr.py, run by
+//     tests/test_abi_cpu.py, fails the build if a compiler instruction names a register of an owned range).
+//   * every MFMA is a volatile statement with a "memory" clobber, so LDS reads keep their source order relative to the
+//     MFMAs: the kernels issue fragment reads PD MFMAs ahead into a ring of R register slots, and the compiler only adds
+//     the counted lgkmcnt waits.
+#define AGPR_CL_64 "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
+#define AGPR_CL_96 AGPR_CL_64, "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191"
+#define AGPR_CL_128 AGPR_CL_96, "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159"
+#define AGPR_CL_192 AGPR_CL_128, "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"
+#ifndef ATTN_ABL
+#define ATTN_ABL 0  // profiling builds only: 1 = no fragment reads, 2 = no B phase, 4 = no C MFMAs, 8 = no A MFMAs
+#endif
+#define OWNED_ASM(OWNED, ...)                                                     \
+    do {                                                                          \
+        static_assert((OWNED) == 64 || (OWNED) == 96 || (OWNED) == 128 || (OWNED) == 192, "no clobber list of this size"); \
+        if constexpr ((OWNED) == 64) asm volatile(__VA_ARGS__ : AGPR_CL_64, "memory");        \
+        else if constexpr ((OWNED) == 96) asm volatile(__VA_ARGS__ : AGPR_CL_96, "memory");   \
+        else if constexpr ((OWNED) == 128) asm volatile(__VA_ARGS__ : AGPR_CL_128, "memory"); \
+        else asm volatile(__VA_ARGS__ : AGPR_CL_192, "memory");                               \
+    } while (0)
+
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+// owned tile (16 registers from owned offset OFF) += A x B, both operands in VGPRs.
+// s_nop 1: a B register written by the VALU instruction just before (v_cvt_pk -> MFMA operand).
+template <int OWNED, int OFF>
+__device__ __forceinline__ void mfma_owned(const bf16x8& a, const bf16x8& b) {
+    static_assert(OFF % 16 == 0 && OFF + 16 <= OWNED, "tile outside the owned range");
+    constexpr int R0 = 256 - OWNED + OFF;
+    OWNED_ASM(OWNED, "s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "i"(R0), "i"(R0 + 15));
+}
+// compiler-allocated tile (an "a" operand, written and read in straight-line code) (+)= A x ownedB, where ownedB is the
+// 4-register B operand at owned offset OFF.  FIRST: start from zero (srcC = 0) instead of accumulating.
+template <int OWNED, int OFF, bool FIRST>
+__device__ __forceinline__ void mfma_ownedB(f32x16& acc, const bf16x8& a) {
+    static_assert(OFF % 4 == 0 && OFF + 4 <= OWNED, "operand outside the owned range");
+    constexpr int R0 = 256 - OWNED + OFF;
+    if constexpr (FIRST) OWNED_ASM(OWNED, "v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=a"(acc) : "v"(a), "i"(R0), "i"(R0 + 3));
+    else OWNED_ASM(OWNED, "v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+a"(acc) : "v"(a), "i"(R0), "i"(R0 + 3));
+}
+// wait states between the last MFMA into a compiler-allocated tile and its first VALU read (16-pass XDL -> read: 18)
+__device__ __forceinline__ void tiles_settle(f32x16& x, f32x16& y) { asm volatile("s_nop 15\n\ts_nop 3" : "+a"(x), "+a"(y)); }
+template <int OWNED, int OFF, int COUNT>
+__device__ __forceinline__ void owned_zero() {
+    static_for<COUNT>([&](auto r) { OWNED_ASM(OWNED, "v_accvgpr_write_b32 a[%c0], 0" ::"i"(256 - OWNED + OFF + r.value)); });
+}
+// a 4-register operand (8 bf16) into owned offset OFF
+template <int OWNED, int OFF>
+__device__ __forceinline__ void owned_write4(const bf16x8& v) {
+    const u32x4 w = __builtin_bit_cast(u32x4, v);
+    OWNED_ASM(OWNED, "v_accvgpr_write_b32 a[%c4], %0\n\tv_accvgpr_write_b32 a[%c5], %1\n\tv_accvgpr_write_b32 a[%c6], %2\n\tv_accvgpr_write_b32 a[%c7], %3"
+              ::"v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "i"(256 - OWNED + OFF), "i"(256 - OWNED + OFF + 1), "i"(256 - OWNED + OFF + 2), "i"(256 - OWNED + OFF + 3));
+}
+template <int OWNED>
+__device__ __forceinline__ void owned_settle() { OWNED_ASM(OWNED, "s_nop 15\n\ts_nop 3" ::); }
+template <int OWNED, int R>
+__device__ __forceinline__ float owned_read() {
+    float x;
+    asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(x) : "i"(256 - OWNED + R));
+    return x;
+}
+
 __device__ __forceinline__ int acc_row(int e, int lane) { return (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); }
 
 // ================================================================================================ forward
@@ -142,6 +220,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int B, int S, int Hq, 
                                                           int64_t ldv, bf16_t* __restrict__ o, int64_t ldo, float* __restrict__ lse,
                                                           const uint8_t* __restrict__ key_mask, int causal, float scale_log2) {
     using C = Cfg<D>;
+    const int abl = causal >> 8;  // profiling only: 1 = no DMA after the first tile, 2 = no exp
+    causal &= 0xff;
     __shared__ __attribute__((aligned(16))) char smem[4 * C::TILE];  // 2 stages x (K row image, V tr image)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -154,9 +234,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int B, int S, int Hq, 
     const int q0 = qb * 128;
     const int qg = q0 + wave * 32 + (lane & 31);
     const bool qvalid = qg < S;
-
-    bf16x8 qf[C::KS];
-    load_rows_frag<D>(q + (int64_t)b * S * ldq + (int64_t)hq * D, ldq, qg, qvalid, lane, qf);
 
     const bf16_t* kbase = k + (int64_t)b * S * ldk + (int64_t)hkv * D;
     const bf16_t* vbase = v + (int64_t)b * S * ldv + (int64_t)hkv * D;
@@ -177,16 +254,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int B, int S, int Hq, 
     };
 
     const LaneOff<D> lo = lane_offsets<D>(lane);
-    issue(0, 0);
+    issue(0, 0);  // first tile first, then the query rows: their latencies overlap
+    bf16x8 qf[C::KS];
+    load_rows_frag<D>(q + (int64_t)b * S * ldq + (int64_t)hq * D, ldq, qg, qvalid, lane, qf);
+    // key-padding byte of this lane's key in the NEXT tile: loaded one tile ahead so its latency hides behind a whole tile
+    uint8_t mk = (key_mask && lane < S) ? key_mask[(int64_t)b * S + lane] : (uint8_t)0;
     for (int kt = 0; kt < ntiles; ++kt) {
         __syncthreads();
-        if (kt + 1 < ntiles) issue(kt + 1, (kt + 1) & 1);
+        if (kt + 1 < ntiles && !(abl & 1)) issue(kt + 1, (kt + 1) & 1);
         const int koff = (kt & 1) * 2 * C::TILE, voff = koff + C::TILE;
         // key-padding bits of this tile (1 = real token); keys beyond S read as padding here and are removed below
         unsigned long long kbits = ~0ull;
         if (key_mask) {
-            const int kg = kt * 64 + lane;
-            kbits = __ballot(kg < S && key_mask[(int64_t)b * S + kg] != 0);
+            kbits = __ballot(mk != 0);
+            const int kn = (kt + 1) * 64 + lane;
+            mk = kn < S ? key_mask[(int64_t)b * S + kn] : (uint8_t)0;
         }
         // a wave whose 32 queries all precede this tile has nothing visible here (unless a row is still fully masked)
         const bool wave_active = !causal || (kt * 64 <= q0 + wave * 32 + 31) || __any(m == MASK_T);
@@ -317,8 +399,12 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(int B, int S, int Hq, c
     }
 }
 
-// ---- dQ pass: query on the lane, exactly the forward's structure with three products per key sub-tile:
-//   S^T = K Q^T ;  dP^T = V dO^T ;  dQ^T += K^T dS^T   with  P^T = exp2(S^T*c - lse2[q]),  dS^T = P^T * (dP^T - delta[q]).
+// ---- dQ pass: query on the lane (the forward's orientation).  Per 64-key tile, for each 32-key sub-tile st:
+//   A(st):  S^T = K Q^T ;  dP^T = V dO^T            (A operand: K / V rows from LDS, B operand: Q / dO rows, owned AGPRs)
+//   B(st):  P^T = exp2(S^T*c - lse2[q]) ;  dS^T = P^T * (dP^T - delta[q]) * scale        (VALU, lane-local row constants)
+//   C(st):  dQ^T += K^T dS^T                        (A operand: transposed reads of the K tile, B operand: packed dS^T)
+// One wave per SIMD, so the overlap is written out: the MFMAs run in the order A(0) A(1) C(0) C(1), B(0) is spread over the
+// MFMAs of A(1) and B(1) over those of C(0), and fragment reads run PD MFMAs ahead of their consumer.
 template <int D>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(int B, int S, int Hq, int Hkv, const bf16_t* __restrict__ q, int64_t ldq,
                                                              const bf16_t* __restrict__ k, int64_t ldk, const bf16_t* __restrict__ v,
@@ -327,6 +413,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(int B, int S, int H
                                                              bf16_t* __restrict__ dq, int64_t lddq, const uint8_t* __restrict__ key_mask,
                                                              int causal, float scale, float scale_log2) {
     using C = Cfg<D>;
+    constexpr int KS = C::KS, DT = C::DT;
+    constexpr int NA = 2 * KS, NC = 2 * DT, NG = 2 * NA + 2 * NC;  // MFMAs of one A part, one C part, one key tile
+    constexpr int OWNED = 16 * DT + 8 * KS, QF0 = 16 * DT, OF0 = QF0 + 4 * KS;  // dQ^T tiles | Q rows | dO rows
+    constexpr int RING = 8, PD = 6;
+    const int abl = causal >> 8;  // profiling only: 1 = no DMA after the first tile
+    causal &= 0xff;
     __shared__ __attribute__((aligned(16))) char smem[6 * C::TILE];  // 2 stages x (K row, K tr, V row)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -339,22 +431,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(int B, int S, int H
     const int qg = q0 + wave * 32 + (lane & 31);
     const bool qvalid = qg < S;
 
-    bf16x8 qf[C::KS], dof[C::KS];
-    load_rows_frag<D>(q + (int64_t)b * S * ldq + (int64_t)hq * D, ldq, qg, qvalid, lane, qf);
-    load_rows_frag<D>(d_o + (int64_t)b * S * lddo + (int64_t)hq * D, lddo, qg, qvalid, lane, dof);
-    const float lse2 = qvalid ? lse[((int64_t)b * Hq + hq) * S + qg] * LOG2E : 0.f;
-    const float dlt = qvalid ? delta[((int64_t)b * Hq + hq) * S + qg] : 0.f;
-
     const bf16_t* kbase = k + (int64_t)b * S * ldk + (int64_t)hkv * D;
     const bf16_t* vbase = v + (int64_t)b * S * ldv + (int64_t)hkv * D;
     const int ntiles_all = (S + 63) / 64;
     const int ntiles = causal ? min(ntiles_all, (q0 + 127) / 64 + 1) : ntiles_all;
-
-    f32x16 dqacc[C::DT];
-#pragma unroll
-    for (int i = 0; i < C::DT; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) dqacc[i][e] = 0.f;
 
     auto issue = [&](int kt, int stage) {
         char* st_ = smem + stage * 3 * C::TILE;
@@ -363,81 +443,120 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(int B, int S, int H
         dma_tile<D, false>(vbase + (int64_t)kt * 64 * ldv, ldv, S - kt * 64, st_ + 2 * C::TILE, wave, lane);
     };
 
-    const LaneOff<D> lo = lane_offsets<D>(lane);
+    // everything with a global-memory latency is requested up front, first tile first; the owned registers are filled after
     issue(0, 0);
+    {
+        bf16x8 tq[KS], to[KS];
+        load_rows_frag<D>(q + (int64_t)b * S * ldq + (int64_t)hq * D, ldq, qg, qvalid, lane, tq);
+        load_rows_frag<D>(d_o + (int64_t)b * S * lddo + (int64_t)hq * D, lddo, qg, qvalid, lane, to);
+        owned_zero<OWNED, 0, 16 * DT>();
+        static_for<KS>([&](auto ks) { owned_write4<OWNED, QF0 + 4 * ks.value>(tq[ks.value]); });
+        static_for<KS>([&](auto ks) { owned_write4<OWNED, OF0 + 4 * ks.value>(to[ks.value]); });
+    }
+    const float lse2 = qvalid ? lse[((int64_t)b * Hq + hq) * S + qg] * LOG2E : 0.f;
+    const float dlt = qvalid ? delta[((int64_t)b * Hq + hq) * S + qg] : 0.f;
+    const LaneOff<D> lo = lane_offsets<D>(lane);
+    uint8_t mk = (key_mask && lane < S) ? key_mask[(int64_t)b * S + lane] : (uint8_t)0;  // one tile ahead, as in the forward
     for (int kt = 0; kt < ntiles; ++kt) {
         __syncthreads();
-        if (kt + 1 < ntiles) issue(kt + 1, (kt + 1) & 1);
+        if (kt + 1 < ntiles && !(abl & 1)) issue(kt + 1, (kt + 1) & 1);
         const int kroff = (kt & 1) * 3 * C::TILE, ktoff = kroff + C::TILE, vroff = kroff + 2 * C::TILE;
         unsigned long long kbits = ~0ull;
         if (key_mask) {
-            const int kg = kt * 64 + lane;
-            kbits = __ballot(kg < S && key_mask[(int64_t)b * S + kg] != 0);
+            kbits = __ballot(mk != 0);
+            const int kn = (kt + 1) * 64 + lane;
+            mk = kn < S ? key_mask[(int64_t)b * S + kn] : (uint8_t)0;
         }
         const bool wave_active = !causal || (kt * 64 <= q0 + wave * 32 + 31);
         if (!wave_active) continue;
         const bool boundary = (kbits != ~0ull) || (kt * 64 + 64 > S) || (causal && kt * 64 + 63 > q0 + wave * 32);
-        int vkx[C::KS], vvx[C::KS], vkt[C::DT];
+        int vkx[KS], vvx[KS], vkt[DT];
 #pragma unroll
-        for (int ks = 0; ks < C::KS; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             vkx[ks] = (lo.row + kroff) ^ (ks << 5);
             vvx[ks] = (lo.row + vroff) ^ (ks << 5);
         }
 #pragma unroll
-        for (int dt = 0; dt < C::DT; ++dt) vkt[dt] = lo.col[dt] + ktoff;
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            f32x16 sacc, pacc;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { sacc[e] = 0.f; pacc[e] = 0.f; }
-#pragma unroll
-            for (int ks = 0; ks < C::KS; ++ks) {
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(smem, vkx[ks], st * 32 * C::ROWB), qf[ks], sacc, 0, 0, 0);
-                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(smem, vvx[ks], st * 32 * C::ROWB), dof[ks], pacc, 0, 0, 0);
-            }
-            if (boundary) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
+        for (int dt = 0; dt < DT; ++dt) vkt[dt] = lo.col[dt] + ktoff;
+
+        auto tile_body = [&](auto bc) {
+            constexpr bool BOUNDARY = decltype(bc)::value;
+            bf16x8 f[RING] = {};
+            f32x16 sacc[2], pacc[2];
+            unsigned dsw[2][8] = {};  // packed dS^T: words 4s..4s+3 of sub-tile st are the B operand of k-step s
+            float dsv[16];
+            auto load = [&](auto gc) {
+                constexpr int g = gc.value;
+                if constexpr (ATTN_ABL & 1) return;
+                if constexpr (g < 2 * NA) {
+                    constexpr int st = g / NA, ks = (g % NA) / 2, which = g % 2;
+                    f[g % RING] = lds_frag(smem, which ? vvx[ks] : vkx[ks], st * 32 * C::ROWB);
+                } else if constexpr (g < NG) {
+                    constexpr int h = g - 2 * NA, st = h / NC, sd = (h % NC) / DT, dt = h % DT;
+                    f[g % RING] = lds_frag_tr<D>(smem, vkt[dt], (st * 32 + 16 * sd) * C::ROWB);
+                }
+            };
+            auto element = [&](auto stc, auto ec) {
+                constexpr int st = stc.value, e = ec.value;
+                if constexpr (ATTN_ABL & 2) return;
+                float p;
+                if constexpr (BOUNDARY) {
                     const int kl = st * 32 + acc_row(e, lane);
                     const int kg = kt * 64 + kl;
                     const bool masked = (causal && kg > qg) || !((kbits >> kl) & 1ull) || kg >= S;
-                    const float p = masked ? 0.f : __builtin_amdgcn_exp2f(fmaf(sacc[e], scale_log2, -lse2));
-                    sacc[e] = p * (pacc[e] - dlt) * scale;  // dS^T (gradient w.r.t. the raw QK^T product)
+                    p = masked ? 0.f : __builtin_amdgcn_exp2f(fmaf(sacc[st][e], scale_log2, -lse2));
+                } else {
+                    p = __builtin_amdgcn_exp2f(fmaf(sacc[st][e], scale_log2, -lse2));
                 }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(sacc[e], scale_log2, -lse2));
-                    sacc[e] = p * (pacc[e] - dlt) * scale;
+                dsv[e] = p * (pacc[st][e] - dlt) * scale;  // dS^T (gradient w.r.t. the raw QK^T product)
+                if constexpr (e % 2 == 1) dsw[st][e / 2] = pack_bf2(dsv[e - 1], dsv[e]);
+            };
+            static_for<PD>([&](auto g) { load(g); });
+            static_for<NG>([&](auto gc) {
+                constexpr int g = gc.value;
+                load(std::integral_constant<int, g + PD>{});
+                if constexpr (g < 2 * NA) {
+                    constexpr int st = g / NA, ks = (g % NA) / 2, which = g % 2;
+                    if constexpr ((ATTN_ABL & 8) && ks > 0) {
+                    } else if constexpr (which == 0) mfma_ownedB<OWNED, QF0 + 4 * ks, ks == 0>(sacc[st], f[g % RING]);
+                    else mfma_ownedB<OWNED, OF0 + 4 * ks, ks == 0>(pacc[st], f[g % RING]);
+                } else if constexpr (!(ATTN_ABL & 4)) {
+                    constexpr int h = g - 2 * NA, st = h / NC, sd = (h % NC) / DT, dt = h % DT;
+                    const u32x4 w = {dsw[st][4 * sd], dsw[st][4 * sd + 1], dsw[st][4 * sd + 2], dsw[st][4 * sd + 3]};
+                    mfma_owned<OWNED, 16 * dt>(f[g % RING], __builtin_bit_cast(bf16x8, w));
                 }
-            }
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 dsf = pack_frag(sacc, s);
-#pragma unroll
-                for (int dt = 0; dt < C::DT; ++dt)
-                    dqacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr<D>(smem, vkt[dt], (st * 32 + 16 * s) * C::ROWB), dsf, dqacc[dt], 0, 0, 0);
-            }
-        }
+                // B(0) rides on the MFMAs of A(1), B(1) on those of C(0)
+                if constexpr (g == NA) tiles_settle(sacc[0], pacc[0]);
+                if constexpr (g == 2 * NA) tiles_settle(sacc[1], pacc[1]);
+                if constexpr (g >= NA && g < 2 * NA) {
+                    constexpr int m = g - NA, per = 16 / NA;
+                    static_for<per>([&](auto i) { element(std::integral_constant<int, 0>{}, std::integral_constant<int, m * per + i.value>{}); });
+                } else if constexpr (g >= 2 * NA && g < 2 * NA + NC) {
+                    constexpr int m = g - 2 * NA, per = 16 / NC;
+                    static_for<per>([&](auto i) { element(std::integral_constant<int, 1>{}, std::integral_constant<int, m * per + i.value>{}); });
+                }
+            });
+        };
+        if (boundary) tile_body(std::true_type{});
+        else tile_body(std::false_type{});
     }
-    if (qvalid) {
-        bf16_t* row = dq + ((int64_t)b * S + qg) * lddq + (int64_t)hq * D;
-#pragma unroll
-        for (int dt = 0; dt < C::DT; ++dt)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int d = dt * 32 + 8 * g4 + 4 * (lane >> 5);
-                u32x2 pk = {pack_bf2(dqacc[dt][4 * g4], dqacc[dt][4 * g4 + 1]), pack_bf2(dqacc[dt][4 * g4 + 2], dqacc[dt][4 * g4 + 3])};
-                *reinterpret_cast<u32x2*>(row + d) = pk;
-            }
-    }
+    owned_settle<OWNED>();
+    bf16_t* row = dq + ((int64_t)b * S + qg) * lddq + (int64_t)hq * D;
+    static_for<DT * 4>([&](auto i) {
+        constexpr int dt = i.value / 4, g4 = i.value % 4, r = 16 * dt + 4 * g4;
+        const int d = dt * 32 + 8 * g4 + 4 * (lane >> 5);
+        const u32x2 pk = {pack_bf2(owned_read<OWNED, r>(), owned_read<OWNED, r + 1>()), pack_bf2(owned_read<OWNED, r + 2>(), owned_read<OWNED, r + 3>())};
+        if (qvalid) *reinterpret_cast<u32x2*>(row + d) = pk;
+    });
 }
 
 // ---- dK/dV pass: KEY on the lane.  One workgroup = 128 keys of one (batch, kv head); each wave owns 32 keys and keeps
-// dK^T, dV^T for them in accumulators while the workgroup sweeps the group's query heads x 64-query tiles:
-//   S = Q K^T (A = Q rows from LDS, B = K rows held in registers), dP = dO V^T (A = dO rows, B = V rows in registers),
-//   P = exp2(S*c - lse2[q]) (row constants come from LDS), dS = P*(dP - delta[q])*scale,
-//   dV^T += dO^T P  and  dK^T += Q^T dS   (A = transposed reads of the dO / Q tile, B = the accumulator tiles of P / dS).
+// dK^T, dV^T for them in (owned) accumulators while the workgroup sweeps the group's query heads x 64-query tiles.  Per
+// 32-query sub-tile st:
+//   A(st):  S = Q K^T ;  dP = dO V^T                (A operand: Q / dO rows from LDS, B operand: K / V rows, owned AGPRs)
+//   B(st):  P = exp2(S*c - lse2[q]) ;  dS = P*(dP - delta[q])*scale                      (row constants come from LDS)
+//   C(st):  dV^T += dO^T P ;  dK^T += Q^T dS        (A operand: transposed reads of the dO / Q tile, B: packed P / dS)
+// Same schedule as the dQ pass: MFMAs in the order A(0) A(1) C(0) C(1), B(0) under A(1), B(1) under C(0), reads PD ahead.
 template <int D>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int Hq, int Hkv, const bf16_t* __restrict__ q, int64_t ldq,
                                                               const bf16_t* __restrict__ k, int64_t ldk, const bf16_t* __restrict__ v,
@@ -446,6 +565,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
                                                               bf16_t* __restrict__ dk, int64_t lddk, bf16_t* __restrict__ dv, int64_t lddv,
                                                               const uint8_t* __restrict__ key_mask, int causal, float scale, float scale_log2) {
     using C = Cfg<D>;
+    constexpr int KS = C::KS, DT = C::DT;
+    constexpr int NA = 2 * KS, NC = 4 * DT, NG = 2 * NA + 2 * NC;
+    constexpr int OWNED = 32 * DT + 8 * KS, DK0 = 16 * DT, KF0 = 32 * DT, VF0 = KF0 + 4 * KS;  // dV^T | dK^T | K rows | V rows
+    constexpr int RING = 8, PD = 6;
+    const int abl = causal >> 8;  // profiling only: 1 = no DMA after the first tile
+    causal &= 0xff;
     // 2 stages x (Q row, Q tr, dO row, dO tr) + 2 stages x 64 x (lse2, delta)
     __shared__ __attribute__((aligned(16))) char smem[8 * C::TILE + 2 * 64 * 8];
     float* rowc = reinterpret_cast<float*>(smem + 8 * C::TILE);
@@ -460,16 +585,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
     const int kg = k0 + wave * 32 + (lane & 31);
     const bool kvalid = kg < S;
     const bool kreal = kvalid && (key_mask == nullptr || key_mask[(int64_t)b * S + kg] != 0);
-
-    bf16x8 kf[C::KS], vf[C::KS];
-    load_rows_frag<D>(k + (int64_t)b * S * ldk + (int64_t)hkv * D, ldk, kg, kvalid, lane, kf);
-    load_rows_frag<D>(v + (int64_t)b * S * ldv + (int64_t)hkv * D, ldv, kg, kvalid, lane, vf);
-
-    f32x16 dkacc[C::DT], dvacc[C::DT];
-#pragma unroll
-    for (int i = 0; i < C::DT; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { dkacc[i][e] = 0.f; dvacc[i][e] = 0.f; }
 
     const int nqt_all = (S + 63) / 64;
     const int qt0 = causal ? k0 / 64 : 0;  // first query tile that can see any key of this block
@@ -486,99 +601,143 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
         dma_tile<D, true>(qb_, ldq, S - qt * 64, st_ + C::TILE, wave, lane);
         dma_tile<D, false>(ob_, lddo, S - qt * 64, st_ + 2 * C::TILE, wave, lane);
         dma_tile<D, true>(ob_, lddo, S - qt * 64, st_ + 3 * C::TILE, wave, lane);
-        if (threadIdx.x < 64) {
-            const int qq = qt * 64 + threadIdx.x;
-            const int64_t idx = ((int64_t)b * Hq + hq) * S + qq;
-            rowc[stage * 128 + threadIdx.x] = qq < S ? lse[idx] * LOG2E : 0.f;
-            rowc[stage * 128 + 64 + threadIdx.x] = qq < S ? delta[idx] : 0.f;
+        if (wave < 2) {  // the tile's 64 lse (wave 0) / delta (wave 1) values: one 4-byte-per-lane DMA piece, rows >= S read 0
+            const float* src = (wave == 0 ? lse : delta) + ((int64_t)b * Hq + hq) * S + (int64_t)qt * 64;
+            auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 0x7fffffff, 0x00020000);
+            const unsigned voff = qt * 64 + lane < S ? (unsigned)(lane * 4) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(reinterpret_cast<char*>(rowc) + stage * 512 + wave * 256), 4, voff, 0, 0, 0);
         }
     };
 
     const LaneOff<D> lo = lane_offsets<D>(lane);
-    if (nit > 0) issue(0, 0);
+    if (nit > 0) issue(0, 0);  // first tile first, then the row operands: their latencies overlap
+    {
+        bf16x8 tk[KS], tv[KS];
+        load_rows_frag<D>(k + (int64_t)b * S * ldk + (int64_t)hkv * D, ldk, kg, kvalid, lane, tk);
+        load_rows_frag<D>(v + (int64_t)b * S * ldv + (int64_t)hkv * D, ldv, kg, kvalid, lane, tv);
+        owned_zero<OWNED, 0, 32 * DT>();
+        static_for<KS>([&](auto ks) { owned_write4<OWNED, KF0 + 4 * ks.value>(tk[ks.value]); });
+        static_for<KS>([&](auto ks) { owned_write4<OWNED, VF0 + 4 * ks.value>(tv[ks.value]); });
+    }
     for (int it = 0; it < nit; ++it) {
         __syncthreads();
-        if (it + 1 < nit) issue(it + 1, (it + 1) & 1);
+        if (it + 1 < nit && !(abl & 1)) issue(it + 1, (it + 1) & 1);
         const int qt = qt0 + it % per_head;
         const int qroff = (it & 1) * 4 * C::TILE, qtoff = qroff + C::TILE, oroff = qroff + 2 * C::TILE, otoff = qroff + 3 * C::TILE;
-        const float* rc = rowc + (it & 1) * 128;
+        const float* rc = rowc + (it & 1) * 128 + 4 * (lane >> 5);
         // queries of this tile all precede this wave's keys -> nothing visible
         if (causal && qt * 64 + 63 < k0 + wave * 32) continue;
         // masks only where the tile touches the diagonal, the sequence end, or this wave holds padded / out-of-range keys
         const bool boundary = (causal && qt * 64 < k0 + wave * 32 + 31) || (qt * 64 + 64 > S) || __any(!kreal);
-        int vqx[C::KS], vox[C::KS], vqt[C::DT], vot[C::DT];
+        int vqx[KS], vox[KS], vqt[DT], vot[DT];
 #pragma unroll
-        for (int ks = 0; ks < C::KS; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             vqx[ks] = (lo.row + qroff) ^ (ks << 5);
             vox[ks] = (lo.row + oroff) ^ (ks << 5);
         }
 #pragma unroll
-        for (int dt = 0; dt < C::DT; ++dt) {
+        for (int dt = 0; dt < DT; ++dt) {
             vqt[dt] = lo.col[dt] + qtoff;
             vot[dt] = lo.col[dt] + otoff;
         }
+
+        auto tile_body = [&](auto bc) {
+            constexpr bool BOUNDARY = decltype(bc)::value;
+            bf16x8 f[RING] = {};
+            f32x16 sacc[2], pacc[2];
+            unsigned pw[2][8] = {}, dsw[2][8] = {};  // packed P / dS: words 4s..4s+3 of sub-tile st are the B operand of k-step s
+            float pv[16], dsv[16], l2r[16], dlr[16];
+            auto load = [&](auto gc) {
+                constexpr int g = gc.value;
+                if constexpr (ATTN_ABL & 1) return;
+                if constexpr (g < 2 * NA) {
+                    constexpr int st = g / NA, ks = (g % NA) / 2, which = g % 2;
+                    f[g % RING] = lds_frag(smem, which ? vox[ks] : vqx[ks], st * 32 * C::ROWB);
+                } else if constexpr (g < NG) {
+                    constexpr int h = g - 2 * NA, st = h / NC, sd = (h % NC) / (2 * DT), dt = (h % (2 * DT)) / 2, which = h % 2;
+                    f[g % RING] = lds_frag_tr<D>(smem, which ? vqt[dt] : vot[dt], (st * 32 + 16 * sd) * C::ROWB);
+                }
+            };
+            // per-query constants of the 16 accumulator rows of sub-tile st: rows 8*g4 + 4*h + 0..3
+            auto row_constants = [&](auto stc) {
+                constexpr int st = stc.value;
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            f32x16 sacc, pacc;
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(rc + st * 32 + 8 * g4);
+                    const f32x4 c = *reinterpret_cast<const f32x4*>(rc + 64 + st * 32 + 8 * g4);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { sacc[e] = 0.f; pacc[e] = 0.f; }
-#pragma unroll
-            for (int ks = 0; ks < C::KS; ++ks) {
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(smem, vqx[ks], st * 32 * C::ROWB), kf[ks], sacc, 0, 0, 0);
-                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(smem, vox[ks], st * 32 * C::ROWB), vf[ks], pacc, 0, 0, 0);
-            }
-            // per-query constants of the 16 accumulator rows: 4 x 16-byte LDS reads each (rows 8*g4 + 4*h + 0..3)
-            float l2r[16], dlr[16];
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(rc + st * 32 + 8 * g4 + 4 * (lane >> 5));
-                const f32x4 c = *reinterpret_cast<const f32x4*>(rc + 64 + st * 32 + 8 * g4 + 4 * (lane >> 5));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { l2r[4 * g4 + e] = a[e]; dlr[4 * g4 + e] = c[e]; }
-            }
-            if (boundary) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
+                    for (int e = 0; e < 4; ++e) { l2r[4 * g4 + e] = a[e] * LOG2E; dlr[4 * g4 + e] = c[e]; }
+                }
+            };
+            auto element = [&](auto stc, auto ec) {
+                constexpr int st = stc.value, e = ec.value;
+                if constexpr (ATTN_ABL & 2) return;
+                float p;
+                if constexpr (BOUNDARY) {
                     const int qq = qt * 64 + st * 32 + acc_row(e, lane);
                     const bool masked = (causal && kg > qq) || !kreal || qq >= S;
-                    const float p = masked ? 0.f : __builtin_amdgcn_exp2f(fmaf(sacc[e], scale_log2, -l2r[e]));
-                    sacc[e] = p;
-                    pacc[e] = p * (pacc[e] - dlr[e]) * scale;
+                    p = masked ? 0.f : __builtin_amdgcn_exp2f(fmaf(sacc[st][e], scale_log2, -l2r[e]));
+                } else {
+                    p = __builtin_amdgcn_exp2f(fmaf(sacc[st][e], scale_log2, -l2r[e]));
                 }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(sacc[e], scale_log2, -l2r[e]));
-                    sacc[e] = p;
-                    pacc[e] = p * (pacc[e] - dlr[e]) * scale;
+                pv[e] = p;
+                dsv[e] = p * (pacc[st][e] - dlr[e]) * scale;
+                if constexpr (e % 2 == 1) {
+                    pw[st][e / 2] = pack_bf2(pv[e - 1], pv[e]);
+                    dsw[st][e / 2] = pack_bf2(dsv[e - 1], dsv[e]);
                 }
-            }
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 pf = pack_frag(sacc, s);
-                const bf16x8 dsf = pack_frag(pacc, s);
-#pragma unroll
-                for (int dt = 0; dt < C::DT; ++dt) {
-                    dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr<D>(smem, vot[dt], (st * 32 + 16 * s) * C::ROWB), pf, dvacc[dt], 0, 0, 0);
-                    dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr<D>(smem, vqt[dt], (st * 32 + 16 * s) * C::ROWB), dsf, dkacc[dt], 0, 0, 0);
+            };
+            static_for<PD>([&](auto g) { load(g); });
+            static_for<NG>([&](auto gc) {
+                constexpr int g = gc.value;
+                if constexpr (g == NA - 1) row_constants(std::integral_constant<int, 0>{});
+                load(std::integral_constant<int, g + PD>{});
+                if constexpr (g < 2 * NA) {
+                    constexpr int st = g / NA, ks = (g % NA) / 2, which = g % 2;
+                    if constexpr ((ATTN_ABL & 8) && ks > 0) {
+                    } else if constexpr (which == 0) mfma_ownedB<OWNED, KF0 + 4 * ks, ks == 0>(sacc[st], f[g % RING]);
+                    else mfma_ownedB<OWNED, VF0 + 4 * ks, ks == 0>(pacc[st], f[g % RING]);
+                } else if constexpr (!(ATTN_ABL & 4)) {
+                    constexpr int h = g - 2 * NA, st = h / NC, sd = (h % NC) / (2 * DT), dt = (h % (2 * DT)) / 2, which = h % 2;
+                    if constexpr (which == 0) {
+                        const u32x4 w = {pw[st][4 * sd], pw[st][4 * sd + 1], pw[st][4 * sd + 2], pw[st][4 * sd + 3]};
+                        mfma_owned<OWNED, 16 * dt>(f[g % RING], __builtin_bit_cast(bf16x8, w));
+                    } else {
+                        const u32x4 w = {dsw[st][4 * sd], dsw[st][4 * sd + 1], dsw[st][4 * sd + 2], dsw[st][4 * sd + 3]};
+                        mfma_owned<OWNED, DK0 + 16 * dt>(f[g % RING], __builtin_bit_cast(bf16x8, w));
+                    }
                 }
-            }
+                // B(0) rides on the MFMAs of A(1), B(1) on those of C(0)
+                if constexpr (g == NA) tiles_settle(sacc[0], pacc[0]);
+                if constexpr (g == 2 * NA) tiles_settle(sacc[1], pacc[1]);
+                if constexpr (g >= NA && g < 2 * NA) {
+                    constexpr int m = g - NA, per = 16 / NA;
+                    static_for<per>([&](auto i) { element(std::integral_constant<int, 0>{}, std::integral_constant<int, m * per + i.value>{}); });
+                    if constexpr (g == 2 * NA - 1) row_constants(std::integral_constant<int, 1>{});
+                } else if constexpr (g >= 2 * NA && g < 2 * NA + NC) {
+                    constexpr int m = g - 2 * NA, per = (16 + NC - 1) / NC;
+                    static_for<per>([&](auto i) {
+                        if constexpr (m * per + i.value < 16) element(std::integral_constant<int, 1>{}, std::integral_constant<int, m * per + i.value>{});
+                    });
+                }
+            });
+        };
+        if (boundary) tile_body(std::true_type{});
+        else tile_body(std::false_type{});
+    }
+    owned_settle<OWNED>();
+    bf16_t* krow = dk + ((int64_t)b * S + kg) * lddk + (int64_t)hkv * D;
+    bf16_t* vrow = dv + ((int64_t)b * S + kg) * lddv + (int64_t)hkv * D;
+    static_for<DT * 4>([&](auto i) {
+        constexpr int dt = i.value / 4, g4 = i.value % 4, rv = 16 * dt + 4 * g4, rk = DK0 + rv;
+        const int d = dt * 32 + 8 * g4 + 4 * (lane >> 5);
+        const u32x2 a = {pack_bf2(owned_read<OWNED, rk>(), owned_read<OWNED, rk + 1>()), pack_bf2(owned_read<OWNED, rk + 2>(), owned_read<OWNED, rk + 3>())};
+        const u32x2 c = {pack_bf2(owned_read<OWNED, rv>(), owned_read<OWNED, rv + 1>()), pack_bf2(owned_read<OWNED, rv + 2>(), owned_read<OWNED, rv + 3>())};
+        if (kvalid) {
+            *reinterpret_cast<u32x2*>(krow + d) = a;
+            *reinterpret_cast<u32x2*>(vrow + d) = c;
         }
-    }
-    if (kvalid) {
-        bf16_t* krow = dk + ((int64_t)b * S + kg) * lddk + (int64_t)hkv * D;
-        bf16_t* vrow = dv + ((int64_t)b * S + kg) * lddv + (int64_t)hkv * D;
-#pragma unroll
-        for (int dt = 0; dt < C::DT; ++dt)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int d = dt * 32 + 8 * g4 + 4 * (lane >> 5);
-                u32x2 a = {pack_bf2(dkacc[dt][4 * g4], dkacc[dt][4 * g4 + 1]), pack_bf2(dkacc[dt][4 * g4 + 2], dkacc[dt][4 * g4 + 3])};
-                u32x2 c = {pack_bf2(dvacc[dt][4 * g4], dvacc[dt][4 * g4 + 1]), pack_bf2(dvacc[dt][4 * g4 + 2], dvacc[dt][4 * g4 + 3])};
-                *reinterpret_cast<u32x2*>(krow + d) = a;
-                *reinterpret_cast<u32x2*>(vrow + d) = c;
-            }
-    }
+    });
 }
 
 int check_common(const char* name, int B, int S, int Hq, int Hkv, int D) {

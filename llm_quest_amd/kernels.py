@@ -208,6 +208,9 @@ def _check_attn_operand(t, name, tokens, width):
         raise ValueError(f"attention: {name} must be bf16 [tokens={tokens}, {width}] with unit inner stride, got {tuple(t.shape)} {t.stride()}")
 
 
+_ATTN_ABLATE = int(os.environ.get("MI355_ATTN_ABLATE", "0")) << 8  # profiling switches of attention.hip
+
+
 def attn_fwd(q, k, v, B, S, Hq, Hkv, D, key_mask=None, causal=True, scale=None):
     """q [B*S,Hq*D], k/v [B*S,Hkv*D] (row-strided views allowed).  Returns (o [B*S,Hq*D], lse fp32 [B,Hq,S])."""
     L.require_gpu(q, k, v, key_mask)
@@ -219,7 +222,7 @@ def attn_fwd(q, k, v, B, S, Hq, Hkv, D, key_mask=None, causal=True, scale=None):
     o = torch.empty((B * S, Hq * D), dtype=BF16, device=q.device)
     lse = torch.empty((B, Hq, S), dtype=F32, device=q.device)
     scale = D ** -0.5 if scale is None else scale
-    L.call("mi355_attn_fwd", B, S, Hq, Hkv, D, L.ptr(q), q.stride(0), L.ptr(k), k.stride(0), L.ptr(v), v.stride(0), L.ptr(o), o.stride(0), L.ptr(lse), L.ptr(key_mask), int(causal), scale)
+    L.call("mi355_attn_fwd", B, S, Hq, Hkv, D, L.ptr(q), q.stride(0), L.ptr(k), k.stride(0), L.ptr(v), v.stride(0), L.ptr(o), o.stride(0), L.ptr(lse), L.ptr(key_mask), int(causal) | _ATTN_ABLATE, scale)
     return o, lse
 
 
@@ -235,7 +238,7 @@ def attn_bwd(q, k, v, o, do, lse, B, S, Hq, Hkv, D, dq, dk, dv, key_mask=None, c
     L.call(
         "mi355_attn_bwd", B, S, Hq, Hkv, D, L.ptr(q), q.stride(0), L.ptr(k), k.stride(0), L.ptr(v), v.stride(0), L.ptr(o), o.stride(0),
         L.ptr(do), do.stride(0), L.ptr(lse), L.ptr(delta), L.ptr(dq), dq.stride(0), L.ptr(dk), dk.stride(0), L.ptr(dv), dv.stride(0),
-        L.ptr(key_mask), int(causal), scale,
+        L.ptr(key_mask), int(causal) | _ATTN_ABLATE, scale,
     )
 
 
