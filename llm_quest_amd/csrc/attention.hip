@@ -21,6 +21,7 @@ constexpr float MASK_T = -2.0e38f;  // finite "masked" score in the log2 domain
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr unsigned OOB = 0x80000000u;
+constexpr int ATTN_MAX_TILES = 512;  // key-mask words kept in LDS by the backward dQ pass: S <= 64 * 512
 
 template <int D>
 struct Cfg {
@@ -31,14 +32,22 @@ struct Cfg {
     static constexpr int TILE = 64 * ROWB;        // bytes of one 64-key tile
     static constexpr int RPP = 1024 / ROWB;       // rows per 1-KiB DMA piece
     static constexpr int PPW = TILE / 1024 / 4;   // pieces per wave per tile
+    // D = 128: ONE image serves both the row reads and the transposing reads of the backward kernels (half the LDS-DMA)
+    static constexpr bool UNI = (D == 128);
 };
 
 // swizzles (chunk index XOR) -- row-read image (32x32 A-operand pattern) and transposed-read image
 template <int D> __device__ __forceinline__ int swz_row(int chunk, int row) { return D == 128 ? chunk ^ (row & 15) : chunk ^ ((row >> 1) & 7); }
 template <int D> __device__ __forceinline__ int swz_tr(int chunk, int row) { return D == 128 ? chunk ^ ((row & 3) << 2) : chunk ^ (((row >> 1) & 1) << 2); }
 
-// DMA one 64-row tile (rows = tokens tok0.., D contiguous elements at column col0) into LDS; TRIMG picks the swizzle
-template <int D, bool TRIMG>
+// unified image (256-byte rows = one bank row, 16 chunks): chunk ^ f(row) with f = the two 2-bit fields of row&15 swapped.
+// f is a bijection over any 16 aligned rows (ds_read_b128 of 16 lanes = 16 rows at one chunk: 16 distinct slots), and its
+// high field follows row&3 (a transposing read's 16 lanes = 4 consecutive rows x 2 adjacent chunks x 2 halves: 8 distinct slots).
+__device__ __forceinline__ int swz_uni(int chunk, int row) { return chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)); }
+constexpr int IMG_ROW = 0, IMG_TR = 1, IMG_UNI = 2;
+
+// DMA one 64-row tile (rows = tokens tok0.., D contiguous elements at column col0) into LDS; IMG picks the swizzle
+template <int D, int IMG>
 __device__ __forceinline__ void dma_tile(const bf16_t* base, int64_t ld, int rows_valid, char* lds, int wave, int lane) {
     using C = Cfg<D>;
     auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base), 0, 0x7fffffff, 0x00020000);
@@ -47,7 +56,7 @@ __device__ __forceinline__ void dma_tile(const bf16_t* base, int64_t ld, int row
         const int pi = wave * C::PPW + j;
         const int row = pi * C::RPP + lane / C::CH;
         const int pos = lane % C::CH;
-        const int c = TRIMG ? swz_tr<D>(pos, row) : swz_row<D>(pos, row);
+        const int c = IMG == IMG_UNI ? swz_uni(pos, row) : IMG == IMG_TR ? swz_tr<D>(pos, row) : swz_row<D>(pos, row);
         const unsigned voff = row < rows_valid ? (unsigned)(row * ld * 2 + c * 16) : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds + pi * 1024), 16, voff, 0, 0, 0);
     }
@@ -87,6 +96,8 @@ template <int D>
 struct LaneOff {
     int row;
     int col[Cfg<D>::DT];
+    int rowu;               // unified image (D = 128 only)
+    int colu[Cfg<D>::DT];
 };
 template <int D>
 __device__ __forceinline__ LaneOff<D> lane_offsets(int lane) {
@@ -100,6 +111,11 @@ __device__ __forceinline__ LaneOff<D> lane_offsets(int lane) {
     const int base = (4 * (g >> 1) + q4) * C::ROWB + ((2 * (g & 1) + (p >> 1)) << 4) + (p & 1) * 8;
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) o.col[dt] = base + ((dt ^ x) << 6);
+    // unified image: row r -> chunk ^ ((r&3)<<2 | (r>>2)&3); a transposing read touches rows 4*(g>>1) + q4 (+8: low field ^ 2)
+    o.rowu = r * C::ROWB + ((h ^ (((r & 3) << 2) | ((r >> 2) & 3))) << 4);
+    const int baseu = (4 * (g >> 1) + q4) * C::ROWB + (((2 * (g & 1) + (p >> 1)) ^ (g >> 1)) << 4) + (p & 1) * 8;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) o.colu[dt] = baseu + ((dt ^ q4) << 6);
     return o;
 }
 // row-image fragment: vx = (lane_row + image_offset) ^ (ks << 5), imm = r0 * ROWB
@@ -115,6 +131,22 @@ __device__ __forceinline__ bf16x8 lds_frag_tr(const char* smem, int v, int imm) 
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return r;
 }
+
+// unified-image transposed fragment: v = lane_colu[dt] + image_offset, imm = k0 * ROWB (k0 a multiple of 16); the rows of
+// the second read are 8 further down, where the low swizzle field differs by 2 (byte bit 5)
+template <int D>
+__device__ __forceinline__ bf16x8 lds_frag_tr_uni(const char* smem, int v, int imm) {
+    const char* a = smem + v + imm;
+    const char* a2 = smem + (v ^ 0x20) + imm + 8 * Cfg<D>::ROWB;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a2));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // pack accumulator registers 8s..8s+7 to a bf16 B-operand fragment
 __device__ __forceinline__ bf16x8 pack_frag(const f32x16& x, int s) {
@@ -249,8 +281,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int B, int S, int Hq, 
 
     auto issue = [&](int kt, int stage) {
         char* ks_ = smem + stage * 2 * C::TILE;
-        dma_tile<D, false>(kbase + (int64_t)kt * 64 * ldk, ldk, S - kt * 64, ks_, wave, lane);
-        dma_tile<D, true>(vbase + (int64_t)kt * 64 * ldv, ldv, S - kt * 64, ks_ + C::TILE, wave, lane);
+        dma_tile<D, IMG_ROW>(kbase + (int64_t)kt * 64 * ldk, ldk, S - kt * 64, ks_, wave, lane);
+        dma_tile<D, IMG_TR>(vbase + (int64_t)kt * 64 * ldv, ldv, S - kt * 64, ks_ + C::TILE, wave, lane);
     };
 
     const LaneOff<D> lo = lane_offsets<D>(lane);
@@ -411,143 +443,174 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(int B, int S, int H
                                                              int64_t ldv, const bf16_t* __restrict__ d_o, int64_t lddo,
                                                              const float* __restrict__ lse, const float* __restrict__ delta,
                                                              bf16_t* __restrict__ dq, int64_t lddq, const uint8_t* __restrict__ key_mask,
-                                                             int causal, float scale, float scale_log2) {
+                                                             int causal, float scale, float scale_log2, int bpw) {
     using C = Cfg<D>;
     constexpr int KS = C::KS, DT = C::DT;
     constexpr int NA = 2 * KS, NC = 2 * DT, NG = 2 * NA + 2 * NC;  // MFMAs of one A part, one C part, one key tile
     constexpr int OWNED = 16 * DT + 8 * KS, QF0 = 16 * DT, OF0 = QF0 + 4 * KS;  // dQ^T tiles | Q rows | dO rows
     constexpr int RING = 8, PD = 6;
-    const int abl = causal >> 8;  // profiling only: 1 = no DMA after the first tile
+    // LDS: NST stages x (K [unified] | V rows)  or, D = 64,  (K rows | K transposed | V rows);  then the key-mask words
+    constexpr bool UNI = C::UNI;
+    constexpr int NIMG = UNI ? 2 : 3, NST = 3, STAGE = NIMG * C::TILE, PIECES = NIMG * C::PPW, VIMG = (NIMG - 1) * C::TILE;
+    const int abl = causal >> 8;  // profiling only: 1 = no DMA after the first tiles
     causal &= 0xff;
-    __shared__ __attribute__((aligned(16))) char smem[6 * C::TILE];  // 2 stages x (K row, K tr, V row)
+    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE + ATTN_MAX_TILES * 8];
+    unsigned long long* kmw = reinterpret_cast<unsigned long long*>(smem + NST * STAGE);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nqb = (S + 127) / 128;
-    const int qb = nqb - 1 - (int)(blockIdx.x % nqb);
-    const int bh = blockIdx.x / nqb;
+    // one workgroup = `bpw` consecutive 128-query blocks of one (batch, head), heaviest (latest) first
+    const int nqb = (S + 127) / 128, nchunk = (nqb + bpw - 1) / bpw;
+    const int chunk = blockIdx.x % nchunk, bh = blockIdx.x / nchunk;
     const int hq = bh % Hq, b = bh / Hq;
     const int hkv = hq / (Hq / Hkv);
-    const int q0 = qb * 128;
-    const int qg = q0 + wave * 32 + (lane & 31);
-    const bool qvalid = qg < S;
-
+    const int qb_hi = nqb - chunk * bpw, qb_lo = max(0, qb_hi - bpw);
+    const int ntiles_all = (S + 63) / 64;
+    auto tiles_of = [&](int qb) { return causal ? min(ntiles_all, (qb * 128 + 127) / 64 + 1) : ntiles_all; };
     const bf16_t* kbase = k + (int64_t)b * S * ldk + (int64_t)hkv * D;
     const bf16_t* vbase = v + (int64_t)b * S * ldv + (int64_t)hkv * D;
-    const int ntiles_all = (S + 63) / 64;
-    const int ntiles = causal ? min(ntiles_all, (q0 + 127) / 64 + 1) : ntiles_all;
 
-    auto issue = [&](int kt, int stage) {
-        char* st_ = smem + stage * 3 * C::TILE;
-        dma_tile<D, false>(kbase + (int64_t)kt * 64 * ldk, ldk, S - kt * 64, st_, wave, lane);
-        dma_tile<D, true>(kbase + (int64_t)kt * 64 * ldk, ldk, S - kt * 64, st_ + C::TILE, wave, lane);
-        dma_tile<D, false>(vbase + (int64_t)kt * 64 * ldv, ldv, S - kt * 64, st_ + 2 * C::TILE, wave, lane);
+    // ---- K/V tile stream over (block, tile), NST-deep: the tile two ahead is in flight while one is being consumed
+    int iqb = qb_hi - 1, ikt = 0, istage = 0;
+    auto issue_next = [&]() -> bool {
+        if (iqb < qb_lo) return false;
+        char* st_ = smem + istage * STAGE;
+        const bf16_t* kp = kbase + (int64_t)ikt * 64 * ldk;
+        if constexpr (UNI) {
+            dma_tile<D, IMG_UNI>(kp, ldk, S - ikt * 64, st_, wave, lane);
+        } else {
+            dma_tile<D, IMG_ROW>(kp, ldk, S - ikt * 64, st_, wave, lane);
+            dma_tile<D, IMG_TR>(kp, ldk, S - ikt * 64, st_ + C::TILE, wave, lane);
+        }
+        dma_tile<D, IMG_ROW>(vbase + (int64_t)ikt * 64 * ldv, ldv, S - ikt * 64, st_ + VIMG, wave, lane);
+        if (++ikt == tiles_of(iqb)) { ikt = 0; --iqb; }
+        istage = istage == NST - 1 ? 0 : istage + 1;
+        return true;
     };
+    int inflight = 0;
+    inflight += issue_next();
+    inflight += issue_next();
 
-    // everything with a global-memory latency is requested up front, first tile first; the owned registers are filled after
-    issue(0, 0);
-    {
-        bf16x8 tq[KS], to[KS];
-        load_rows_frag<D>(q + (int64_t)b * S * ldq + (int64_t)hq * D, ldq, qg, qvalid, lane, tq);
-        load_rows_frag<D>(d_o + (int64_t)b * S * lddo + (int64_t)hq * D, lddo, qg, qvalid, lane, to);
-        owned_zero<OWNED, 0, 16 * DT>();
-        static_for<KS>([&](auto ks) { owned_write4<OWNED, QF0 + 4 * ks.value>(tq[ks.value]); });
-        static_for<KS>([&](auto ks) { owned_write4<OWNED, OF0 + 4 * ks.value>(to[ks.value]); });
-    }
-    const float lse2 = qvalid ? lse[((int64_t)b * Hq + hq) * S + qg] * LOG2E : 0.f;
-    const float dlt = qvalid ? delta[((int64_t)b * Hq + hq) * S + qg] : 0.f;
+    // key-padding bits of every 64-key tile of this batch row (1 = real token), once per workgroup
+    if (key_mask)
+        for (int t = wave; t < ntiles_all; t += 4) {
+            const int kgl = t * 64 + lane;
+            const unsigned long long bits = __ballot(kgl < S && key_mask[(int64_t)b * S + kgl] != 0);
+            if (lane == 0) kmw[t] = bits;
+        }
+
     const LaneOff<D> lo = lane_offsets<D>(lane);
-    uint8_t mk = (key_mask && lane < S) ? key_mask[(int64_t)b * S + lane] : (uint8_t)0;  // one tile ahead, as in the forward
-    for (int kt = 0; kt < ntiles; ++kt) {
-        __syncthreads();
-        if (kt + 1 < ntiles && !(abl & 1)) issue(kt + 1, (kt + 1) & 1);
-        const int kroff = (kt & 1) * 3 * C::TILE, ktoff = kroff + C::TILE, vroff = kroff + 2 * C::TILE;
-        unsigned long long kbits = ~0ull;
-        if (key_mask) {
-            kbits = __ballot(mk != 0);
-            const int kn = (kt + 1) * 64 + lane;
-            mk = kn < S ? key_mask[(int64_t)b * S + kn] : (uint8_t)0;
+    int cstage = 0;
+    for (int qb = qb_hi - 1; qb >= qb_lo; --qb) {
+        const int q0 = qb * 128;
+        const int qg = q0 + wave * 32 + (lane & 31);
+        const bool qvalid = qg < S;
+        {
+            bf16x8 tq[KS], to[KS];
+            load_rows_frag<D>(q + (int64_t)b * S * ldq + (int64_t)hq * D, ldq, qg, qvalid, lane, tq);
+            load_rows_frag<D>(d_o + (int64_t)b * S * lddo + (int64_t)hq * D, lddo, qg, qvalid, lane, to);
+            owned_zero<OWNED, 0, 16 * DT>();
+            static_for<KS>([&](auto ks) { owned_write4<OWNED, QF0 + 4 * ks.value>(tq[ks.value]); });
+            static_for<KS>([&](auto ks) { owned_write4<OWNED, OF0 + 4 * ks.value>(to[ks.value]); });
         }
-        const bool wave_active = !causal || (kt * 64 <= q0 + wave * 32 + 31);
-        if (!wave_active) continue;
-        const bool boundary = (kbits != ~0ull) || (kt * 64 + 64 > S) || (causal && kt * 64 + 63 > q0 + wave * 32);
-        int vkx[KS], vvx[KS], vkt[DT];
+        const float lse2 = qvalid ? lse[((int64_t)b * Hq + hq) * S + qg] * LOG2E : 0.f;
+        const float dlt = qvalid ? delta[((int64_t)b * Hq + hq) * S + qg] : 0.f;
+        const int ntiles = tiles_of(qb);
+        for (int kt = 0; kt < ntiles; ++kt) {
+            // this wave's pieces of the tile have landed (a younger tile may stay in flight), then everybody's
+            if (inflight >= 2) wait_vmcnt<PIECES>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            --inflight;
+            if (!(abl & 1)) inflight += issue_next();  // into the stage that was consumed before this barrier
+            const int kroff = cstage * STAGE, ktoff = UNI ? kroff : kroff + C::TILE, vroff = kroff + VIMG;
+            cstage = cstage == NST - 1 ? 0 : cstage + 1;
+            unsigned long long kbits = ~0ull;
+            if (key_mask) {
+                const unsigned long long w = kmw[kt];
+                kbits = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(w >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)w);
+            }
+            const bool wave_active = !causal || (kt * 64 <= q0 + wave * 32 + 31);
+            if (!wave_active) continue;
+            const bool boundary = (kbits != ~0ull) || (kt * 64 + 64 > S) || (causal && kt * 64 + 63 > q0 + wave * 32);
+            int vkx[KS], vvx[KS], vkt[DT];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            vkx[ks] = (lo.row + kroff) ^ (ks << 5);
-            vvx[ks] = (lo.row + vroff) ^ (ks << 5);
-        }
+            for (int ks = 0; ks < KS; ++ks) {
+                vkx[ks] = ((UNI ? lo.rowu : lo.row) + kroff) ^ (ks << 5);
+                vvx[ks] = (lo.row + vroff) ^ (ks << 5);
+            }
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) vkt[dt] = lo.col[dt] + ktoff;
+            for (int dt = 0; dt < DT; ++dt) vkt[dt] = (UNI ? lo.colu[dt] : lo.col[dt]) + ktoff;
 
-        auto tile_body = [&](auto bc) {
-            constexpr bool BOUNDARY = decltype(bc)::value;
-            bf16x8 f[RING] = {};
-            f32x16 sacc[2], pacc[2];
-            unsigned dsw[2][8] = {};  // packed dS^T: words 4s..4s+3 of sub-tile st are the B operand of k-step s
-            float dsv[16];
-            auto load = [&](auto gc) {
-                constexpr int g = gc.value;
-                if constexpr (ATTN_ABL & 1) return;
-                if constexpr (g < 2 * NA) {
-                    constexpr int st = g / NA, ks = (g % NA) / 2, which = g % 2;
-                    f[g % RING] = lds_frag(smem, which ? vvx[ks] : vkx[ks], st * 32 * C::ROWB);
-                } else if constexpr (g < NG) {
-                    constexpr int h = g - 2 * NA, st = h / NC, sd = (h % NC) / DT, dt = h % DT;
-                    f[g % RING] = lds_frag_tr<D>(smem, vkt[dt], (st * 32 + 16 * sd) * C::ROWB);
-                }
+            auto tile_body = [&](auto bc) {
+                constexpr bool BOUNDARY = decltype(bc)::value;
+                bf16x8 f[RING] = {};
+                f32x16 sacc[2], pacc[2];
+                unsigned dsw[2][8] = {};  // packed dS^T: words 4s..4s+3 of sub-tile st are the B operand of k-step s
+                float dsv[16];
+                auto load = [&](auto gc) {
+                    constexpr int g = gc.value;
+                    if constexpr (ATTN_ABL & 1) return;
+                    if constexpr (g < 2 * NA) {
+                        constexpr int st = g / NA, ks = (g % NA) / 2, which = g % 2;
+                        f[g % RING] = lds_frag(smem, which ? vvx[ks] : vkx[ks], st * 32 * C::ROWB);
+                    } else if constexpr (g < NG) {
+                        constexpr int h = g - 2 * NA, st = h / NC, sd = (h % NC) / DT, dt = h % DT;
+                        if constexpr (UNI) f[g % RING] = lds_frag_tr_uni<D>(smem, vkt[dt], (st * 32 + 16 * sd) * C::ROWB);
+                        else f[g % RING] = lds_frag_tr<D>(smem, vkt[dt], (st * 32 + 16 * sd) * C::ROWB);
+                    }
+                };
+                auto element = [&](auto stc, auto ec) {
+                    constexpr int st = stc.value, e = ec.value;
+                    if constexpr (ATTN_ABL & 2) return;
+                    float p;
+                    if constexpr (BOUNDARY) {
+                        const int kl = st * 32 + acc_row(e, lane);
+                        const int kg = kt * 64 + kl;
+                        const bool masked = (causal && kg > qg) || !((kbits >> kl) & 1ull) || kg >= S;
+                        p = masked ? 0.f : __builtin_amdgcn_exp2f(fmaf(sacc[st][e], scale_log2, -lse2));
+                    } else {
+                        p = __builtin_amdgcn_exp2f(fmaf(sacc[st][e], scale_log2, -lse2));
+                    }
+                    dsv[e] = p * (pacc[st][e] - dlt) * scale;  // dS^T (gradient w.r.t. the raw QK^T product)
+                    if constexpr (e % 2 == 1) dsw[st][e / 2] = pack_bf2(dsv[e - 1], dsv[e]);
+                };
+                static_for<PD>([&](auto g) { load(g); });
+                static_for<NG>([&](auto gc) {
+                    constexpr int g = gc.value;
+                    load(std::integral_constant<int, g + PD>{});
+                    if constexpr (g < 2 * NA) {
+                        constexpr int st = g / NA, ks = (g % NA) / 2, which = g % 2;
+                        if constexpr ((ATTN_ABL & 8) && ks > 0) {
+                        } else if constexpr (which == 0) mfma_ownedB<OWNED, QF0 + 4 * ks, ks == 0>(sacc[st], f[g % RING]);
+                        else mfma_ownedB<OWNED, OF0 + 4 * ks, ks == 0>(pacc[st], f[g % RING]);
+                    } else if constexpr (!(ATTN_ABL & 4)) {
+                        constexpr int h = g - 2 * NA, st = h / NC, sd = (h % NC) / DT, dt = h % DT;
+                        const u32x4 w = {dsw[st][4 * sd], dsw[st][4 * sd + 1], dsw[st][4 * sd + 2], dsw[st][4 * sd + 3]};
+                        mfma_owned<OWNED, 16 * dt>(f[g % RING], __builtin_bit_cast(bf16x8, w));
+                    }
+                    // B(0) rides on the MFMAs of A(1), B(1) on those of C(0)
+                    if constexpr (g == NA) tiles_settle(sacc[0], pacc[0]);
+                    if constexpr (g == 2 * NA) tiles_settle(sacc[1], pacc[1]);
+                    if constexpr (g >= NA && g < 2 * NA) {
+                        constexpr int m = g - NA, per = 16 / NA;
+                        static_for<per>([&](auto i) { element(std::integral_constant<int, 0>{}, std::integral_constant<int, m * per + i.value>{}); });
+                    } else if constexpr (g >= 2 * NA && g < 2 * NA + NC) {
+                        constexpr int m = g - 2 * NA, per = 16 / NC;
+                        static_for<per>([&](auto i) { element(std::integral_constant<int, 1>{}, std::integral_constant<int, m * per + i.value>{}); });
+                    }
+                });
             };
-            auto element = [&](auto stc, auto ec) {
-                constexpr int st = stc.value, e = ec.value;
-                if constexpr (ATTN_ABL & 2) return;
-                float p;
-                if constexpr (BOUNDARY) {
-                    const int kl = st * 32 + acc_row(e, lane);
-                    const int kg = kt * 64 + kl;
-                    const bool masked = (causal && kg > qg) || !((kbits >> kl) & 1ull) || kg >= S;
-                    p = masked ? 0.f : __builtin_amdgcn_exp2f(fmaf(sacc[st][e], scale_log2, -lse2));
-                } else {
-                    p = __builtin_amdgcn_exp2f(fmaf(sacc[st][e], scale_log2, -lse2));
-                }
-                dsv[e] = p * (pacc[st][e] - dlt) * scale;  // dS^T (gradient w.r.t. the raw QK^T product)
-                if constexpr (e % 2 == 1) dsw[st][e / 2] = pack_bf2(dsv[e - 1], dsv[e]);
-            };
-            static_for<PD>([&](auto g) { load(g); });
-            static_for<NG>([&](auto gc) {
-                constexpr int g = gc.value;
-                load(std::integral_constant<int, g + PD>{});
-                if constexpr (g < 2 * NA) {
-                    constexpr int st = g / NA, ks = (g % NA) / 2, which = g % 2;
-                    if constexpr ((ATTN_ABL & 8) && ks > 0) {
-                    } else if constexpr (which == 0) mfma_ownedB<OWNED, QF0 + 4 * ks, ks == 0>(sacc[st], f[g % RING]);
-                    else mfma_ownedB<OWNED, OF0 + 4 * ks, ks == 0>(pacc[st], f[g % RING]);
-                } else if constexpr (!(ATTN_ABL & 4)) {
-                    constexpr int h = g - 2 * NA, st = h / NC, sd = (h % NC) / DT, dt = h % DT;
-                    const u32x4 w = {dsw[st][4 * sd], dsw[st][4 * sd + 1], dsw[st][4 * sd + 2], dsw[st][4 * sd + 3]};
-                    mfma_owned<OWNED, 16 * dt>(f[g % RING], __builtin_bit_cast(bf16x8, w));
-                }
-                // B(0) rides on the MFMAs of A(1), B(1) on those of C(0)
-                if constexpr (g == NA) tiles_settle(sacc[0], pacc[0]);
-                if constexpr (g == 2 * NA) tiles_settle(sacc[1], pacc[1]);
-                if constexpr (g >= NA && g < 2 * NA) {
-                    constexpr int m = g - NA, per = 16 / NA;
-                    static_for<per>([&](auto i) { element(std::integral_constant<int, 0>{}, std::integral_constant<int, m * per + i.value>{}); });
-                } else if constexpr (g >= 2 * NA && g < 2 * NA + NC) {
-                    constexpr int m = g - 2 * NA, per = 16 / NC;
-                    static_for<per>([&](auto i) { element(std::integral_constant<int, 1>{}, std::integral_constant<int, m * per + i.value>{}); });
-                }
-            });
-        };
-        if (boundary) tile_body(std::true_type{});
-        else tile_body(std::false_type{});
+            if (boundary) tile_body(std::true_type{});
+            else tile_body(std::false_type{});
+        }
+        owned_settle<OWNED>();
+        bf16_t* row = dq + ((int64_t)b * S + qg) * lddq + (int64_t)hq * D;
+        static_for<DT * 4>([&](auto i) {
+            constexpr int dt = i.value / 4, g4 = i.value % 4, r = 16 * dt + 4 * g4;
+            const int d = dt * 32 + 8 * g4 + 4 * (lane >> 5);
+            const u32x2 pk = {pack_bf2(owned_read<OWNED, r>(), owned_read<OWNED, r + 1>()), pack_bf2(owned_read<OWNED, r + 2>(), owned_read<OWNED, r + 3>())};
+            if (qvalid) *reinterpret_cast<u32x2*>(row + d) = pk;
+        });
     }
-    owned_settle<OWNED>();
-    bf16_t* row = dq + ((int64_t)b * S + qg) * lddq + (int64_t)hq * D;
-    static_for<DT * 4>([&](auto i) {
-        constexpr int dt = i.value / 4, g4 = i.value % 4, r = 16 * dt + 4 * g4;
-        const int d = dt * 32 + 8 * g4 + 4 * (lane >> 5);
-        const u32x2 pk = {pack_bf2(owned_read<OWNED, r>(), owned_read<OWNED, r + 1>()), pack_bf2(owned_read<OWNED, r + 2>(), owned_read<OWNED, r + 3>())};
-        if (qvalid) *reinterpret_cast<u32x2*>(row + d) = pk;
-    });
 }
 
 // ---- dK/dV pass: KEY on the lane.  One workgroup = 128 keys of one (batch, kv head); each wave owns 32 keys and keeps
@@ -563,181 +626,211 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
                                                               int64_t ldv, const bf16_t* __restrict__ d_o, int64_t lddo,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
                                                               bf16_t* __restrict__ dk, int64_t lddk, bf16_t* __restrict__ dv, int64_t lddv,
-                                                              const uint8_t* __restrict__ key_mask, int causal, float scale, float scale_log2) {
+                                                              const uint8_t* __restrict__ key_mask, int causal, float scale, float scale_log2,
+                                                              int bpw) {
     using C = Cfg<D>;
     constexpr int KS = C::KS, DT = C::DT;
     constexpr int NA = 2 * KS, NC = 4 * DT, NG = 2 * NA + 2 * NC;
     constexpr int OWNED = 32 * DT + 8 * KS, DK0 = 16 * DT, KF0 = 32 * DT, VF0 = KF0 + 4 * KS;  // dV^T | dK^T | K rows | V rows
     constexpr int RING = 8, PD = 6;
-    const int abl = causal >> 8;  // profiling only: 1 = no DMA after the first tile
+    // LDS: NST stages x (Q | dO [unified images])  or, D = 64,  (Q rows | Q transposed | dO rows | dO transposed);
+    // then NST x 64 x (lse, delta)
+    constexpr bool UNI = C::UNI;
+    constexpr int NIMG = UNI ? 2 : 4, NST = 3, STAGE = NIMG * C::TILE, PIECES = NIMG * C::PPW;
+    constexpr int OIMG = (UNI ? 1 : 2) * C::TILE;  // offset of the dO image(s) inside a stage
+    const int abl = causal >> 8;  // profiling only: 1 = no DMA after the first tiles
     causal &= 0xff;
-    // 2 stages x (Q row, Q tr, dO row, dO tr) + 2 stages x 64 x (lse2, delta)
-    __shared__ __attribute__((aligned(16))) char smem[8 * C::TILE + 2 * 64 * 8];
-    float* rowc = reinterpret_cast<float*>(smem + 8 * C::TILE);
+    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE + NST * 512];
+    char* rowc = smem + NST * STAGE;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nkb = (S + 127) / 128;
-    const int kb = blockIdx.x % nkb;
-    const int bh = blockIdx.x / nkb;
+    // one workgroup = `bpw` consecutive 128-key blocks of one (batch, kv head)
+    const int nkb = (S + 127) / 128, nchunk = (nkb + bpw - 1) / bpw;
+    const int chunk = blockIdx.x % nchunk, bh = blockIdx.x / nchunk;
     const int hkv = bh % Hkv, b = bh / Hkv;
     const int rep = Hq / Hkv;
-    const int k0 = kb * 128;
-    const int kg = k0 + wave * 32 + (lane & 31);
-    const bool kvalid = kg < S;
-    const bool kreal = kvalid && (key_mask == nullptr || key_mask[(int64_t)b * S + kg] != 0);
-
+    const int kb_lo = chunk * bpw, kb_hi = min(nkb, kb_lo + bpw);
     const int nqt_all = (S + 63) / 64;
-    const int qt0 = causal ? k0 / 64 : 0;  // first query tile that can see any key of this block
-    const int per_head = nqt_all - qt0;
-    const int nit = per_head * rep;
+    auto qt0_of = [&](int kb) { return causal ? kb * 2 : 0; };  // first query tile that can see any key of the block
 
-    auto issue = [&](int it, int stage) {
-        const int hq = hkv * rep + it / per_head;
-        const int qt = qt0 + it % per_head;
-        char* st_ = smem + stage * 4 * C::TILE;
+    // ---- Q / dO tile stream over (key block, head, query tile), NST-deep
+    int ikb = kb_lo, iit = 0, istage = 0;
+    auto issue_next = [&]() -> bool {
+        while (ikb < kb_hi && iit >= (nqt_all - qt0_of(ikb)) * rep) { ++ikb; iit = 0; }
+        if (ikb >= kb_hi) return false;
+        const int per_head = nqt_all - qt0_of(ikb);
+        const int hq = hkv * rep + iit / per_head;
+        const int qt = qt0_of(ikb) + iit % per_head;
+        char* st_ = smem + istage * STAGE;
         const bf16_t* qb_ = q + ((int64_t)b * S + (int64_t)qt * 64) * ldq + (int64_t)hq * D;
         const bf16_t* ob_ = d_o + ((int64_t)b * S + (int64_t)qt * 64) * lddo + (int64_t)hq * D;
-        dma_tile<D, false>(qb_, ldq, S - qt * 64, st_, wave, lane);
-        dma_tile<D, true>(qb_, ldq, S - qt * 64, st_ + C::TILE, wave, lane);
-        dma_tile<D, false>(ob_, lddo, S - qt * 64, st_ + 2 * C::TILE, wave, lane);
-        dma_tile<D, true>(ob_, lddo, S - qt * 64, st_ + 3 * C::TILE, wave, lane);
-        if (wave < 2) {  // the tile's 64 lse (wave 0) / delta (wave 1) values: one 4-byte-per-lane DMA piece, rows >= S read 0
-            const float* src = (wave == 0 ? lse : delta) + ((int64_t)b * Hq + hq) * S + (int64_t)qt * 64;
+        if constexpr (UNI) {
+            dma_tile<D, IMG_UNI>(qb_, ldq, S - qt * 64, st_, wave, lane);
+            dma_tile<D, IMG_UNI>(ob_, lddo, S - qt * 64, st_ + OIMG, wave, lane);
+        } else {
+            dma_tile<D, IMG_ROW>(qb_, ldq, S - qt * 64, st_, wave, lane);
+            dma_tile<D, IMG_TR>(qb_, ldq, S - qt * 64, st_ + C::TILE, wave, lane);
+            dma_tile<D, IMG_ROW>(ob_, lddo, S - qt * 64, st_ + OIMG, wave, lane);
+            dma_tile<D, IMG_TR>(ob_, lddo, S - qt * 64, st_ + OIMG + C::TILE, wave, lane);
+        }
+        {   // the tile's 64 lse / delta values: 4-byte-per-lane pieces, rows >= S read 0.  Every wave issues one (waves 2, 3
+            // duplicate 0, 1) so that all waves have the same number of pieces in flight for the counted wait.
+            const float* src = ((wave & 1) == 0 ? lse : delta) + ((int64_t)b * Hq + hq) * S + (int64_t)qt * 64;
             auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 0x7fffffff, 0x00020000);
             const unsigned voff = qt * 64 + lane < S ? (unsigned)(lane * 4) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(reinterpret_cast<char*>(rowc) + stage * 512 + wave * 256), 4, voff, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(rowc + istage * 512 + (wave & 1) * 256), 4, voff, 0, 0, 0);
         }
+        ++iit;
+        istage = istage == NST - 1 ? 0 : istage + 1;
+        return true;
     };
+    int inflight = 0;
+    inflight += issue_next();
+    inflight += issue_next();
 
     const LaneOff<D> lo = lane_offsets<D>(lane);
-    if (nit > 0) issue(0, 0);  // first tile first, then the row operands: their latencies overlap
-    {
-        bf16x8 tk[KS], tv[KS];
-        load_rows_frag<D>(k + (int64_t)b * S * ldk + (int64_t)hkv * D, ldk, kg, kvalid, lane, tk);
-        load_rows_frag<D>(v + (int64_t)b * S * ldv + (int64_t)hkv * D, ldv, kg, kvalid, lane, tv);
-        owned_zero<OWNED, 0, 32 * DT>();
-        static_for<KS>([&](auto ks) { owned_write4<OWNED, KF0 + 4 * ks.value>(tk[ks.value]); });
-        static_for<KS>([&](auto ks) { owned_write4<OWNED, VF0 + 4 * ks.value>(tv[ks.value]); });
-    }
-    for (int it = 0; it < nit; ++it) {
-        __syncthreads();
-        if (it + 1 < nit && !(abl & 1)) issue(it + 1, (it + 1) & 1);
-        const int qt = qt0 + it % per_head;
-        const int qroff = (it & 1) * 4 * C::TILE, qtoff = qroff + C::TILE, oroff = qroff + 2 * C::TILE, otoff = qroff + 3 * C::TILE;
-        const float* rc = rowc + (it & 1) * 128 + 4 * (lane >> 5);
-        // queries of this tile all precede this wave's keys -> nothing visible
-        if (causal && qt * 64 + 63 < k0 + wave * 32) continue;
-        // masks only where the tile touches the diagonal, the sequence end, or this wave holds padded / out-of-range keys
-        const bool boundary = (causal && qt * 64 < k0 + wave * 32 + 31) || (qt * 64 + 64 > S) || __any(!kreal);
-        int vqx[KS], vox[KS], vqt[DT], vot[DT];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            vqx[ks] = (lo.row + qroff) ^ (ks << 5);
-            vox[ks] = (lo.row + oroff) ^ (ks << 5);
+    int cstage = 0;
+    for (int kb = kb_lo; kb < kb_hi; ++kb) {
+        const int k0 = kb * 128;
+        const int kg = k0 + wave * 32 + (lane & 31);
+        const bool kvalid = kg < S;
+        const bool kreal = kvalid && (key_mask == nullptr || key_mask[(int64_t)b * S + kg] != 0);
+        {
+            bf16x8 tk[KS], tv[KS];
+            load_rows_frag<D>(k + (int64_t)b * S * ldk + (int64_t)hkv * D, ldk, kg, kvalid, lane, tk);
+            load_rows_frag<D>(v + (int64_t)b * S * ldv + (int64_t)hkv * D, ldv, kg, kvalid, lane, tv);
+            owned_zero<OWNED, 0, 32 * DT>();
+            static_for<KS>([&](auto ks) { owned_write4<OWNED, KF0 + 4 * ks.value>(tk[ks.value]); });
+            static_for<KS>([&](auto ks) { owned_write4<OWNED, VF0 + 4 * ks.value>(tv[ks.value]); });
         }
+        const int qt0 = qt0_of(kb);
+        const int per_head = nqt_all - qt0;
+        const int nit = per_head * rep;
+        for (int it = 0; it < nit; ++it) {
+            // this wave's pieces of the tile have landed (a younger tile may stay in flight), then everybody's
+            if (inflight >= 2) wait_vmcnt<PIECES + 1>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            --inflight;
+            if (!(abl & 1)) inflight += issue_next();  // into the stage that was consumed before this barrier
+            const int qt = qt0 + it % per_head;
+            const int qroff = cstage * STAGE, qtoff = UNI ? qroff : qroff + C::TILE, oroff = qroff + OIMG, otoff = UNI ? oroff : oroff + C::TILE;
+            const float* rc = reinterpret_cast<const float*>(rowc + cstage * 512) + 4 * (lane >> 5);
+            cstage = cstage == NST - 1 ? 0 : cstage + 1;
+            // queries of this tile all precede this wave's keys -> nothing visible
+            if (causal && qt * 64 + 63 < k0 + wave * 32) continue;
+            // masks only where the tile touches the diagonal, the sequence end, or this wave holds padded / out-of-range keys
+            const bool boundary = (causal && qt * 64 < k0 + wave * 32 + 31) || (qt * 64 + 64 > S) || __any(!kreal);
+            int vqx[KS], vox[KS], vqt[DT], vot[DT];
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            vqt[dt] = lo.col[dt] + qtoff;
-            vot[dt] = lo.col[dt] + otoff;
-        }
+            for (int ks = 0; ks < KS; ++ks) {
+                vqx[ks] = ((UNI ? lo.rowu : lo.row) + qroff) ^ (ks << 5);
+                vox[ks] = ((UNI ? lo.rowu : lo.row) + oroff) ^ (ks << 5);
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                vqt[dt] = (UNI ? lo.colu[dt] : lo.col[dt]) + qtoff;
+                vot[dt] = (UNI ? lo.colu[dt] : lo.col[dt]) + otoff;
+            }
 
-        auto tile_body = [&](auto bc) {
-            constexpr bool BOUNDARY = decltype(bc)::value;
-            bf16x8 f[RING] = {};
-            f32x16 sacc[2], pacc[2];
-            unsigned pw[2][8] = {}, dsw[2][8] = {};  // packed P / dS: words 4s..4s+3 of sub-tile st are the B operand of k-step s
-            float pv[16], dsv[16], l2r[16], dlr[16];
-            auto load = [&](auto gc) {
-                constexpr int g = gc.value;
-                if constexpr (ATTN_ABL & 1) return;
-                if constexpr (g < 2 * NA) {
-                    constexpr int st = g / NA, ks = (g % NA) / 2, which = g % 2;
-                    f[g % RING] = lds_frag(smem, which ? vox[ks] : vqx[ks], st * 32 * C::ROWB);
-                } else if constexpr (g < NG) {
-                    constexpr int h = g - 2 * NA, st = h / NC, sd = (h % NC) / (2 * DT), dt = (h % (2 * DT)) / 2, which = h % 2;
-                    f[g % RING] = lds_frag_tr<D>(smem, which ? vqt[dt] : vot[dt], (st * 32 + 16 * sd) * C::ROWB);
-                }
-            };
-            // per-query constants of the 16 accumulator rows of sub-tile st: rows 8*g4 + 4*h + 0..3
-            auto row_constants = [&](auto stc) {
-                constexpr int st = stc.value;
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(rc + st * 32 + 8 * g4);
-                    const f32x4 c = *reinterpret_cast<const f32x4*>(rc + 64 + st * 32 + 8 * g4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { l2r[4 * g4 + e] = a[e] * LOG2E; dlr[4 * g4 + e] = c[e]; }
-                }
-            };
-            auto element = [&](auto stc, auto ec) {
-                constexpr int st = stc.value, e = ec.value;
-                if constexpr (ATTN_ABL & 2) return;
-                float p;
-                if constexpr (BOUNDARY) {
-                    const int qq = qt * 64 + st * 32 + acc_row(e, lane);
-                    const bool masked = (causal && kg > qq) || !kreal || qq >= S;
-                    p = masked ? 0.f : __builtin_amdgcn_exp2f(fmaf(sacc[st][e], scale_log2, -l2r[e]));
-                } else {
-                    p = __builtin_amdgcn_exp2f(fmaf(sacc[st][e], scale_log2, -l2r[e]));
-                }
-                pv[e] = p;
-                dsv[e] = p * (pacc[st][e] - dlr[e]) * scale;
-                if constexpr (e % 2 == 1) {
-                    pw[st][e / 2] = pack_bf2(pv[e - 1], pv[e]);
-                    dsw[st][e / 2] = pack_bf2(dsv[e - 1], dsv[e]);
-                }
-            };
-            static_for<PD>([&](auto g) { load(g); });
-            static_for<NG>([&](auto gc) {
-                constexpr int g = gc.value;
-                if constexpr (g == NA - 1) row_constants(std::integral_constant<int, 0>{});
-                load(std::integral_constant<int, g + PD>{});
-                if constexpr (g < 2 * NA) {
-                    constexpr int st = g / NA, ks = (g % NA) / 2, which = g % 2;
-                    if constexpr ((ATTN_ABL & 8) && ks > 0) {
-                    } else if constexpr (which == 0) mfma_ownedB<OWNED, KF0 + 4 * ks, ks == 0>(sacc[st], f[g % RING]);
-                    else mfma_ownedB<OWNED, VF0 + 4 * ks, ks == 0>(pacc[st], f[g % RING]);
-                } else if constexpr (!(ATTN_ABL & 4)) {
-                    constexpr int h = g - 2 * NA, st = h / NC, sd = (h % NC) / (2 * DT), dt = (h % (2 * DT)) / 2, which = h % 2;
-                    if constexpr (which == 0) {
-                        const u32x4 w = {pw[st][4 * sd], pw[st][4 * sd + 1], pw[st][4 * sd + 2], pw[st][4 * sd + 3]};
-                        mfma_owned<OWNED, 16 * dt>(f[g % RING], __builtin_bit_cast(bf16x8, w));
-                    } else {
-                        const u32x4 w = {dsw[st][4 * sd], dsw[st][4 * sd + 1], dsw[st][4 * sd + 2], dsw[st][4 * sd + 3]};
-                        mfma_owned<OWNED, DK0 + 16 * dt>(f[g % RING], __builtin_bit_cast(bf16x8, w));
+            auto tile_body = [&](auto bc) {
+                constexpr bool BOUNDARY = decltype(bc)::value;
+                bf16x8 f[RING] = {};
+                f32x16 sacc[2], pacc[2];
+                unsigned pw[2][8] = {}, dsw[2][8] = {};  // packed P / dS: words 4s..4s+3 of sub-tile st are the B operand of k-step s
+                float pv[16], dsv[16], l2r[16], dlr[16];
+                auto load = [&](auto gc) {
+                    constexpr int g = gc.value;
+                    if constexpr (ATTN_ABL & 1) return;
+                    if constexpr (g < 2 * NA) {
+                        constexpr int st = g / NA, ks = (g % NA) / 2, which = g % 2;
+                        f[g % RING] = lds_frag(smem, which ? vox[ks] : vqx[ks], st * 32 * C::ROWB);
+                    } else if constexpr (g < NG) {
+                        constexpr int h = g - 2 * NA, st = h / NC, sd = (h % NC) / (2 * DT), dt = (h % (2 * DT)) / 2, which = h % 2;
+                        if constexpr (UNI) f[g % RING] = lds_frag_tr_uni<D>(smem, which ? vqt[dt] : vot[dt], (st * 32 + 16 * sd) * C::ROWB);
+                        else f[g % RING] = lds_frag_tr<D>(smem, which ? vqt[dt] : vot[dt], (st * 32 + 16 * sd) * C::ROWB);
                     }
-                }
-                // B(0) rides on the MFMAs of A(1), B(1) on those of C(0)
-                if constexpr (g == NA) tiles_settle(sacc[0], pacc[0]);
-                if constexpr (g == 2 * NA) tiles_settle(sacc[1], pacc[1]);
-                if constexpr (g >= NA && g < 2 * NA) {
-                    constexpr int m = g - NA, per = 16 / NA;
-                    static_for<per>([&](auto i) { element(std::integral_constant<int, 0>{}, std::integral_constant<int, m * per + i.value>{}); });
-                    if constexpr (g == 2 * NA - 1) row_constants(std::integral_constant<int, 1>{});
-                } else if constexpr (g >= 2 * NA && g < 2 * NA + NC) {
-                    constexpr int m = g - 2 * NA, per = (16 + NC - 1) / NC;
-                    static_for<per>([&](auto i) {
-                        if constexpr (m * per + i.value < 16) element(std::integral_constant<int, 1>{}, std::integral_constant<int, m * per + i.value>{});
-                    });
-                }
-            });
-        };
-        if (boundary) tile_body(std::true_type{});
-        else tile_body(std::false_type{});
-    }
-    owned_settle<OWNED>();
-    bf16_t* krow = dk + ((int64_t)b * S + kg) * lddk + (int64_t)hkv * D;
-    bf16_t* vrow = dv + ((int64_t)b * S + kg) * lddv + (int64_t)hkv * D;
-    static_for<DT * 4>([&](auto i) {
-        constexpr int dt = i.value / 4, g4 = i.value % 4, rv = 16 * dt + 4 * g4, rk = DK0 + rv;
-        const int d = dt * 32 + 8 * g4 + 4 * (lane >> 5);
-        const u32x2 a = {pack_bf2(owned_read<OWNED, rk>(), owned_read<OWNED, rk + 1>()), pack_bf2(owned_read<OWNED, rk + 2>(), owned_read<OWNED, rk + 3>())};
-        const u32x2 c = {pack_bf2(owned_read<OWNED, rv>(), owned_read<OWNED, rv + 1>()), pack_bf2(owned_read<OWNED, rv + 2>(), owned_read<OWNED, rv + 3>())};
-        if (kvalid) {
-            *reinterpret_cast<u32x2*>(krow + d) = a;
-            *reinterpret_cast<u32x2*>(vrow + d) = c;
+                };
+                // per-query constants of the 16 accumulator rows of sub-tile st: rows 8*g4 + 4*h + 0..3
+                auto row_constants = [&](auto stc) {
+                    constexpr int st = stc.value;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(rc + st * 32 + 8 * g4);
+                        const f32x4 c = *reinterpret_cast<const f32x4*>(rc + 64 + st * 32 + 8 * g4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { l2r[4 * g4 + e] = a[e] * LOG2E; dlr[4 * g4 + e] = c[e]; }
+                    }
+                };
+                auto element = [&](auto stc, auto ec) {
+                    constexpr int st = stc.value, e = ec.value;
+                    if constexpr (ATTN_ABL & 2) return;
+                    float p;
+                    if constexpr (BOUNDARY) {
+                        const int qq = qt * 64 + st * 32 + acc_row(e, lane);
+                        const bool masked = (causal && kg > qq) || !kreal || qq >= S;
+                        p = masked ? 0.f : __builtin_amdgcn_exp2f(fmaf(sacc[st][e], scale_log2, -l2r[e]));
+                    } else {
+                        p = __builtin_amdgcn_exp2f(fmaf(sacc[st][e], scale_log2, -l2r[e]));
+                    }
+                    pv[e] = p;
+                    dsv[e] = p * (pacc[st][e] - dlr[e]) * scale;
+                    if constexpr (e % 2 == 1) {
+                        pw[st][e / 2] = pack_bf2(pv[e - 1], pv[e]);
+                        dsw[st][e / 2] = pack_bf2(dsv[e - 1], dsv[e]);
+                    }
+                };
+                static_for<PD>([&](auto g) { load(g); });
+                static_for<NG>([&](auto gc) {
+                    constexpr int g = gc.value;
+                    if constexpr (g == NA - 1) row_constants(std::integral_constant<int, 0>{});
+                    load(std::integral_constant<int, g + PD>{});
+                    if constexpr (g < 2 * NA) {
+                        constexpr int st = g / NA, ks = (g % NA) / 2, which = g % 2;
+                        if constexpr ((ATTN_ABL & 8) && ks > 0) {
+                        } else if constexpr (which == 0) mfma_ownedB<OWNED, KF0 + 4 * ks, ks == 0>(sacc[st], f[g % RING]);
+                        else mfma_ownedB<OWNED, VF0 + 4 * ks, ks == 0>(pacc[st], f[g % RING]);
+                    } else if constexpr (!(ATTN_ABL & 4)) {
+                        constexpr int h = g - 2 * NA, st = h / NC, sd = (h % NC) / (2 * DT), dt = (h % (2 * DT)) / 2, which = h % 2;
+                        if constexpr (which == 0) {
+                            const u32x4 w = {pw[st][4 * sd], pw[st][4 * sd + 1], pw[st][4 * sd + 2], pw[st][4 * sd + 3]};
+                            mfma_owned<OWNED, 16 * dt>(f[g % RING], __builtin_bit_cast(bf16x8, w));
+                        } else {
+                            const u32x4 w = {dsw[st][4 * sd], dsw[st][4 * sd + 1], dsw[st][4 * sd + 2], dsw[st][4 * sd + 3]};
+                            mfma_owned<OWNED, DK0 + 16 * dt>(f[g % RING], __builtin_bit_cast(bf16x8, w));
+                        }
+                    }
+                    // B(0) rides on the MFMAs of A(1), B(1) on those of C(0)
+                    if constexpr (g == NA) tiles_settle(sacc[0], pacc[0]);
+                    if constexpr (g == 2 * NA) tiles_settle(sacc[1], pacc[1]);
+                    if constexpr (g >= NA && g < 2 * NA) {
+                        constexpr int m = g - NA, per = 16 / NA;
+                        static_for<per>([&](auto i) { element(std::integral_constant<int, 0>{}, std::integral_constant<int, m * per + i.value>{}); });
+                        if constexpr (g == 2 * NA - 1) row_constants(std::integral_constant<int, 1>{});
+                    } else if constexpr (g >= 2 * NA && g < 2 * NA + NC) {
+                        constexpr int m = g - 2 * NA, per = (16 + NC - 1) / NC;
+                        static_for<per>([&](auto i) {
+                            if constexpr (m * per + i.value < 16) element(std::integral_constant<int, 1>{}, std::integral_constant<int, m * per + i.value>{});
+                        });
+                    }
+                });
+            };
+            if (boundary) tile_body(std::true_type{});
+            else tile_body(std::false_type{});
         }
-    });
+        owned_settle<OWNED>();
+        bf16_t* krow = dk + ((int64_t)b * S + kg) * lddk + (int64_t)hkv * D;
+        bf16_t* vrow = dv + ((int64_t)b * S + kg) * lddv + (int64_t)hkv * D;
+        static_for<DT * 4>([&](auto i) {
+            constexpr int dt = i.value / 4, g4 = i.value % 4, rv = 16 * dt + 4 * g4, rk = DK0 + rv;
+            const int d = dt * 32 + 8 * g4 + 4 * (lane >> 5);
+            const u32x2 a = {pack_bf2(owned_read<OWNED, rk>(), owned_read<OWNED, rk + 1>()), pack_bf2(owned_read<OWNED, rk + 2>(), owned_read<OWNED, rk + 3>())};
+            const u32x2 c = {pack_bf2(owned_read<OWNED, rv>(), owned_read<OWNED, rv + 1>()), pack_bf2(owned_read<OWNED, rv + 2>(), owned_read<OWNED, rv + 3>())};
+            if (kvalid) {
+                *reinterpret_cast<u32x2*>(krow + d) = a;
+                *reinterpret_cast<u32x2*>(vrow + d) = c;
+            }
+        });
+    }
 }
 
 int check_common(const char* name, int B, int S, int Hq, int Hkv, int D) {
@@ -778,14 +871,20 @@ extern "C" int mi355_attn_bwd(int B, int S, int Hq, int Hkv, int D, const void* 
     const float sl2 = scale * LOG2E;
     const int64_t items = (int64_t)B * S * Hq;
     const int dgrid = (int)((items + 3) / 4 > 2048 ? 2048 : (items + 3) / 4);
-    const int64_t gq = (int64_t)B * Hq * ((S + 127) / 128), gk = (int64_t)B * Hkv * ((S + 127) / 128);
+    // enough (batch, head) pairs to fill the chip twice over: one workgroup walks all blocks of its pair (no per-block launch,
+    // prologue and first-tile latency); otherwise one block per workgroup for parallelism
+    const int nblk = (S + 127) / 128;
+    const int bpw_q = (int64_t)B * Hq >= 512 ? nblk : 1;
+    const int bpw_k = (int64_t)B * Hkv >= 512 ? nblk : 1;
+    const int64_t gq = (int64_t)B * Hq * ((nblk + bpw_q - 1) / bpw_q), gk = (int64_t)B * Hkv * ((nblk + bpw_k - 1) / bpw_k);
+    MI355_REQUIRE(S <= 64 * ATTN_MAX_TILES, "mi355_attn_bwd: S must be <= %d", 64 * ATTN_MAX_TILES);
     MI355_REQUIRE(gq < 0x7fffffffLL, "mi355_attn_bwd: grid too large");
 #define BWD_LAUNCH(DD)                                                                                                              \
     hipLaunchKernelGGL(attn_delta_kernel<DD>, dim3(dgrid), dim3(256), 0, s, B, S, Hq, (const bf16_t*)o, ldo, (const bf16_t*)d_o, lddo, delta); \
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<DD>, dim3((unsigned)gk), dim3(256), 0, s, B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, \
-                       (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, key_mask, causal, scale, sl2); \
+                       (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, key_mask, causal, scale, sl2, bpw_k); \
     hipLaunchKernelGGL(attn_bwd_dq_kernel<DD>, dim3((unsigned)gq), dim3(256), 0, s, B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,  \
-                       (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dq, lddq, key_mask, causal, scale, sl2);
+                       (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dq, lddq, key_mask, causal, scale, sl2, bpw_q);
     if (D == 128) {
         BWD_LAUNCH(128)
     } else {

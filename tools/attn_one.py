@@ -5,7 +5,8 @@ import torch
 from llm_quest_amd import kernels as K
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-S, Hq, Hkv, D = 709, 16, 8, 128
+S = int(sys.argv[3]) if len(sys.argv) > 3 else 709
+Hq, Hkv, D = 16, 8, 128
 r = lambda *s: torch.randn(*s, device="cuda").to(torch.bfloat16)
 qkv = r(B * S, (Hq + 2 * Hkv) * D)
 q, k, v = r(B * S, Hq * D), r(B * S, Hkv * D), qkv[:, (Hq + Hkv) * D:]

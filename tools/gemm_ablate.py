@@ -5,6 +5,9 @@ import torch
 from llm_quest_amd import _lib as L, kernels as K
 M = N = 4096; Kd = 8192
 r = lambda *s: torch.randn(*s, device="cuda").to(torch.bfloat16)
+_w = r(4096, 4096)
+for _ in range(200): _w @ _w  # clocks up before anything is timed
+torch.cuda.synchronize()
 for name, form, sa, sb in (("NT", L.GEMM_NT, (M, Kd), (N, Kd)), ("NN", L.GEMM_NN, (M, Kd), (Kd, N)), ("TN", L.GEMM_TN, (Kd, M), (Kd, N))):
     a, b = r(*sa), r(*sb)
     res = []
