@@ -145,6 +145,27 @@ __device__ __forceinline__ bf16x8 lds_frag_tr_uni(const char* smem, int v, int i
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return r;
 }
+// Transposed fragment read from an asm statement.  hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of the first
+// ds_read_tr16_b64 INTRINSIC that follows an LDS-DMA (it cannot tell the read from the DMA's destination; plain ds_read_b128
+// loads are not affected): with one wave per SIMD that exposes the whole latency of the tile just requested, every trip.
+// An asm read is invisible to that logic -- and to the compiler's lgkmcnt bookkeeping: the two halves stay separate 64-bit
+// values until `tr_wait<N>` (the statement that carries the counted s_waitcnt and names both halves) has run.  LDS returns
+// data in issue order, so N = the LDS operations issued after this fragment's reads (compiler-issued reads in between only
+// make the wait stricter).
+struct TrHalves {
+    bf16x4 lo, hi;
+};
+template <int IMM0, int IMM1>
+__device__ __forceinline__ void tr_issue(TrHalves& f, unsigned a0, unsigned a1) {
+    static_assert(IMM0 >= 0 && IMM1 < 65536, "ds offset field is 16 bits");
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%c4\n\tds_read_b64_tr_b16 %1, %3 offset:%c5" : "=&v"(f.lo), "=&v"(f.hi) : "v"(a0), "v"(a1), "i"(IMM0), "i"(IMM1));
+}
+template <int N>
+__device__ __forceinline__ bf16x8 tr_wait(TrHalves& f) {
+    static_assert(N >= 0 && N <= 15, "lgkmcnt field is 4 bits");
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.lo), "+v"(f.hi) : "n"(N) : "memory");
+    return __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -197,6 +218,14 @@ __device__ __forceinline__ void load_rows_frag(const bf16_t* base, int64_t ld, i
         else asm volatile(__VA_ARGS__ : AGPR_CL_192, "memory");                               \
     } while (0)
 
+#if ATTN_ABL & 16
+__device__ unsigned long long g_prof[16];
+#define PROF_T() (prof_on ? __builtin_readcyclecounter() : 0ull)
+#define PROF_ADD(i, t0) do { if (prof_on) prof_acc[i] += __builtin_readcyclecounter() - (t0); } while (0)
+#else
+#define PROF_T() 0ull
+#define PROF_ADD(i, t0) do { (void)(t0); } while (0)
+#endif
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (N > 0) {
@@ -212,17 +241,17 @@ __device__ __forceinline__ void mfma_owned(const bf16x8& a, const bf16x8& b) {
     constexpr int R0 = 256 - OWNED + OFF;
     OWNED_ASM(OWNED, "s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "i"(R0), "i"(R0 + 15));
 }
-// compiler-allocated tile (an "a" operand, written and read in straight-line code) (+)= A x ownedB, where ownedB is the
+// compiler-allocated tile (16 VGPRs: the VALU reads it right after, no accvgpr copies) (+)= A x ownedB, where ownedB is the
 // 4-register B operand at owned offset OFF.  FIRST: start from zero (srcC = 0) instead of accumulating.
 template <int OWNED, int OFF, bool FIRST>
 __device__ __forceinline__ void mfma_ownedB(f32x16& acc, const bf16x8& a) {
     static_assert(OFF % 4 == 0 && OFF + 4 <= OWNED, "operand outside the owned range");
     constexpr int R0 = 256 - OWNED + OFF;
-    if constexpr (FIRST) OWNED_ASM(OWNED, "v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=a"(acc) : "v"(a), "i"(R0), "i"(R0 + 3));
-    else OWNED_ASM(OWNED, "v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+a"(acc) : "v"(a), "i"(R0), "i"(R0 + 3));
+    if constexpr (FIRST) OWNED_ASM(OWNED, "v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(acc) : "v"(a), "i"(R0), "i"(R0 + 3));
+    else OWNED_ASM(OWNED, "v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(acc) : "v"(a), "i"(R0), "i"(R0 + 3));
 }
 // wait states between the last MFMA into a compiler-allocated tile and its first VALU read (16-pass XDL -> read: 18)
-__device__ __forceinline__ void tiles_settle(f32x16& x, f32x16& y) { asm volatile("s_nop 15\n\ts_nop 3" : "+a"(x), "+a"(y)); }
+__device__ __forceinline__ void tiles_settle(f32x16& x, f32x16& y) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(x), "+v"(y)); }
 template <int OWNED, int OFF, int COUNT>
 __device__ __forceinline__ void owned_zero() {
     static_for<COUNT>([&](auto r) { OWNED_ASM(OWNED, "v_accvgpr_write_b32 a[%c0], 0" ::"i"(256 - OWNED + OFF + r.value)); });
@@ -499,6 +528,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(int B, int S, int H
         }
 
     const LaneOff<D> lo = lane_offsets<D>(lane);
+    const unsigned lds0 = (unsigned)(unsigned long long)LDS_PTR(smem);
     int cstage = 0;
     for (int qb = qb_hi - 1; qb >= qb_lo; --qb) {
         const int q0 = qb * 128;
@@ -543,6 +573,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(int B, int S, int H
             auto tile_body = [&](auto bc) {
                 constexpr bool BOUNDARY = decltype(bc)::value;
                 bf16x8 f[RING] = {};
+                TrHalves ft[RING] = {};
                 f32x16 sacc[2], pacc[2];
                 unsigned dsw[2][8] = {};  // packed dS^T: words 4s..4s+3 of sub-tile st are the B operand of k-step s
                 float dsv[16];
@@ -553,9 +584,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(int B, int S, int H
                         constexpr int st = g / NA, ks = (g % NA) / 2, which = g % 2;
                         f[g % RING] = lds_frag(smem, which ? vvx[ks] : vkx[ks], st * 32 * C::ROWB);
                     } else if constexpr (g < NG) {
-                        constexpr int h = g - 2 * NA, st = h / NC, sd = (h % NC) / DT, dt = h % DT;
-                        if constexpr (UNI) f[g % RING] = lds_frag_tr_uni<D>(smem, vkt[dt], (st * 32 + 16 * sd) * C::ROWB);
-                        else f[g % RING] = lds_frag_tr<D>(smem, vkt[dt], (st * 32 + 16 * sd) * C::ROWB);
+                        constexpr int h = g - 2 * NA, st = h / NC, sd = (h % NC) / DT, dt = h % DT, imm = (st * 32 + 16 * sd) * C::ROWB;
+                        tr_issue<imm, imm + 8 * C::ROWB>(ft[g % RING], lds0 + vkt[dt], lds0 + (UNI ? vkt[dt] ^ 0x20 : vkt[dt]));
                     }
                 };
                 auto element = [&](auto stc, auto ec) {
@@ -585,7 +615,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(int B, int S, int H
                     } else if constexpr (!(ATTN_ABL & 4)) {
                         constexpr int h = g - 2 * NA, st = h / NC, sd = (h % NC) / DT, dt = h % DT;
                         const u32x4 w = {dsw[st][4 * sd], dsw[st][4 * sd + 1], dsw[st][4 * sd + 2], dsw[st][4 * sd + 3]};
-                        mfma_owned<OWNED, 16 * dt>(f[g % RING], __builtin_bit_cast(bf16x8, w));
+                        constexpr int younger = NG - 1 - g < PD ? NG - 1 - g : PD;
+                        mfma_owned<OWNED, 16 * dt>(tr_wait<2 * younger>(ft[g % RING]), __builtin_bit_cast(bf16x8, w));
                     }
                     // B(0) rides on the MFMAs of A(1), B(1) on those of C(0)
                     if constexpr (g == NA) tiles_settle(sacc[0], pacc[0]);
@@ -608,7 +639,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(int B, int S, int H
             constexpr int dt = i.value / 4, g4 = i.value % 4, r = 16 * dt + 4 * g4;
             const int d = dt * 32 + 8 * g4 + 4 * (lane >> 5);
             const u32x2 pk = {pack_bf2(owned_read<OWNED, r>(), owned_read<OWNED, r + 1>()), pack_bf2(owned_read<OWNED, r + 2>(), owned_read<OWNED, r + 3>())};
-            if (qvalid) *reinterpret_cast<u32x2*>(row + d) = pk;
+            if (qvalid && !(abl & 2)) *reinterpret_cast<u32x2*>(row + d) = pk;
         });
     }
 }
@@ -684,13 +715,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
         istage = istage == NST - 1 ? 0 : istage + 1;
         return true;
     };
+    [[maybe_unused]] const bool prof_on = threadIdx.x == 0;
+    [[maybe_unused]] unsigned long long prof_acc[8] = {};
+    [[maybe_unused]] const unsigned long long t_wg = PROF_T();
     int inflight = 0;
     inflight += issue_next();
     inflight += issue_next();
 
     const LaneOff<D> lo = lane_offsets<D>(lane);
+    const unsigned lds0 = (unsigned)(unsigned long long)LDS_PTR(smem);
     int cstage = 0;
     for (int kb = kb_lo; kb < kb_hi; ++kb) {
+        [[maybe_unused]] const unsigned long long t_pro = PROF_T();
         const int k0 = kb * 128;
         const int kg = k0 + wave * 32 + (lane & 31);
         const bool kvalid = kg < S;
@@ -706,12 +742,25 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
         const int qt0 = qt0_of(kb);
         const int per_head = nqt_all - qt0;
         const int nit = per_head * rep;
+        PROF_ADD(3, t_pro);
         for (int it = 0; it < nit; ++it) {
             // this wave's pieces of the tile have landed (a younger tile may stay in flight), then everybody's
+            [[maybe_unused]] const unsigned long long t_w = PROF_T();
             if (inflight >= 2) wait_vmcnt<PIECES + 1>(); else wait_vmcnt<0>();
+            PROF_ADD(1, t_w);
+            [[maybe_unused]] const unsigned long long t_b = PROF_T();
             __builtin_amdgcn_s_barrier();
+            PROF_ADD(6, t_b);
             --inflight;
+            [[maybe_unused]] const unsigned long long t_i = PROF_T();
             if (!(abl & 1)) inflight += issue_next();  // into the stage that was consumed before this barrier
+            PROF_ADD(7, t_i);
+#if ATTN_ABL & 16
+            struct BodyTimer {
+                unsigned long long t0; bool on; unsigned long long* acc;
+                __device__ ~BodyTimer() { if (on) { acc[2] += __builtin_readcyclecounter() - t0; acc[5] += 1; } }
+            } body_timer{PROF_T(), prof_on, prof_acc};
+#endif
             const int qt = qt0 + it % per_head;
             const int qroff = cstage * STAGE, qtoff = UNI ? qroff : qroff + C::TILE, oroff = qroff + OIMG, otoff = UNI ? oroff : oroff + C::TILE;
             const float* rc = reinterpret_cast<const float*>(rowc + cstage * 512) + 4 * (lane >> 5);
@@ -735,6 +784,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
             auto tile_body = [&](auto bc) {
                 constexpr bool BOUNDARY = decltype(bc)::value;
                 bf16x8 f[RING] = {};
+                TrHalves ft[RING] = {};
                 f32x16 sacc[2], pacc[2];
                 unsigned pw[2][8] = {}, dsw[2][8] = {};  // packed P / dS: words 4s..4s+3 of sub-tile st are the B operand of k-step s
                 float pv[16], dsv[16], l2r[16], dlr[16];
@@ -746,8 +796,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
                         f[g % RING] = lds_frag(smem, which ? vox[ks] : vqx[ks], st * 32 * C::ROWB);
                     } else if constexpr (g < NG) {
                         constexpr int h = g - 2 * NA, st = h / NC, sd = (h % NC) / (2 * DT), dt = (h % (2 * DT)) / 2, which = h % 2;
-                        if constexpr (UNI) f[g % RING] = lds_frag_tr_uni<D>(smem, which ? vqt[dt] : vot[dt], (st * 32 + 16 * sd) * C::ROWB);
-                        else f[g % RING] = lds_frag_tr<D>(smem, which ? vqt[dt] : vot[dt], (st * 32 + 16 * sd) * C::ROWB);
+                        constexpr int imm = (st * 32 + 16 * sd) * C::ROWB;
+                        const int va = which ? vqt[dt] : vot[dt];
+                        tr_issue<imm, imm + 8 * C::ROWB>(ft[g % RING], lds0 + va, lds0 + (UNI ? va ^ 0x20 : va));
                     }
                 };
                 // per-query constants of the 16 accumulator rows of sub-tile st: rows 8*g4 + 4*h + 0..3
@@ -791,12 +842,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
                         else mfma_ownedB<OWNED, VF0 + 4 * ks, ks == 0>(pacc[st], f[g % RING]);
                     } else if constexpr (!(ATTN_ABL & 4)) {
                         constexpr int h = g - 2 * NA, st = h / NC, sd = (h % NC) / (2 * DT), dt = (h % (2 * DT)) / 2, which = h % 2;
+                        constexpr int younger = NG - 1 - g < PD ? NG - 1 - g : PD;
+                        const bf16x8 fa = tr_wait<2 * younger>(ft[g % RING]);
                         if constexpr (which == 0) {
                             const u32x4 w = {pw[st][4 * sd], pw[st][4 * sd + 1], pw[st][4 * sd + 2], pw[st][4 * sd + 3]};
-                            mfma_owned<OWNED, 16 * dt>(f[g % RING], __builtin_bit_cast(bf16x8, w));
+                            mfma_owned<OWNED, 16 * dt>(fa, __builtin_bit_cast(bf16x8, w));
                         } else {
                             const u32x4 w = {dsw[st][4 * sd], dsw[st][4 * sd + 1], dsw[st][4 * sd + 2], dsw[st][4 * sd + 3]};
-                            mfma_owned<OWNED, DK0 + 16 * dt>(f[g % RING], __builtin_bit_cast(bf16x8, w));
+                            mfma_owned<OWNED, DK0 + 16 * dt>(fa, __builtin_bit_cast(bf16x8, w));
                         }
                     }
                     // B(0) rides on the MFMAs of A(1), B(1) on those of C(0)
@@ -817,6 +870,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
             if (boundary) tile_body(std::true_type{});
             else tile_body(std::false_type{});
         }
+        [[maybe_unused]] const unsigned long long t_epi = PROF_T();
         owned_settle<OWNED>();
         bf16_t* krow = dk + ((int64_t)b * S + kg) * lddk + (int64_t)hkv * D;
         bf16_t* vrow = dv + ((int64_t)b * S + kg) * lddv + (int64_t)hkv * D;
@@ -825,12 +879,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
             const int d = dt * 32 + 8 * g4 + 4 * (lane >> 5);
             const u32x2 a = {pack_bf2(owned_read<OWNED, rk>(), owned_read<OWNED, rk + 1>()), pack_bf2(owned_read<OWNED, rk + 2>(), owned_read<OWNED, rk + 3>())};
             const u32x2 c = {pack_bf2(owned_read<OWNED, rv>(), owned_read<OWNED, rv + 1>()), pack_bf2(owned_read<OWNED, rv + 2>(), owned_read<OWNED, rv + 3>())};
-            if (kvalid) {
+            if (kvalid && !(abl & 2)) {
                 *reinterpret_cast<u32x2*>(krow + d) = a;
                 *reinterpret_cast<u32x2*>(vrow + d) = c;
             }
         });
+        PROF_ADD(4, t_epi);
     }
+    PROF_ADD(0, t_wg);
+#if ATTN_ABL & 16
+    if (prof_on)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_prof[i], prof_acc[i]);
+#endif
 }
 
 int check_common(const char* name, int B, int S, int Hq, int Hkv, int D) {
@@ -840,6 +900,18 @@ int check_common(const char* name, int B, int S, int Hq, int Hkv, int D) {
 }
 
 }  // namespace
+
+#if ATTN_ABL & 16
+extern "C" int mi355_debug_prof(unsigned long long* out, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 2;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return 3;
+    }
+    return 0;
+}
+#endif
 
 extern "C" int mi355_attn_fwd(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk,
                               const void* v, int64_t ldv, void* o, int64_t ldo, float* lse, const uint8_t* key_mask,
