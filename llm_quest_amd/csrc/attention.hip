@@ -206,6 +206,10 @@ __device__ __forceinline__ void load_rows_frag(const bf16_t* base, int64_t ld, i
 #define AGPR_CL_96 AGPR_CL_64, "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191"
 #define AGPR_CL_128 AGPR_CL_96, "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159"
 #define AGPR_CL_192 AGPR_CL_128, "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"
+#ifndef ATTN_RING
+#define ATTN_RING 8   // fragment-ring slots of the backward kernels
+#define ATTN_PD 6     // fragments requested ahead of the MFMA that consumes them (2 * PD <= 15: lgkmcnt is 4 bits)
+#endif
 #ifndef ATTN_ABL
 #define ATTN_ABL 0  // profiling builds only: 1 = no fragment reads, 2 = no B phase, 4 = no C MFMAs, 8 = no A MFMAs
 #endif
@@ -477,7 +481,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(int B, int S, int H
     constexpr int KS = C::KS, DT = C::DT;
     constexpr int NA = 2 * KS, NC = 2 * DT, NG = 2 * NA + 2 * NC;  // MFMAs of one A part, one C part, one key tile
     constexpr int OWNED = 16 * DT + 8 * KS, QF0 = 16 * DT, OF0 = QF0 + 4 * KS;  // dQ^T tiles | Q rows | dO rows
-    constexpr int RING = 8, PD = 6;
+    constexpr int RING = ATTN_RING, PD = ATTN_PD;
     // LDS: NST stages x (K [unified] | V rows)  or, D = 64,  (K rows | K transposed | V rows);  then the key-mask words
     constexpr bool UNI = C::UNI;
     constexpr int NIMG = UNI ? 2 : 3, NST = 3, STAGE = NIMG * C::TILE, PIECES = NIMG * C::PPW, VIMG = (NIMG - 1) * C::TILE;
@@ -591,16 +595,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(int B, int S, int H
                 auto element = [&](auto stc, auto ec) {
                     constexpr int st = stc.value, e = ec.value;
                     if constexpr (ATTN_ABL & 2) return;
-                    float p;
+                    float t = fmaf(sacc[st][e], scale_log2, -lse2);
                     if constexpr (BOUNDARY) {
                         const int kl = st * 32 + acc_row(e, lane);
                         const int kg = kt * 64 + kl;
                         const bool masked = (causal && kg > qg) || !((kbits >> kl) & 1ull) || kg >= S;
-                        p = masked ? 0.f : __builtin_amdgcn_exp2f(fmaf(sacc[st][e], scale_log2, -lse2));
-                    } else {
-                        p = __builtin_amdgcn_exp2f(fmaf(sacc[st][e], scale_log2, -lse2));
+                        t = masked ? -INFINITY : t;  // exp2(-inf) = 0: no branch around the exp
                     }
-                    dsv[e] = p * (pacc[st][e] - dlt) * scale;  // dS^T (gradient w.r.t. the raw QK^T product)
+                    dsv[e] = __builtin_amdgcn_exp2f(t) * (pacc[st][e] - dlt);  // dS^T / scale (the factor is applied to dQ once)
                     if constexpr (e % 2 == 1) dsw[st][e / 2] = pack_bf2(dsv[e - 1], dsv[e]);
                 };
                 static_for<PD>([&](auto g) { load(g); });
@@ -628,6 +630,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(int B, int S, int H
                         constexpr int m = g - 2 * NA, per = 16 / NC;
                         static_for<per>([&](auto i) { element(std::integral_constant<int, 1>{}, std::integral_constant<int, m * per + i.value>{}); });
                     }
+                    // keep this step's VALU where it is written: left alone, hipcc gathers a whole B phase into one MFMA gap
+                    __builtin_amdgcn_sched_barrier(0);
                 });
             };
             if (boundary) tile_body(std::true_type{});
@@ -638,7 +642,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(int B, int S, int H
         static_for<DT * 4>([&](auto i) {
             constexpr int dt = i.value / 4, g4 = i.value % 4, r = 16 * dt + 4 * g4;
             const int d = dt * 32 + 8 * g4 + 4 * (lane >> 5);
-            const u32x2 pk = {pack_bf2(owned_read<OWNED, r>(), owned_read<OWNED, r + 1>()), pack_bf2(owned_read<OWNED, r + 2>(), owned_read<OWNED, r + 3>())};
+            const u32x2 pk = {pack_bf2(owned_read<OWNED, r>() * scale, owned_read<OWNED, r + 1>() * scale),
+                              pack_bf2(owned_read<OWNED, r + 2>() * scale, owned_read<OWNED, r + 3>() * scale)};
             if (qvalid && !(abl & 2)) *reinterpret_cast<u32x2*>(row + d) = pk;
         });
     }
@@ -663,7 +668,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
     constexpr int KS = C::KS, DT = C::DT;
     constexpr int NA = 2 * KS, NC = 4 * DT, NG = 2 * NA + 2 * NC;
     constexpr int OWNED = 32 * DT + 8 * KS, DK0 = 16 * DT, KF0 = 32 * DT, VF0 = KF0 + 4 * KS;  // dV^T | dK^T | K rows | V rows
-    constexpr int RING = 8, PD = 6;
+    constexpr int RING = ATTN_RING, PD = ATTN_PD;
     // LDS: NST stages x (Q | dO [unified images])  or, D = 64,  (Q rows | Q transposed | dO rows | dO transposed);
     // then NST x 64 x (lse, delta)
     constexpr bool UNI = C::UNI;
@@ -716,7 +721,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
         return true;
     };
     [[maybe_unused]] const bool prof_on = threadIdx.x == 0;
-    [[maybe_unused]] unsigned long long prof_acc[8] = {};
+    [[maybe_unused]] unsigned long long prof_acc[16] = {};
     [[maybe_unused]] const unsigned long long t_wg = PROF_T();
     int inflight = 0;
     inflight += issue_next();
@@ -798,7 +803,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
                         constexpr int h = g - 2 * NA, st = h / NC, sd = (h % NC) / (2 * DT), dt = (h % (2 * DT)) / 2, which = h % 2;
                         constexpr int imm = (st * 32 + 16 * sd) * C::ROWB;
                         const int va = which ? vqt[dt] : vot[dt];
-                        tr_issue<imm, imm + 8 * C::ROWB>(ft[g % RING], lds0 + va, lds0 + (UNI ? va ^ 0x20 : va));
+                        if constexpr (!(ATTN_ABL & 32)) tr_issue<imm, imm + 8 * C::ROWB>(ft[g % RING], lds0 + va, lds0 + (UNI ? va ^ 0x20 : va));
                     }
                 };
                 // per-query constants of the 16 accumulator rows of sub-tile st: rows 8*g4 + 4*h + 0..3
@@ -815,24 +820,29 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
                 auto element = [&](auto stc, auto ec) {
                     constexpr int st = stc.value, e = ec.value;
                     if constexpr (ATTN_ABL & 2) return;
-                    float p;
+                    float t = fmaf(sacc[st][e], scale_log2, -l2r[e]);
                     if constexpr (BOUNDARY) {
                         const int qq = qt * 64 + st * 32 + acc_row(e, lane);
                         const bool masked = (causal && kg > qq) || !kreal || qq >= S;
-                        p = masked ? 0.f : __builtin_amdgcn_exp2f(fmaf(sacc[st][e], scale_log2, -l2r[e]));
-                    } else {
-                        p = __builtin_amdgcn_exp2f(fmaf(sacc[st][e], scale_log2, -l2r[e]));
+                        t = masked ? -INFINITY : t;  // exp2(-inf) = 0: no branch around the exp
                     }
+                    const float p = __builtin_amdgcn_exp2f(t);
                     pv[e] = p;
-                    dsv[e] = p * (pacc[st][e] - dlr[e]) * scale;
+                    dsv[e] = p * (pacc[st][e] - dlr[e]);  // dS / scale (the factor is applied to dK once)
                     if constexpr (e % 2 == 1) {
                         pw[st][e / 2] = pack_bf2(pv[e - 1], pv[e]);
                         dsw[st][e / 2] = pack_bf2(dsv[e - 1], dsv[e]);
                     }
                 };
                 static_for<PD>([&](auto g) { load(g); });
+                [[maybe_unused]] unsigned long long t_seg = PROF_T();
                 static_for<NG>([&](auto gc) {
                     constexpr int g = gc.value;
+#if ATTN_ABL & 16
+                    if constexpr (g == NA || g == 2 * NA || g == 2 * NA + NC) {
+                        if (prof_on) { const unsigned long long now = __builtin_readcyclecounter(); prof_acc[8 + (g == NA ? 0 : g == 2 * NA ? 1 : 2)] += now - t_seg; t_seg = now; }
+                    }
+#endif
                     if constexpr (g == NA - 1) row_constants(std::integral_constant<int, 0>{});
                     load(std::integral_constant<int, g + PD>{});
                     if constexpr (g < 2 * NA) {
@@ -844,7 +854,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
                         constexpr int h = g - 2 * NA, st = h / NC, sd = (h % NC) / (2 * DT), dt = (h % (2 * DT)) / 2, which = h % 2;
                         constexpr int younger = NG - 1 - g < PD ? NG - 1 - g : PD;
                         const bf16x8 fa = tr_wait<2 * younger>(ft[g % RING]);
-                        if constexpr (which == 0) {
+                        if constexpr (ATTN_ABL & 64) {  // profiling: same MFMA count into a VGPR tile with an AGPR B operand
+                            mfma_ownedB<OWNED, KF0, false>(sacc[(g / 2) % 2], fa);
+                        } else if constexpr (ATTN_ABL & 128) {  // profiling: owned accumulators but a fixed B operand
+                            if constexpr (ATTN_ABL & 256) {  // ... with the B phase kept alive
+                                const u32x4 w = {pw[st][4 * sd], dsw[st][4 * sd + 1], pw[st][4 * sd + 2], dsw[st][4 * sd + 3]};
+                                asm volatile("" ::"v"(w));
+                            }
+                            mfma_owned<OWNED, (which ? DK0 : 0) + 16 * dt>(fa, f[0]);
+                        } else if constexpr (which == 0) {
                             const u32x4 w = {pw[st][4 * sd], pw[st][4 * sd + 1], pw[st][4 * sd + 2], pw[st][4 * sd + 3]};
                             mfma_owned<OWNED, 16 * dt>(fa, __builtin_bit_cast(bf16x8, w));
                         } else {
@@ -865,7 +883,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
                             if constexpr (m * per + i.value < 16) element(std::integral_constant<int, 1>{}, std::integral_constant<int, m * per + i.value>{});
                         });
                     }
+                    // keep this step's VALU where it is written: left alone, hipcc gathers a whole B phase into one MFMA gap
+                    __builtin_amdgcn_sched_barrier(0);
                 });
+                PROF_ADD(11, t_seg);
             };
             if (boundary) tile_body(std::true_type{});
             else tile_body(std::false_type{});
@@ -877,7 +898,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
         static_for<DT * 4>([&](auto i) {
             constexpr int dt = i.value / 4, g4 = i.value % 4, rv = 16 * dt + 4 * g4, rk = DK0 + rv;
             const int d = dt * 32 + 8 * g4 + 4 * (lane >> 5);
-            const u32x2 a = {pack_bf2(owned_read<OWNED, rk>(), owned_read<OWNED, rk + 1>()), pack_bf2(owned_read<OWNED, rk + 2>(), owned_read<OWNED, rk + 3>())};
+            const u32x2 a = {pack_bf2(owned_read<OWNED, rk>() * scale, owned_read<OWNED, rk + 1>() * scale),
+                             pack_bf2(owned_read<OWNED, rk + 2>() * scale, owned_read<OWNED, rk + 3>() * scale)};
             const u32x2 c = {pack_bf2(owned_read<OWNED, rv>(), owned_read<OWNED, rv + 1>()), pack_bf2(owned_read<OWNED, rv + 2>(), owned_read<OWNED, rv + 3>())};
             if (kvalid && !(abl & 2)) {
                 *reinterpret_cast<u32x2*>(krow + d) = a;
@@ -889,7 +911,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
     PROF_ADD(0, t_wg);
 #if ATTN_ABL & 16
     if (prof_on)
-        for (int i = 0; i < 8; ++i) atomicAdd(&g_prof[i], prof_acc[i]);
+        for (int i = 0; i < 16; ++i) atomicAdd(&g_prof[i], prof_acc[i]);
 #endif
 }
 

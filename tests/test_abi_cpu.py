@@ -67,3 +67,26 @@ def test_no_cpu_fallback():
     w = torch.ones(1024, dtype=torch.bfloat16)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         kernels.rmsnorm_fwd(x, w)
+
+
+def test_attention_backward_owned_agprs_are_untouched_by_the_compiler(tmp_path):
+    """attention.hip owns the top AGPRs of its backward kernels by name (gradient tiles + resident operands).  The generated
+    code must not name a register of those ranges outside the kernels' own asm statements (tools/audit_agpr.py)."""
+    import importlib.util
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "llm_quest_amd", "csrc", "attention.hip")
+    out = tmp_path / "attention.s"
+    res = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-S", "--cuda-device-only",
+                          "-o", str(out), src], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    spec = importlib.util.spec_from_file_location("audit_agpr", os.path.join(ROOT, "tools", "audit_agpr.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad, seen = mod.audit(str(out))
+    assert not bad, bad[:5]
+    assert set(seen) == set(mod.OWNED), seen

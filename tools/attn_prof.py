@@ -19,4 +19,5 @@ for rep in range(2):
 names = ["wg total", "vmcnt wait", "tile body", "block prologue", "block epilogue", "tiles", "barrier", "issue"]
 nwg = B * Hkv
 for i, n in enumerate(names): print(f"{n:16s} {out[i]/nwg:12.0f} per WG")
+print("segments per tile: A0 %.0f  A1|B0 %.0f  C0|B1 %.0f  C1 %.0f" % tuple(out[8 + i] / max(out[5], 1) for i in range(4)))
 print(f"per tile: body {out[2]/max(out[5],1):.0f} cycles, wait {out[1]/max(out[5],1):.0f}, barrier {out[6]/max(out[5],1):.0f}, issue {out[7]/max(out[5],1):.0f}")
