@@ -441,23 +441,29 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int B, int S, int Hq, 
 }
 
 // ================================================================================================ backward
-// delta[b,h,q] = sum_d dO[q,d] * O[q,d]   (one wave per (token, head))
+// delta[b,h,q] = sum_d dO[q,d] * O[q,d].  HBM-bound: 16-byte loads, D/8 lanes per (token, head) row, so one wave covers
+// 512/D adjacent heads of a token (contiguous in the token-major operands) per 1-KiB load instruction.
 template <int D>
 __global__ __launch_bounds__(256) void attn_delta_kernel(int B, int S, int Hq, const bf16_t* __restrict__ o, int64_t ldo,
                                                          const bf16_t* __restrict__ d_o, int64_t lddo, float* __restrict__ delta) {
-    const int lane = threadIdx.x & 63;
-    const int64_t total = (int64_t)B * S * Hq;
+    constexpr int LPR = D / 8, RPW = 64 / LPR;  // lanes per row, rows (heads) per wave-instruction
+    const int lane = threadIdx.x & 63, sub = lane / LPR, li = lane % LPR;
+    const int hgroups = (Hq + RPW - 1) / RPW;
+    const int64_t total = (int64_t)B * S * hgroups;
     for (int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); item < total; item += (int64_t)gridDim.x * 4) {
-        const int64_t tok = item / Hq;
-        const int h = (int)(item - tok * Hq);
+        const int64_t tok = item / hgroups;
+        const int h = (int)(item - tok * hgroups) * RPW + sub;
         float s = 0.f;
-        for (int c = lane * 2; c < D; c += 128) {
-            const unsigned a = *reinterpret_cast<const unsigned*>(o + tok * ldo + (int64_t)h * D + c);
-            const unsigned g = *reinterpret_cast<const unsigned*>(d_o + tok * lddo + (int64_t)h * D + c);
-            s += __uint_as_float(a << 16) * __uint_as_float(g << 16) + __uint_as_float(a & 0xffff0000u) * __uint_as_float(g & 0xffff0000u);
+        if (h < Hq) {
+            const u32x4 a = *reinterpret_cast<const u32x4*>(o + tok * ldo + (int64_t)h * D + li * 8);
+            const u32x4 g = *reinterpret_cast<const u32x4*>(d_o + tok * lddo + (int64_t)h * D + li * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                s += __uint_as_float(a[e] << 16) * __uint_as_float(g[e] << 16) + __uint_as_float(a[e] & 0xffff0000u) * __uint_as_float(g[e] & 0xffff0000u);
         }
-        s = wave_sum(s);
-        if (lane == 0) {
+#pragma unroll
+        for (int off = LPR / 2; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (li == 0 && h < Hq) {
             const int64_t bb = tok / S, sq = tok - bb * S;
             delta[(bb * Hq + h) * S + sq] = s;
         }
@@ -961,10 +967,11 @@ extern "C" int mi355_attn_bwd(int B, int S, int Hq, int Hkv, int D, const void* 
     if (check_common("mi355_attn_bwd", B, S, Hq, Hkv, D)) return 1;
     MI355_REQUIRE(q && k && v && o && d_o && lse && delta && dq && dk && dv, "mi355_attn_bwd: null pointer");
     MI355_REQUIRE(((ldq | ldk | ldv | ldo | lddo | lddq | lddk | lddv) & 7) == 0, "mi355_attn_bwd: leading dimensions must be multiples of 8");
+    MI355_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)d_o) & 15) == 0, "mi355_attn_bwd: operands must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const float sl2 = scale * LOG2E;
-    const int64_t items = (int64_t)B * S * Hq;
-    const int dgrid = (int)((items + 3) / 4 > 2048 ? 2048 : (items + 3) / 4);
+    const int64_t items = (int64_t)B * S * ((Hq + 512 / D - 1) / (512 / D));
+    const int dgrid = (int)((items + 3) / 4 > 8192 ? 8192 : (items + 3) / 4);
     // enough (batch, head) pairs to fill the chip twice over: one workgroup walks all blocks of its pair (no per-block launch,
     // prologue and first-tile latency); otherwise one block per workgroup for parallelism
     const int nblk = (S + 127) / 128;

@@ -351,6 +351,87 @@ def gen_qwen35(out):
     _save(os.path.join(out, "qwen35_vision_tiny.safetensors"), t, "Qwen3.5 vision tower (tiny) + wrapper index fixtures")
 
 
+TINY_Q35_TEXT = dict(
+    vocab_size=256, emb_dim=64, hidden_dim=128, n_layers=4, linear_sdpa_ratio=2, n_heads=2, num_kv_groups=1, head_dim=32,
+    rope_base=10_000_000, partial_rope_factor=0.5, context_length=64, linear_num_qk_heads=2, linear_num_value_heads=4,
+    linear_qk_head_dim=16, linear_value_head_dim=16, linear_conv_kernel_size=4, tie_embeddings=True, p_dropout=0.0, training=False,
+    mrope_section=[3, 3, 2],
+)
+
+
+def gen_qwen35_text(out):
+    """BASELINE config 5 text stack: per-op vectors + a tiny hybrid model, bf16 and fp32."""
+    from llm_quest.common.rope import RoPE
+    from llm_quest.qwen.qwen3_5.qwen3_5_text_model import Qwen3_5TextModel
+    from llm_quest.qwen.qwen3_next.qwen3_next_attention import ZeroCenteredRMSNorm, compute_alpha_factor, gated_delta_rule, l2_norm
+
+    t = {}
+    torch.manual_seed(SEED)
+    # --- MRoPE-I axis pattern: per-axis constant tables make the interleave readable as an index map
+    for name, sec in {"s11_11_10": [11, 11, 10], "s2_2_2": [2, 2, 2], "s3_3_2": [3, 3, 2]}.items():
+        half = sum(sec)
+        cos = torch.stack([torch.full((1, 1, half), float(a)) for a in range(3)])
+        mc, _ = RoPE.interleave_mrope_coeffs(cos, cos.clone(), sec)
+        t[f"mrope.axis.{name}"] = mc[0, 0].to(torch.int32)
+    # --- apply_mrope on random q with 3-axis ids and partial rotation
+    cos, sin = RoPE.compute_angles(10_000_000, 32, 64, rotation_factor=0.5)
+    q = torch.randn(2, 2, 10, 32).to(torch.bfloat16)
+    pid = torch.randint(0, 40, (3, 2, 10))
+    t["mrope.cos"], t["mrope.sin"], t["mrope.q"], t["mrope.pid"] = cos, sin, q, pid
+    t["mrope.out"] = RoPE.apply_mrope(q, cos, sin, pid, [3, 3, 2])
+    # --- small ops
+    x = torch.randn(3, 5, 64).to(torch.bfloat16)
+    norm = ZeroCenteredRMSNorm(64, dtype=torch.bfloat16)
+    with torch.no_grad():
+        norm.scale.copy_(0.1 * torch.randn(64))
+    t["zc.x"], t["zc.scale"], t["zc.out"] = x, norm.scale.detach(), norm(x).detach()
+    v = torch.randn(2, 3, 7, 16)
+    t["l2.x"], t["l2.out"] = v, l2_norm(v)
+    log_A, a, dtb = torch.log(torch.rand(4) * 16), torch.randn(2, 9, 4), torch.ones(4)
+    t["alpha.log_A"], t["alpha.a"], t["alpha.dt_bias"], t["alpha.out"] = log_A, a, dtb, compute_alpha_factor(log_A, a, dtb)
+    # --- gated delta rule (fp32 recurrence on bf16 operands) with gradients
+    qq, kk = (l2_norm(torch.randn(2, 4, 12, 16)).to(torch.bfloat16).requires_grad_(True) for _ in range(2))
+    vv = torch.randn(2, 4, 12, 16).to(torch.bfloat16).requires_grad_(True)
+    beta = torch.rand(2, 4, 12).requires_grad_(True)
+    alpha = (0.5 + 0.5 * torch.rand(2, 4, 12)).requires_grad_(True)
+    o, state = gated_delta_rule(qq, kk, vv, beta, alpha)
+    go = torch.randn_like(o.float())
+    (o.float() * go).sum().backward()
+    for n_, ten in (("q", qq), ("k", kk), ("v", vv), ("beta", beta), ("alpha", alpha)):
+        t["gdr." + n_], t["gdr.grad." + n_] = ten.detach(), ten.grad
+    t["gdr.out"], t["gdr.state"], t["gdr.gout"] = o.detach(), state.detach(), go
+    # --- tiny hybrid model: layers 0, 2 FusedGatedDeltaNet, layers 1, 3 MRoPEGatedAttention
+    ids = torch.randint(0, 256, (2, 24))
+    am = torch.ones(2, 24, dtype=torch.bool)
+    am[0, 20:] = False
+    pid = torch.arange(24).view(1, 1, 24).repeat(3, 2, 1)
+    pid[1, :, 6:14] = 6 + torch.arange(8) // 4  # an "image" span: H / W advance on their own grid
+    pid[2, :, 6:14] = 6 + torch.arange(8) % 4
+    pid[:, :, 14:] -= 4
+    t["txt.ids"], t["txt.attn_mask"], t["txt.pid"] = ids, am.to(torch.uint8), pid
+    g = None
+    for tag, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+        torch.manual_seed(SEED + 7)
+        m = Qwen3_5TextModel({**TINY_Q35_TEXT, "dtype": dt}).train()
+        with torch.no_grad():
+            for n_, p_ in m.named_parameters():
+                if n_.endswith("scale") or n_.endswith("post_norm.weight") or n_.endswith("dt_bias"):
+                    p_.add_((0.1 * torch.randn(p_.shape)).to(p_.dtype))
+        logits = m(ids, attn_mask=am, position_ids=pid)
+        if g is None:
+            g = torch.randn(logits.shape)
+        (logits.float() * g).sum().backward()
+        with torch.no_grad():
+            t[f"txt.{tag}.logits_text_only"] = m(ids)
+        for k_, v_ in m.state_dict().items():
+            t[f"txt.{tag}.sd." + k_] = v_.to(torch.uint8) if v_.dtype == torch.bool else v_
+        t[f"txt.{tag}.logits"] = logits.detach()
+        for n_, p_ in m.named_parameters():
+            t[f"txt.{tag}.grad." + n_] = p_.grad
+    t["txt.gout"] = g
+    _save(os.path.join(out, "qwen35_text_tiny.safetensors"), t, "Qwen3.5 text stack (tiny hybrid GDN / gated attention) + per-op vectors")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -361,7 +442,7 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
     only = os.environ.get("GOLDEN_ONLY")
-    for fn in (gen_index, gen_ops, gen_qwen, gen_vit, gen_vlm, gen_gpt, gen_qwen35):
+    for fn in (gen_index, gen_ops, gen_qwen, gen_vit, gen_vlm, gen_gpt, gen_qwen35, gen_qwen35_text):
         if only and fn.__name__ != only:
             continue
         fn(args.out)

@@ -5,6 +5,7 @@ bit-identical on the CPU too (same ATen ops in the same order), with a tiny tole
 """
 
 import numpy as np
+import pytest
 import torch
 
 from conftest import sub_dict
@@ -231,3 +232,67 @@ def test_qwen35_vision_tower(golden):
             close(sd[k].grad, g, rtol=1e-4, atol=2e-5)
         else:
             close(sd[k].grad, g, rtol=1e-4, atol=2e-5)
+
+
+# ----------------------------------------------------------------------------- BASELINE config 5: Qwen3.5 text stack (a24)
+def test_qwen35_text_index_and_small_ops(golden):
+    from oracle import qwen3_5_text as q35t
+
+    t = golden("qwen35_text_tiny")
+    for name, sec in {"s11_11_10": [11, 11, 10], "s2_2_2": [2, 2, 2], "s3_3_2": [3, 3, 2]}.items():
+        assert np.array_equal(q35t.mrope_axis_of_frequency(sec, sum(sec)), t[f"mrope.axis.{name}"].numpy()), name
+    # the pattern SURVEY.md records for [11, 11, 10]: [T, H, W] x 10, then T, H
+    assert q35t.mrope_axis_of_frequency([11, 11, 10], 32).tolist() == [0, 1, 2] * 10 + [0, 1]
+    c, s = q35t.mrope_coeffs(t["mrope.cos"], t["mrope.sin"], t["mrope.pid"], [3, 3, 2])
+    q = t["mrope.q"]
+    out = q35t.rope_partial(q, c.unsqueeze(1).to(q.dtype), s.unsqueeze(1).to(q.dtype))
+    assert torch.equal(out, t["mrope.out"])
+    assert torch.equal(q35t.zc_rmsnorm(t["zc.x"], t["zc.scale"]), t["zc.out"])
+    assert torch.equal(q35t.l2_norm(t["l2.x"]), t["l2.out"])
+    assert torch.equal(q35t.alpha_factor(t["alpha.log_A"], t["alpha.a"], t["alpha.dt_bias"]), t["alpha.out"])
+
+
+def test_qwen35_gated_delta_rule(golden):
+    from oracle import qwen3_5_text as q35t
+
+    t = golden("qwen35_text_tiny")
+    ins = [t["gdr." + n].clone().requires_grad_(True) for n in ("q", "k", "v", "beta", "alpha")]
+    o, state = q35t.gated_delta_rule(*ins)
+    assert torch.equal(o, t["gdr.out"]) and torch.equal(state, t["gdr.state"])
+    (o.float() * t["gdr.gout"]).sum().backward()
+    for n, x in zip(("q", "k", "v", "beta", "alpha"), ins):
+        assert torch.allclose(x.grad.float(), t["gdr.grad." + n].float(), rtol=1e-5, atol=1e-6), n
+
+
+@pytest.mark.parametrize("tag", ["fp32", "bf16"])
+def test_qwen35_text_tiny(golden, tag):
+    from oracle import qwen3_5_text as q35t
+    from oracle.gen_golden import TINY_Q35_TEXT
+
+    t = golden("qwen35_text_tiny")
+    cfg = dict(TINY_Q35_TEXT)
+    sd = {}
+    for k, v in sub_dict(t, f"txt.{tag}.sd.").items():
+        if k == "mask":
+            sd[k] = v.bool()
+        elif k == "out_head.weight":
+            continue  # tied to emb_dict.weight
+        else:
+            sd[k] = v.clone().requires_grad_(v.is_floating_point() and k not in ("cos", "sin"))
+    ids, am, pid = t["txt.ids"], t["txt.attn_mask"].bool(), t["txt.pid"]
+    logits = q35t.text_model_forward(sd, cfg, x=ids, attn_mask=am, position_ids=pid)
+    ref = t[f"txt.{tag}.logits"]
+    assert logits.dtype == ref.dtype
+    tol = 1e-5 if tag == "fp32" else 2e-2  # bf16: same ops, but ATen's fused SDPA / linear kernels may order sums differently
+    assert (logits.float() - ref.float()).norm() <= tol * ref.float().norm()
+    (logits.float() * t["txt.gout"]).sum().backward()
+    grads = sub_dict(t, f"txt.{tag}.grad.")
+    assert set(grads) - {"out_head.weight"} <= set(sd)
+    for k, g in grads.items():
+        if k == "out_head.weight":
+            continue
+        got = sd[k].grad.float()
+        assert (got - g.float()).norm() <= (1e-4 if tag == "fp32" else 4e-2) * g.float().norm() + 1e-6, k
+    with torch.no_grad():
+        lo = q35t.text_model_forward(sd, cfg, x=ids)
+    assert (lo.float() - t[f"txt.{tag}.logits_text_only"].float()).norm() <= tol * t[f"txt.{tag}.logits_text_only"].float().norm()
