@@ -246,43 +246,53 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(int64_t tokens, in
     const int H = Hq + Hkv;
     const int groups = (H + G::HPW - 1) / G::HPW;
     const int64_t ld = (int64_t)(Hq + 2 * Hkv) * D;
-    const int64_t total = tokens * groups;
-    for (int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); item < total; item += (int64_t)gridDim.x * 4) {
-        const int64_t t = item / groups;
-        const int h = (int)(item - t * groups) * G::HPW + sub;
-        const bool valid = h < H;
-        const int hh = valid ? h : 0;
-        const bf16_t* src = qkv + t * ld + (int64_t)hh * D;
-        const bf16_t* wgt = hh < Hq ? qw : kw;
-        const bool norm = qw != nullptr;  // qw == kw == NULL: RoPE only (Qwen3.5 vision attention, qwen3_5_vision_model.py:176-177)
-        float x1[4], x2[4], w1[4] = {1.f, 1.f, 1.f, 1.f}, w2[4] = {1.f, 1.f, 1.f, 1.f};
-        unpack4(*reinterpret_cast<const u32x2*>(src + i), x1);
-        unpack4(*reinterpret_cast<const u32x2*>(src + G::HALF + i), x2);
-        float r = 1.0f;
-        if (norm) {
-            unpack4(*reinterpret_cast<const u32x2*>(wgt + i), w1);
-            unpack4(*reinterpret_cast<const u32x2*>(wgt + G::HALF + i), w2);
-            float ss = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ss += x1[e] * x1[e] + x2[e] * x2[e];
-            ss = head_sum<G::LPH>(ss);
-            r = rsqrtf(ss / (float)D + eps);
-        }
+    const bool norm = qw != nullptr;  // qw == kw == NULL: RoPE only (Qwen3.5 vision attention, qwen3_5_vision_model.py:176-177)
+    // per-lane constants of the whole launch: the norm weights of this lane's 2 x 4 features, for q heads and for k heads
+    float wq1[4] = {1.f, 1.f, 1.f, 1.f}, wq2[4] = {1.f, 1.f, 1.f, 1.f}, wk1[4] = {1.f, 1.f, 1.f, 1.f}, wk2[4] = {1.f, 1.f, 1.f, 1.f};
+    if (norm) {
+        unpack4(*reinterpret_cast<const u32x2*>(qw + i), wq1);
+        unpack4(*reinterpret_cast<const u32x2*>(qw + G::HALF + i), wq2);
+        unpack4(*reinterpret_cast<const u32x2*>(kw + i), wk1);
+        unpack4(*reinterpret_cast<const u32x2*>(kw + G::HALF + i), wk2);
+    }
+    // one wave = one token at a time: its rotary coefficients are fetched once and reused by every head of the token
+    for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < tokens; t += (int64_t)gridDim.x * 4) {
         const int64_t p = pos[t];
         const f32x4 c1 = *reinterpret_cast<const f32x4*>(cosT + p * D + i), s1 = *reinterpret_cast<const f32x4*>(sinT + p * D + i);
         const f32x4 c2 = *reinterpret_cast<const f32x4*>(cosT + p * D + G::HALF + i), s2 = *reinterpret_cast<const f32x4*>(sinT + p * D + G::HALF + i);
-        float y1[4], y2[4];
+        float cb1[4], sb1[4], cb2[4], sb2[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float n1 = rbf(x1[e] * r * w1[e]), n2 = rbf(x2[e] * r * w2[e]);
-            y1[e] = rbf(rbf(c1[e]) * n1) + rbf(rbf(s1[e]) * (-n2));
-            y2[e] = rbf(rbf(c2[e]) * n2) + rbf(rbf(s2[e]) * n1);
-        }
-        if (valid) {
-            bf16_t* dst = h < Hq ? qo + t * (int64_t)Hq * D + (int64_t)h * D : ko + t * (int64_t)Hkv * D + (int64_t)(h - Hq) * D;
-            *reinterpret_cast<u32x2*>(dst + i) = pack4(y1);
-            *reinterpret_cast<u32x2*>(dst + G::HALF + i) = pack4(y2);
-            if (i == 0 && rstd) rstd[t * H + h] = r;
+        for (int e = 0; e < 4; ++e) { cb1[e] = rbf(c1[e]); sb1[e] = rbf(s1[e]); cb2[e] = rbf(c2[e]); sb2[e] = rbf(s2[e]); }
+        for (int grp = 0; grp < groups; ++grp) {
+            const int h = grp * G::HPW + sub;
+            const bool valid = h < H;
+            const int hh = valid ? h : 0;
+            const bool isq = hh < Hq;
+            const bf16_t* src = qkv + t * ld + (int64_t)hh * D;
+            float x1[4], x2[4];
+            unpack4(*reinterpret_cast<const u32x2*>(src + i), x1);
+            unpack4(*reinterpret_cast<const u32x2*>(src + G::HALF + i), x2);
+            float r = 1.0f;
+            if (norm) {
+                float ss = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ss += x1[e] * x1[e] + x2[e] * x2[e];
+                ss = head_sum<G::LPH>(ss);
+                r = rsqrtf(ss / (float)D + eps);
+            }
+            float y1[4], y2[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float n1 = rbf(x1[e] * r * (isq ? wq1[e] : wk1[e])), n2 = rbf(x2[e] * r * (isq ? wq2[e] : wk2[e]));
+                y1[e] = rbf(cb1[e] * n1) + rbf(sb1[e] * (-n2));
+                y2[e] = rbf(cb2[e] * n2) + rbf(sb2[e] * n1);
+            }
+            if (valid) {
+                bf16_t* dst = isq ? qo + t * (int64_t)Hq * D + (int64_t)h * D : ko + t * (int64_t)Hkv * D + (int64_t)(h - Hq) * D;
+                *reinterpret_cast<u32x2*>(dst + i) = pack4(y1);
+                *reinterpret_cast<u32x2*>(dst + G::HALF + i) = pack4(y2);
+                if (i == 0 && rstd) rstd[t * H + h] = r;
+            }
         }
     }
 }
@@ -302,56 +312,66 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(int64_t tokens, in
     const int H = Hq + Hkv;
     const int groups = (H + G::HPW - 1) / G::HPW;
     const int64_t ld = (int64_t)(Hq + 2 * Hkv) * D;
-    const int64_t total = tokens * groups;
     for (int j = threadIdx.x; j < 2 * D; j += 256) dw_lds[j] = 0.f;
     __syncthreads();
     float dwq1[4] = {0, 0, 0, 0}, dwq2[4] = {0, 0, 0, 0}, dwk1[4] = {0, 0, 0, 0}, dwk2[4] = {0, 0, 0, 0};
-    for (int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); item < total; item += (int64_t)gridDim.x * 4) {
-        const int64_t t = item / groups;
-        const int h = (int)(item - t * groups) * G::HPW + sub;
-        const bool valid = h < H;
-        const int hh = valid ? h : 0;
-        const bool isq = hh < Hq;
-        const bool norm = qw != nullptr;
-        const bf16_t* src = qkv + t * ld + (int64_t)hh * D;
-        const bf16_t* wgt = isq ? qw : kw;
-        const bf16_t* g = isq ? dq + t * (int64_t)Hq * D + (int64_t)hh * D : dk + t * (int64_t)Hkv * D + (int64_t)(hh - Hq) * D;
-        float x1[4] = {0, 0, 0, 0}, x2[4] = {0, 0, 0, 0}, w1[4] = {1.f, 1.f, 1.f, 1.f}, w2[4] = {1.f, 1.f, 1.f, 1.f}, g1[4], g2[4];
-        if (norm) {
-            unpack4(*reinterpret_cast<const u32x2*>(src + i), x1);
-            unpack4(*reinterpret_cast<const u32x2*>(src + G::HALF + i), x2);
-            unpack4(*reinterpret_cast<const u32x2*>(wgt + i), w1);
-            unpack4(*reinterpret_cast<const u32x2*>(wgt + G::HALF + i), w2);
-        }
-        unpack4(*reinterpret_cast<const u32x2*>(g + i), g1);
-        unpack4(*reinterpret_cast<const u32x2*>(g + G::HALF + i), g2);
-        const float r = norm ? rstd[t * H + hh] : 1.0f;
+    const bool norm = qw != nullptr;
+    float wq1[4] = {1.f, 1.f, 1.f, 1.f}, wq2[4] = {1.f, 1.f, 1.f, 1.f}, wk1[4] = {1.f, 1.f, 1.f, 1.f}, wk2[4] = {1.f, 1.f, 1.f, 1.f};
+    if (norm) {
+        unpack4(*reinterpret_cast<const u32x2*>(qw + i), wq1);
+        unpack4(*reinterpret_cast<const u32x2*>(qw + G::HALF + i), wq2);
+        unpack4(*reinterpret_cast<const u32x2*>(kw + i), wk1);
+        unpack4(*reinterpret_cast<const u32x2*>(kw + G::HALF + i), wk2);
+    }
+    // one wave = one token at a time (rotary coefficients fetched once per token, reused by all its heads)
+    for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < tokens; t += (int64_t)gridDim.x * 4) {
         const int64_t p = pos[t];
         const f32x4 c1 = *reinterpret_cast<const f32x4*>(cosT + p * D + i), s1 = *reinterpret_cast<const f32x4*>(sinT + p * D + i);
         const f32x4 c2 = *reinterpret_cast<const f32x4*>(cosT + p * D + G::HALF + i), s2 = *reinterpret_cast<const f32x4*>(sinT + p * D + G::HALF + i);
-        float dn1[4], dn2[4], xh1[4], xh2[4];
-        float dot = 0.f;
+        float cb1[4], sb1[4], cb2[4], sb2[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            // y1 = c1*n1 - s1*n2 ; y2 = c2*n2 + s2*n1
-            dn1[e] = rbf(c1[e]) * g1[e] + rbf(s2[e]) * g2[e];
-            dn2[e] = rbf(c2[e]) * g2[e] - rbf(s1[e]) * g1[e];
-            xh1[e] = x1[e] * r;
-            xh2[e] = x2[e] * r;
-            dot += dn1[e] * w1[e] * xh1[e] + dn2[e] * w2[e] * xh2[e];
-        }
-        dot = head_sum<G::LPH>(dot) / (float)D;
-        if (valid) {
-            float d1[4], d2[4];
+        for (int e = 0; e < 4; ++e) { cb1[e] = rbf(c1[e]); sb1[e] = rbf(s1[e]); cb2[e] = rbf(c2[e]); sb2[e] = rbf(s2[e]); }
+        for (int grp = 0; grp < groups; ++grp) {
+            const int h = grp * G::HPW + sub;
+            const bool valid = h < H;
+            const int hh = valid ? h : 0;
+            const bool isq = hh < Hq;
+            const bf16_t* src = qkv + t * ld + (int64_t)hh * D;
+            const bf16_t* g = isq ? dq + t * (int64_t)Hq * D + (int64_t)hh * D : dk + t * (int64_t)Hkv * D + (int64_t)(hh - Hq) * D;
+            float x1[4] = {0, 0, 0, 0}, x2[4] = {0, 0, 0, 0}, g1[4], g2[4];
+            if (norm) {
+                unpack4(*reinterpret_cast<const u32x2*>(src + i), x1);
+                unpack4(*reinterpret_cast<const u32x2*>(src + G::HALF + i), x2);
+            }
+            unpack4(*reinterpret_cast<const u32x2*>(g + i), g1);
+            unpack4(*reinterpret_cast<const u32x2*>(g + G::HALF + i), g2);
+            const float r = norm ? rstd[t * H + hh] : 1.0f;
+            float dn1[4], dn2[4], xh1[4], xh2[4], w1[4], w2[4];
+            float dot = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                d1[e] = norm ? r * (dn1[e] * w1[e] - xh1[e] * dot) : dn1[e];
-                d2[e] = norm ? r * (dn2[e] * w2[e] - xh2[e] * dot) : dn2[e];
-                if (isq) { dwq1[e] += dn1[e] * xh1[e]; dwq2[e] += dn2[e] * xh2[e]; } else { dwk1[e] += dn1[e] * xh1[e]; dwk2[e] += dn2[e] * xh2[e]; }
+                // y1 = c1*n1 - s1*n2 ; y2 = c2*n2 + s2*n1
+                w1[e] = isq ? wq1[e] : wk1[e];
+                w2[e] = isq ? wq2[e] : wk2[e];
+                dn1[e] = cb1[e] * g1[e] + sb2[e] * g2[e];
+                dn2[e] = cb2[e] * g2[e] - sb1[e] * g1[e];
+                xh1[e] = x1[e] * r;
+                xh2[e] = x2[e] * r;
+                dot += dn1[e] * w1[e] * xh1[e] + dn2[e] * w2[e] * xh2[e];
             }
-            bf16_t* dst = dqkv + t * ld + (int64_t)h * D;
-            *reinterpret_cast<u32x2*>(dst + i) = pack4(d1);
-            *reinterpret_cast<u32x2*>(dst + G::HALF + i) = pack4(d2);
+            dot = head_sum<G::LPH>(dot) / (float)D;
+            if (valid) {
+                float d1[4], d2[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    d1[e] = norm ? r * (dn1[e] * w1[e] - xh1[e] * dot) : dn1[e];
+                    d2[e] = norm ? r * (dn2[e] * w2[e] - xh2[e] * dot) : dn2[e];
+                    if (isq) { dwq1[e] += dn1[e] * xh1[e]; dwq2[e] += dn2[e] * xh2[e]; } else { dwk1[e] += dn1[e] * xh1[e]; dwk2[e] += dn2[e] * xh2[e]; }
+                }
+                bf16_t* dst = dqkv + t * ld + (int64_t)h * D;
+                *reinterpret_cast<u32x2*>(dst + i) = pack4(d1);
+                *reinterpret_cast<u32x2*>(dst + G::HALF + i) = pack4(d2);
+            }
         }
     }
 #pragma unroll
@@ -510,7 +530,7 @@ extern "C" int mi355_qknorm_rope_fwd(int64_t tokens, int Hq, int Hkv, int D, con
     MI355_REQUIRE(tokens > 0 && Hq > 0 && Hkv > 0 && qkv && cos && sin && pos && q_out && k_out, "mi355_qknorm_rope_fwd: bad arguments");
     MI355_REQUIRE((qw == nullptr) == (kw == nullptr) && (qw == nullptr || rstd != nullptr), "mi355_qknorm_rope_fwd: pass both norm weights (and rstd) or neither (RoPE only)");
     const int hpw = D == 128 ? 4 : 8;
-    const int grid = row_grid(tokens * ((Hq + Hkv + hpw - 1) / hpw));
+    const int grid = row_grid(tokens);
     hipStream_t s = (hipStream_t)stream;
     if (D == 128)
         hipLaunchKernelGGL(qknorm_rope_fwd_kernel<128>, dim3(grid), dim3(256), 0, s, tokens, Hq, Hkv, (const bf16_t*)qkv, (const bf16_t*)qw, (const bf16_t*)kw, cos, sin, pos, (bf16_t*)q_out, (bf16_t*)k_out, rstd, eps);
