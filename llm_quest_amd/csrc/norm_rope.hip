@@ -211,20 +211,21 @@ __global__ __launch_bounds__(1024) void reduce_rows_kernel(int parts, int64_t n,
 }
 
 // --------------------------------------------------------------------------- fused QK-RMSNorm + RoPE
-// RoPE pairs element i with i + D/2, so a lane owns 4 consecutive elements of the first half and the matching 4 of the
-// second half (two 8-byte loads); D/8 lanes cover a head and a wave processes 64/(D/8) heads of one token at a time
-// (4 for D=128, 8 for D=64).  Reference rounding points:
+// RoPE pairs element i with i + D/2, so a lane owns 8 consecutive elements of the first half and the matching 8 of the
+// second half (two 16-byte loads); D/16 lanes cover a head and a wave processes 64/(D/16) heads of one token per pass
+// (8 for D=128, 16 for D=64); a wave walks all heads of its token, so the rotary coefficients are fetched once per token.  Reference rounding points:
 //   n  = bf16( float(x) * rstd * float(w) )                                                     (PytorchRMSNorm)
 //   y1 = bf16( bf16(cos_b*n1) + bf16(sin_b*(-n2)) ),  y2 = bf16( bf16(cos_b*n2) + bf16(sin_b*n1) )  (RoPE.apply in bf16)
-__device__ __forceinline__ void unpack4(const u32x2 v, float (&f)[4]) {
-    f[0] = __uint_as_float(v[0] << 16); f[1] = __uint_as_float(v[0] & 0xffff0000u);
-    f[2] = __uint_as_float(v[1] << 16); f[3] = __uint_as_float(v[1] & 0xffff0000u);
+constexpr int QV = 8;  // features per lane per half: one 16-byte load
+__device__ __forceinline__ void load8f(const float* p, float (&f)[QV]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f[e] = a[e]; f[4 + e] = b[e]; }
 }
-__device__ __forceinline__ u32x2 pack4(const float (&f)[4]) { return (u32x2){pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3])}; }
 
 template <int D>
 struct QkGeom {
-    static constexpr int HALF = D / 2, LPH = HALF / 4, HPW = 64 / LPH;
+    static constexpr int HALF = D / 2, LPH = HALF / QV, HPW = 64 / LPH;
 };
 
 template <int LPH>
@@ -242,55 +243,57 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(int64_t tokens, in
                                                               bf16_t* __restrict__ ko, float* __restrict__ rstd, float eps) {
     using G = QkGeom<D>;
     const int lane = threadIdx.x & 63;
-    const int sub = lane / G::LPH, i = (lane % G::LPH) * 4;
+    const int sub = lane / G::LPH, i = (lane % G::LPH) * QV;
     const int H = Hq + Hkv;
     const int groups = (H + G::HPW - 1) / G::HPW;
     const int64_t ld = (int64_t)(Hq + 2 * Hkv) * D;
     const bool norm = qw != nullptr;  // qw == kw == NULL: RoPE only (Qwen3.5 vision attention, qwen3_5_vision_model.py:176-177)
     // per-lane constants of the whole launch: the norm weights of this lane's 2 x 4 features, for q heads and for k heads
-    float wq1[4] = {1.f, 1.f, 1.f, 1.f}, wq2[4] = {1.f, 1.f, 1.f, 1.f}, wk1[4] = {1.f, 1.f, 1.f, 1.f}, wk2[4] = {1.f, 1.f, 1.f, 1.f};
+    float wq1[QV] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, wq2[QV] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, wk1[QV] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, wk2[QV] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
     if (norm) {
-        unpack4(*reinterpret_cast<const u32x2*>(qw + i), wq1);
-        unpack4(*reinterpret_cast<const u32x2*>(qw + G::HALF + i), wq2);
-        unpack4(*reinterpret_cast<const u32x2*>(kw + i), wk1);
-        unpack4(*reinterpret_cast<const u32x2*>(kw + G::HALF + i), wk2);
+        unpack8(*reinterpret_cast<const u32x4*>(qw + i), wq1);
+        unpack8(*reinterpret_cast<const u32x4*>(qw + G::HALF + i), wq2);
+        unpack8(*reinterpret_cast<const u32x4*>(kw + i), wk1);
+        unpack8(*reinterpret_cast<const u32x4*>(kw + G::HALF + i), wk2);
     }
     // one wave = one token at a time: its rotary coefficients are fetched once and reused by every head of the token
     for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < tokens; t += (int64_t)gridDim.x * 4) {
         const int64_t p = pos[t];
-        const f32x4 c1 = *reinterpret_cast<const f32x4*>(cosT + p * D + i), s1 = *reinterpret_cast<const f32x4*>(sinT + p * D + i);
-        const f32x4 c2 = *reinterpret_cast<const f32x4*>(cosT + p * D + G::HALF + i), s2 = *reinterpret_cast<const f32x4*>(sinT + p * D + G::HALF + i);
-        float cb1[4], sb1[4], cb2[4], sb2[4];
+        float cb1[QV], sb1[QV], cb2[QV], sb2[QV];
+        load8f(cosT + p * D + i, cb1);
+        load8f(sinT + p * D + i, sb1);
+        load8f(cosT + p * D + G::HALF + i, cb2);
+        load8f(sinT + p * D + G::HALF + i, sb2);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { cb1[e] = rbf(c1[e]); sb1[e] = rbf(s1[e]); cb2[e] = rbf(c2[e]); sb2[e] = rbf(s2[e]); }
+        for (int e = 0; e < QV; ++e) { cb1[e] = rbf(cb1[e]); sb1[e] = rbf(sb1[e]); cb2[e] = rbf(cb2[e]); sb2[e] = rbf(sb2[e]); }
         for (int grp = 0; grp < groups; ++grp) {
             const int h = grp * G::HPW + sub;
             const bool valid = h < H;
             const int hh = valid ? h : 0;
             const bool isq = hh < Hq;
             const bf16_t* src = qkv + t * ld + (int64_t)hh * D;
-            float x1[4], x2[4];
-            unpack4(*reinterpret_cast<const u32x2*>(src + i), x1);
-            unpack4(*reinterpret_cast<const u32x2*>(src + G::HALF + i), x2);
+            float x1[QV], x2[QV];
+            unpack8(*reinterpret_cast<const u32x4*>(src + i), x1);
+            unpack8(*reinterpret_cast<const u32x4*>(src + G::HALF + i), x2);
             float r = 1.0f;
             if (norm) {
                 float ss = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ss += x1[e] * x1[e] + x2[e] * x2[e];
+                for (int e = 0; e < QV; ++e) ss += x1[e] * x1[e] + x2[e] * x2[e];
                 ss = head_sum<G::LPH>(ss);
                 r = rsqrtf(ss / (float)D + eps);
             }
-            float y1[4], y2[4];
+            float y1[QV], y2[QV];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < QV; ++e) {
                 const float n1 = rbf(x1[e] * r * (isq ? wq1[e] : wk1[e])), n2 = rbf(x2[e] * r * (isq ? wq2[e] : wk2[e]));
                 y1[e] = rbf(cb1[e] * n1) + rbf(sb1[e] * (-n2));
                 y2[e] = rbf(cb2[e] * n2) + rbf(sb2[e] * n1);
             }
             if (valid) {
                 bf16_t* dst = isq ? qo + t * (int64_t)Hq * D + (int64_t)h * D : ko + t * (int64_t)Hkv * D + (int64_t)(h - Hq) * D;
-                *reinterpret_cast<u32x2*>(dst + i) = pack4(y1);
-                *reinterpret_cast<u32x2*>(dst + G::HALF + i) = pack4(y2);
+                *reinterpret_cast<u32x4*>(dst + i) = pack8(y1);
+                *reinterpret_cast<u32x4*>(dst + G::HALF + i) = pack8(y2);
                 if (i == 0 && rstd) rstd[t * H + h] = r;
             }
         }
@@ -308,29 +311,31 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(int64_t tokens, in
     using G = QkGeom<D>;
     __shared__ float dw_lds[2 * D];
     const int lane = threadIdx.x & 63;
-    const int sub = lane / G::LPH, i = (lane % G::LPH) * 4;
+    const int sub = lane / G::LPH, i = (lane % G::LPH) * QV;
     const int H = Hq + Hkv;
     const int groups = (H + G::HPW - 1) / G::HPW;
     const int64_t ld = (int64_t)(Hq + 2 * Hkv) * D;
     for (int j = threadIdx.x; j < 2 * D; j += 256) dw_lds[j] = 0.f;
     __syncthreads();
-    float dwq1[4] = {0, 0, 0, 0}, dwq2[4] = {0, 0, 0, 0}, dwk1[4] = {0, 0, 0, 0}, dwk2[4] = {0, 0, 0, 0};
+    float dwq1[QV] = {0, 0, 0, 0, 0, 0, 0, 0}, dwq2[QV] = {0, 0, 0, 0, 0, 0, 0, 0}, dwk1[QV] = {0, 0, 0, 0, 0, 0, 0, 0}, dwk2[QV] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool norm = qw != nullptr;
-    float wq1[4] = {1.f, 1.f, 1.f, 1.f}, wq2[4] = {1.f, 1.f, 1.f, 1.f}, wk1[4] = {1.f, 1.f, 1.f, 1.f}, wk2[4] = {1.f, 1.f, 1.f, 1.f};
+    float wq1[QV] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, wq2[QV] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, wk1[QV] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, wk2[QV] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
     if (norm) {
-        unpack4(*reinterpret_cast<const u32x2*>(qw + i), wq1);
-        unpack4(*reinterpret_cast<const u32x2*>(qw + G::HALF + i), wq2);
-        unpack4(*reinterpret_cast<const u32x2*>(kw + i), wk1);
-        unpack4(*reinterpret_cast<const u32x2*>(kw + G::HALF + i), wk2);
+        unpack8(*reinterpret_cast<const u32x4*>(qw + i), wq1);
+        unpack8(*reinterpret_cast<const u32x4*>(qw + G::HALF + i), wq2);
+        unpack8(*reinterpret_cast<const u32x4*>(kw + i), wk1);
+        unpack8(*reinterpret_cast<const u32x4*>(kw + G::HALF + i), wk2);
     }
     // one wave = one token at a time (rotary coefficients fetched once per token, reused by all its heads)
     for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < tokens; t += (int64_t)gridDim.x * 4) {
         const int64_t p = pos[t];
-        const f32x4 c1 = *reinterpret_cast<const f32x4*>(cosT + p * D + i), s1 = *reinterpret_cast<const f32x4*>(sinT + p * D + i);
-        const f32x4 c2 = *reinterpret_cast<const f32x4*>(cosT + p * D + G::HALF + i), s2 = *reinterpret_cast<const f32x4*>(sinT + p * D + G::HALF + i);
-        float cb1[4], sb1[4], cb2[4], sb2[4];
+        float cb1[QV], sb1[QV], cb2[QV], sb2[QV];
+        load8f(cosT + p * D + i, cb1);
+        load8f(sinT + p * D + i, sb1);
+        load8f(cosT + p * D + G::HALF + i, cb2);
+        load8f(sinT + p * D + G::HALF + i, sb2);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { cb1[e] = rbf(c1[e]); sb1[e] = rbf(s1[e]); cb2[e] = rbf(c2[e]); sb2[e] = rbf(s2[e]); }
+        for (int e = 0; e < QV; ++e) { cb1[e] = rbf(cb1[e]); sb1[e] = rbf(sb1[e]); cb2[e] = rbf(cb2[e]); sb2[e] = rbf(sb2[e]); }
         for (int grp = 0; grp < groups; ++grp) {
             const int h = grp * G::HPW + sub;
             const bool valid = h < H;
@@ -338,18 +343,18 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(int64_t tokens, in
             const bool isq = hh < Hq;
             const bf16_t* src = qkv + t * ld + (int64_t)hh * D;
             const bf16_t* g = isq ? dq + t * (int64_t)Hq * D + (int64_t)hh * D : dk + t * (int64_t)Hkv * D + (int64_t)(hh - Hq) * D;
-            float x1[4] = {0, 0, 0, 0}, x2[4] = {0, 0, 0, 0}, g1[4], g2[4];
+            float x1[QV] = {0, 0, 0, 0, 0, 0, 0, 0}, x2[QV] = {0, 0, 0, 0, 0, 0, 0, 0}, g1[QV], g2[QV];
             if (norm) {
-                unpack4(*reinterpret_cast<const u32x2*>(src + i), x1);
-                unpack4(*reinterpret_cast<const u32x2*>(src + G::HALF + i), x2);
+                unpack8(*reinterpret_cast<const u32x4*>(src + i), x1);
+                unpack8(*reinterpret_cast<const u32x4*>(src + G::HALF + i), x2);
             }
-            unpack4(*reinterpret_cast<const u32x2*>(g + i), g1);
-            unpack4(*reinterpret_cast<const u32x2*>(g + G::HALF + i), g2);
+            unpack8(*reinterpret_cast<const u32x4*>(g + i), g1);
+            unpack8(*reinterpret_cast<const u32x4*>(g + G::HALF + i), g2);
             const float r = norm ? rstd[t * H + hh] : 1.0f;
-            float dn1[4], dn2[4], xh1[4], xh2[4], w1[4], w2[4];
+            float dn1[QV], dn2[QV], xh1[QV], xh2[QV], w1[QV], w2[QV];
             float dot = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < QV; ++e) {
                 // y1 = c1*n1 - s1*n2 ; y2 = c2*n2 + s2*n1
                 w1[e] = isq ? wq1[e] : wk1[e];
                 w2[e] = isq ? wq2[e] : wk2[e];
@@ -361,21 +366,21 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(int64_t tokens, in
             }
             dot = head_sum<G::LPH>(dot) / (float)D;
             if (valid) {
-                float d1[4], d2[4];
+                float d1[QV], d2[QV];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < QV; ++e) {
                     d1[e] = norm ? r * (dn1[e] * w1[e] - xh1[e] * dot) : dn1[e];
                     d2[e] = norm ? r * (dn2[e] * w2[e] - xh2[e] * dot) : dn2[e];
                     if (isq) { dwq1[e] += dn1[e] * xh1[e]; dwq2[e] += dn2[e] * xh2[e]; } else { dwk1[e] += dn1[e] * xh1[e]; dwk2[e] += dn2[e] * xh2[e]; }
                 }
                 bf16_t* dst = dqkv + t * ld + (int64_t)h * D;
-                *reinterpret_cast<u32x2*>(dst + i) = pack4(d1);
-                *reinterpret_cast<u32x2*>(dst + G::HALF + i) = pack4(d2);
+                *reinterpret_cast<u32x4*>(dst + i) = pack8(d1);
+                *reinterpret_cast<u32x4*>(dst + G::HALF + i) = pack8(d2);
             }
         }
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < QV; ++e) {
         atomicAdd(&dw_lds[i + e], dwq1[e]);
         atomicAdd(&dw_lds[G::HALF + i + e], dwq2[e]);
         atomicAdd(&dw_lds[D + i + e], dwk1[e]);
@@ -529,7 +534,6 @@ extern "C" int mi355_qknorm_rope_fwd(int64_t tokens, int Hq, int Hkv, int D, con
     MI355_REQUIRE(D == 128 || D == 64, "mi355_qknorm_rope_fwd: head_dim must be 64 or 128 (got %d)", D);
     MI355_REQUIRE(tokens > 0 && Hq > 0 && Hkv > 0 && qkv && cos && sin && pos && q_out && k_out, "mi355_qknorm_rope_fwd: bad arguments");
     MI355_REQUIRE((qw == nullptr) == (kw == nullptr) && (qw == nullptr || rstd != nullptr), "mi355_qknorm_rope_fwd: pass both norm weights (and rstd) or neither (RoPE only)");
-    const int hpw = D == 128 ? 4 : 8;
     const int grid = row_grid(tokens);
     hipStream_t s = (hipStream_t)stream;
     if (D == 128)
