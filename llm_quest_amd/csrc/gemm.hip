@@ -19,6 +19,8 @@
 //   * Epilogue: accumulators -> LDS (fp32, 64x64 at a time per wave) -> row-contiguous 16-B global stores with
 //     bias/GELU/residual fused, or raw fp32 slabs when K is split (few output tiles + long K: weight gradients).
 //   * Workgroup -> tile map: XCD-aware (blocks b and b+8 share an L2) then 8-row super-groups.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -49,6 +51,19 @@ struct TileCfg {
 using Cfg128 = TileCfg<128, 128, 2, 2, 64, 2>;      // 68 KiB LDS, 2 workgroups / CU, vmcnt(0) structure
 using Cfg256 = TileCfg<256, 256, 2, 4, 64, 2>;      // 136 KiB LDS, 1 workgroup (8 waves) / CU
 using Cfg256a = TileCfg<256, 256, 2, 4, 32, 4>;     // 136 KiB LDS, 4-stage ring, alternating wave groups
+using Cfg256b = TileCfg<256, 256, 2, 4, 32, 5>;     // 160 KiB LDS (all of it), 5-stage ring, ONE barrier per phase (tile hint 4)
+
+#ifndef GEMM_PROF
+#define GEMM_PROF 0  // profiling builds only: in-kernel cycle stamps of the alternating loop (tools/gemm_prof.py)
+#endif
+#if GEMM_PROF
+__device__ unsigned long long g_gemm_prof[32];
+#define GP_T() __builtin_readcyclecounter()
+#define GP_ADD(i, t0) do { const unsigned long long now_ = __builtin_readcyclecounter(); gp[i] += now_ - (t0); (t0) = now_; } while (0)
+#else
+#define GP_T() 0ull
+#define GP_ADD(i, t0) do { } while (0)
+#endif
 
 struct GemmParams {
     const bf16_t* A;
@@ -129,6 +144,7 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* tile, int c0, int kk, int 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -192,7 +208,77 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
     const int nt = min(nt_all, t0 + per);
 
     bool extra_barrier = false;
-    if constexpr (T::BK == 32) {
+    if constexpr (std::is_same_v<T, Cfg256b>) {
+        // ---- alternating groups, ONE barrier per phase.  The two groups stay one barrier apart (waves 4-7 take an extra one
+        // up front), so at every barrier one group has just finished a load segment and the other a 16-MFMA cluster; a phase
+        // is { load segment ; lgkmcnt(0) ; s_barrier ; 16 MFMAs }.  With half the barriers the hazards are covered by distance:
+        //   WAR  the DMA of tile t+3 (issued during tile t) lands in the stage of tile t-2 (5 stages), which both groups left
+        //        at least one barrier before the issuing wave's current one;
+        //   RAW  a wave confirms its pieces of tile t+1 (counted vmcnt; they were requested 3-4 phases earlier) in phase 0
+        //        of tile t; the group that runs ahead reads tile t+1 two barriers later, after the group behind has passed
+        //        its own phase-0 wait.
+        static_assert(T::NW == 8 && T::KK == 1 && T::NS == 5 && T::A_PPW == 2 && T::B_PPW == 2, "single-barrier loop: 8 waves, 5 stages, 2+2 pieces");
+        constexpr int HM = T::FM / 2;
+        const bool late = wave >= 4;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (t0 + i < nt) issue_tile(t0 + i, i);
+        if (t0 < nt) {
+            const int younger = nt - 1 - t0;
+            if (younger >= 2) wait_vmcnt<8>(); else if (younger >= 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();  // tile t0 landed for every wave
+        if (late) __builtin_amdgcn_s_barrier();
+        bf16x8 a[HM], b[T::FN];
+        for (int t = t0; t < nt; ++t) {
+            const char* sA = smem + ((t - t0) % T::NS) * T::STAGE;
+            const char* sB = sA + T::A_BYTES;
+            const int nxt = t + 3;
+            const int nst = (nxt - t0) % T::NS;
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                if (ph == 0) {
+#pragma unroll
+                    for (int j = 0; j < T::FN; ++j) b[j] = B_TR ? frag_tr<T::BN>(sB, wc0 + j * 16, 0, lane) : frag_rowk<BK>(sB, wc0 + j * 16, 0, lane);
+                }
+#pragma unroll
+                for (int i = 0; i < HM; ++i) {
+                    const int r0 = wr0 + (ph * HM + i) * 16;
+                    a[i] = A_TR ? frag_tr<T::BM>(sA, r0, 0, lane) : frag_rowk<BK>(sA, r0, 0, lane);
+                }
+                if (nxt < nt) {
+                    const int64_t krem = p.K - (int64_t)nxt * BK;
+                    if (ph == 0) {
+                        const bf16_t* pa = baseA + nxt * stepA;
+                        char* dA = smem + nst * T::STAGE + wave * T::A_PPW * 1024;
+#pragma unroll
+                        for (int j = 0; j < T::A_PPW; ++j) dma_piece(pa, kneedA[j] < krem ? voffA[j] : OOB, dA + j * 1024);
+                    } else {
+                        const bf16_t* pb = baseB + nxt * stepB;
+                        char* dB = smem + nst * T::STAGE + T::A_BYTES + wave * T::B_PPW * 1024;
+#pragma unroll
+                        for (int j = 0; j < T::B_PPW; ++j) dma_piece(pb, kneedB[j] < krem ? voffB[j] : OOB, dB + j * 1024);
+                    }
+                }
+                if (ph == 0 && t + 1 < nt) {  // this wave's share of tile t+1 has landed; tile t+2 and the A pieces of t+3 may be in flight
+                    if (nxt < nt) wait_vmcnt<6>(); else if (t + 2 < nt) wait_vmcnt<4>(); else wait_vmcnt<0>();
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < HM; ++i)
+#pragma unroll
+                    for (int j = 0; j < T::FN; ++j)
+                        acc[ph * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[ph * HM + i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        extra_barrier = !late;  // the early group balances the late group's extra barrier
+    } else if constexpr (T::BK == 32) {
         // ---- alternating-group loop (8 waves, BK = 32, NS-stage ring).  Waves 4-7 run ONE barrier behind waves 0-3, so on
         // every SIMD one wave is in its 16-MFMA cluster while its partner is in the load segment (fragment reads, two
         // LDS-DMA issues, waits).  A phase = { load segment ; lgkmcnt(0) ; s_barrier ; 16 MFMAs ; s_barrier }, two phases per
@@ -213,6 +299,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
         __builtin_amdgcn_s_barrier();  // tile t0 landed for every wave
         if (late) __builtin_amdgcn_s_barrier();
         bf16x8 a[HM], b[T::FN];
+        [[maybe_unused]] unsigned long long gp[8] = {};
+        [[maybe_unused]] const unsigned long long gp_start = GP_T();
         for (int t = t0; t < nt; ++t) {
             const char* sA = smem + ((t - t0) % T::NS) * T::STAGE;
             const char* sB = sA + T::A_BYTES;
@@ -220,6 +308,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
             const int nst = (nxt - t0) % T::NS;
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph) {
+                [[maybe_unused]] unsigned long long gt = GP_T();
                 // -------- load segment
                 if (!(p.ablate & 2) || t == t0) {
                     if (ph == 0) {
@@ -232,6 +321,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
                         a[i] = A_TR ? frag_tr<T::BM>(sA, r0, 0, lane) : frag_rowk<BK>(sA, r0, 0, lane);
                     }
                 }
+                GP_ADD(0, gt);  // fragment reads issued
                 if (nxt < nt && !(p.ablate & 1)) {  // two of this wave's four DMA pieces of tile t+NS-1 per phase: A pieces, then B pieces
                     const int64_t krem = p.K - (int64_t)nxt * BK;
                     if (ph == 0) {
@@ -246,14 +336,18 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
                         for (int j = 0; j < T::B_PPW; ++j) dma_piece(pb, kneedB[j] < krem ? voffB[j] : OOB, dB + j * 1024);
                     }
                 }
+                GP_ADD(1, gt);  // DMA issued
                 if (ph == 1 && t + 1 < nt) {  // this wave's share of tile t+1 has landed (tiles t+2.. may stay in flight)
                     const int younger = min(nt - 1, t + T::NS - 1) - (t + 1);
                     if (younger >= 2) wait_vmcnt<8>(); else if (younger >= 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
                 }
+                GP_ADD(2, gt);  // vmcnt wait
                 const bool wait_late = (p.ablate & 8) || ((p.ablate & 16) && ph == 0);
                 if (!wait_late) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                GP_ADD(3, gt);  // lgkmcnt wait
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
+                GP_ADD(4, gt);  // barrier in front of the cluster
                 if (wait_late) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 // -------- MFMA cluster
@@ -265,9 +359,19 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
                         acc[ph * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[ph * HM + i][j], 0, 0, 0);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
+                GP_ADD(5, gt);  // MFMA cluster issued
                 if (!(p.ablate & 4)) __builtin_amdgcn_s_barrier();
+                GP_ADD(6, gt);  // barrier behind the cluster
             }
         }
+#if GEMM_PROF
+        if ((threadIdx.x & 63) == 0 && (wave == 0 || wave == 4)) {
+            const int o = wave == 0 ? 0 : 16;
+            for (int i = 0; i < 7; ++i) atomicAdd(&g_gemm_prof[o + i], gp[i]);
+            atomicAdd(&g_gemm_prof[o + 7], __builtin_readcyclecounter() - gp_start);
+            atomicAdd(&g_gemm_prof[o + 8], (unsigned long long)(2 * (nt - t0)));
+        }
+#endif
         extra_barrier = !late && !(p.ablate & 4);  // the early group balances the late group's extra barrier
     } else {
     // ---- main loop: 4 phases per K-tile = (k-step kk, half of the wave's rows mh); the fragments of phase p+1 are read
@@ -607,6 +711,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(int64_t M, int64_t N, const
 
 }  // namespace
 
+#if GEMM_PROF
+extern "C" int mi355_debug_gemm_prof(unsigned long long* out, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_prof), sizeof(unsigned long long) * 32) != hipSuccess) return 2;
+    if (reset) {
+        unsigned long long z[32] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_prof), z, sizeof(z)) != hipSuccess) return 3;
+    }
+    return 0;
+}
+#endif
+
 extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                                int64_t ldb, void* C, int64_t ldc, int out_dtype, const float* bias,
                                const void* residual, int64_t ldr, int epilogue, void* workspace, int64_t workspace_bytes,
@@ -617,7 +733,7 @@ extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const 
     MI355_REQUIRE(workspace == nullptr || ((uintptr_t)workspace & 15) == 0, "mi355_gemm_bf16: workspace must be 16-byte aligned");
     const int ablate = tile_hint >> 8;
     tile_hint &= 0xff;
-    MI355_REQUIRE(tile_hint >= 0 && tile_hint <= 3, "mi355_gemm_bf16: tile_hint must be 0 (auto), 1 (128x128), 2 (256x256) or 3 (256x256, alternating wave groups)");
+    MI355_REQUIRE(tile_hint >= 0 && tile_hint <= 4, "mi355_gemm_bf16: tile_hint must be 0 (auto), 1 (128x128), 2 (256x256), 3 (256x256, alternating wave groups) or 4 (3 with one barrier per phase)");
     GemmParams p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.bias = bias; p.R = residual;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
@@ -629,12 +745,13 @@ extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const 
         // forward / dgrad shapes and for the large weight gradients; small weight gradients (few tiles, K = tokens) do
         // better on 128x128 tiles with split-K; tiny problems stay on 128x128.
         if (M < 256 || N < 256) cfg = 1;
-        else if (form == MI355_GEMM_TN) cfg = (M * N > 5 * 1024 * 1024) ? 3 : 1;
-        else cfg = 3;
+        else if (form == MI355_GEMM_TN) cfg = (M * N > 5 * 1024 * 1024) ? 4 : 1;
+        else cfg = 4;
     }
     switch (cfg) {
         case 2: return launch_form<Cfg256>(form, p, out_dtype, workspace, workspace_bytes, s);
         case 3: return launch_form<Cfg256a>(form, p, out_dtype, workspace, workspace_bytes, s);
+        case 4: return launch_form<Cfg256b>(form, p, out_dtype, workspace, workspace_bytes, s);
         default: return launch_form<Cfg128>(form, p, out_dtype, workspace, workspace_bytes, s);
     }
 }
@@ -644,7 +761,7 @@ extern "C" int mi355_gemm_bf16_grouped(int form, int count, const mi355_gemm_pro
     MI355_REQUIRE(form >= 0 && form <= 2, "mi355_gemm_bf16_grouped: bad form %d", form);
     MI355_REQUIRE(count >= 1 && count <= MAX_GROUP && problems, "mi355_gemm_bf16_grouped: count must be 1..%d", MAX_GROUP);
     MI355_REQUIRE(out_dtype == MI355_DT_BF16 || out_dtype == MI355_DT_F32, "mi355_gemm_bf16_grouped: bad out_dtype");
-    MI355_REQUIRE(tile_hint == 0 || tile_hint == 1 || tile_hint == 3, "mi355_gemm_bf16_grouped: tile_hint must be 0 (auto), 1 (128x128) or 3 (256x256)");
+    MI355_REQUIRE(tile_hint == 0 || tile_hint == 1 || tile_hint == 3 || tile_hint == 4, "mi355_gemm_bf16_grouped: tile_hint must be 0 (auto), 1 (128x128), 3 or 4 (256x256)");
     GroupTable tbl;
     tbl.count = count;
     int64_t tiles256 = 0;
@@ -661,8 +778,9 @@ extern "C" int mi355_gemm_bf16_grouped(int form, int count, const mi355_gemm_pro
     }
     for (int i = count; i < MAX_GROUP; ++i) tbl.g[i] = tbl.g[0];
     // 256x256 tiles (one workgroup per CU) once they cover most of the chip; otherwise 128x128 (two per CU, 4x the tiles)
-    const int cfg = tile_hint ? tile_hint : ((small || tiles256 < 160) ? 1 : 3);
+    const int cfg = tile_hint ? tile_hint : ((small || tiles256 < 160) ? 1 : 4);
     hipStream_t s = (hipStream_t)stream;
+    if (cfg == 4) return launch_grouped_form<Cfg256b>(form, tbl, out_dtype, s);
     if (cfg == 3) return launch_grouped_form<Cfg256a>(form, tbl, out_dtype, s);
     return launch_grouped_form<Cfg128>(form, tbl, out_dtype, s);
 }

@@ -54,7 +54,7 @@ GEMM_SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
 @pytest.mark.parametrize("form", ["NT", "NN", "TN"])
 @pytest.mark.parametrize("M,N,K_", GEMM_SHAPES)
 def test_gemm_forms(K, form, M, N, K_, tile):
@@ -77,6 +77,28 @@ def test_gemm_forms(K, form, M, N, K_, tile):
     # fp32 accumulation of exact bf16 products: only summation order differs
     err = rel_l2(out, ref)
     assert err < 2e-6, f"{form} {M}x{N}x{K_} tile {tile}: rel l2 {err}"
+
+
+@pytest.mark.parametrize("form", ["NT", "NN", "TN"])
+def test_gemm_single_barrier_loop_matches_two_barrier_loop(K, form):
+    """Tile 4 (one barrier per phase, 5-stage ring) against tile 3, bit for bit (same MFMA, same K order), over K-tile counts
+    1..6 and a long K, ragged M / N, repeated to give a hazard a chance to show."""
+    from llm_quest_amd import _lib as L
+
+    g = torch.Generator().manual_seed(5)
+    f = {"NT": L.GEMM_NT, "NN": L.GEMM_NN, "TN": L.GEMM_TN}[form]
+    for (M, N, Kd) in [(304, 520, 32), (256, 256, 40), (520, 264, 96), (264, 776, 136), (512, 512, 160), (520, 520, 192), (776, 1032, 4096)]:
+        if form == "NT":
+            a, b = torch.randn(M, Kd, generator=g), torch.randn(N, Kd, generator=g)
+        elif form == "NN":
+            a, b = torch.randn(M, Kd, generator=g), torch.randn(Kd, N, generator=g)
+        else:
+            a, b = torch.randn(Kd, M, generator=g), torch.randn(Kd, N, generator=g)
+        a, b = dev(a.to(BF16)), dev(b.to(BF16))
+        ref = K.gemm(f, a, b, out_dtype=F32, allow_split_k=False, tile=3)
+        for _ in range(5):
+            got = K.gemm(f, a, b, out_dtype=F32, allow_split_k=False, tile=4)
+            assert torch.equal(got, ref), (form, M, N, Kd)
 
 
 def test_gemm_epilogues(K):
@@ -129,7 +151,7 @@ def test_gemm_split_k_weight_gradient_shapes(K):
     assert rel_l2(K.gemm(L.GEMM_NT, dev(a), dev(b), out_dtype=F32), a.float() @ b.float().t()) < 2e-6
 
 
-@pytest.mark.parametrize("tile", [0, 1, 3])
+@pytest.mark.parametrize("tile", [0, 1, 3, 4])
 def test_gemm_grouped_matches_single_launches(K, tile):
     """One grouped launch == the same problems launched one by one (bit-exact: same tile kernel, same K order), for ragged
     shapes, strided operand views, accumulation into an existing gradient, bf16 and fp32 outputs."""

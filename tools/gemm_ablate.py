@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from llm_quest_amd import _lib as L, kernels as K
 M = N = 4096; Kd = 8192
+TILE = int(os.environ.get("GEMM_TILE", "3"))
 r = lambda *s: torch.randn(*s, device="cuda").to(torch.bfloat16)
 _w = r(4096, 4096)
 for _ in range(200): _w @ _w  # clocks up before anything is timed
@@ -12,7 +13,7 @@ for name, form, sa, sb in (("NT", L.GEMM_NT, (M, Kd), (N, Kd)), ("NN", L.GEMM_NN
     a, b = r(*sa), r(*sb)
     res = []
     for ab in [int(x, 0) for x in (sys.argv[1] if len(sys.argv) > 1 else "0,1,2,3,4,8").split(",")]:
-        tile = 3 | (ab << 8)
+        tile = TILE | (ab << 8)
         out = K.gemm(form, a, b, tile=tile, allow_split_k=False)
         for _ in range(3): K.gemm(form, a, b, out=out, tile=tile, allow_split_k=False)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
