@@ -119,6 +119,31 @@ def test_attention_backward_fullsize_consistency(K):
     assert abs(float(lhs - rhs)) < 1e-3 * float(scale)
 
 
+def test_attention_backward_persistent_equals_per_block_workgroups(K):
+    """With >= 512 (batch, head) pairs one workgroup walks ALL blocks of its pair (3-stage tile stream across block
+    boundaries); below that there is one workgroup per block.  Same arithmetic in the same order -> bit-identical gradients.
+    The small-batch form is the one the oracle parity tests exercise (tests/test_kernels_gpu.py)."""
+    g = torch.Generator().manual_seed(21)
+    b_ = 64  # 64 * 8 kv heads = 512 pairs -> persistent dK/dV;  64 * 16 = 1024 -> persistent dQ
+    q = torch.randn(b_ * S, HQ * DH, generator=g).to(BF16).cuda()
+    k = torch.randn(b_ * S, HKV * DH, generator=g).to(BF16).cuda()
+    v = torch.randn(b_ * S, HKV * DH, generator=g).to(BF16).cuda()
+    do = torch.randn(b_ * S, HQ * DH, generator=g).to(BF16).cuda()
+    km = torch.ones(b_, S, dtype=torch.uint8)
+    km[::3, S - 150 :] = 0  # ragged rows: padded keys at the end of every third sample
+    km = km.cuda()
+    o, lse = K.attn_fwd(q, k, v, b_, S, HQ, HKV, DH, key_mask=km, causal=True)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    K.attn_bwd(q, k, v, o, do, lse, b_, S, HQ, HKV, DH, dq, dk, dv, key_mask=km, causal=True)
+    part = 16  # 16 * 16 = 256 < 512 pairs: one workgroup per block
+    for i in range(0, b_, part):
+        r = slice(i * S, (i + part) * S)
+        dq2, dk2, dv2 = torch.empty_like(q[r]), torch.empty_like(k[r]), torch.empty_like(v[r])
+        K.attn_bwd(q[r], k[r], v[r], o[r], do[r], lse[i : i + part], part, S, HQ, HKV, DH, dq2, dk2, dv2, key_mask=km[i : i + part], causal=True)
+        assert torch.equal(dq[r], dq2) and torch.equal(dk[r], dk2) and torch.equal(dv[r], dv2), i
+    assert torch.isfinite(dq.float()).all() and torch.isfinite(dk.float()).all() and torch.isfinite(dv.float()).all()
+
+
 def test_fusion_embedding_patch_gathers_bit_exact_at_full_size(K):
     from llm_quest_amd.multimodal.vlm_engine import fuse_embeddings
     from oracle import index_ops
