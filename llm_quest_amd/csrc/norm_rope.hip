@@ -480,6 +480,74 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int wi
     for (int i = threadIdx.x; i < 2 * width; i += 256) dparam_partial[(int64_t)blockIdx.x * 2 * width + i] = dp_lds[i];
 }
 
+// Same, for widths that are multiples of 256 (ViT 768): the row lives in registers (VPL float4 per lane), the parameter
+// gradients accumulate in registers across the rows of a wave and meet in LDS once per block -- no per-element LDS atomics.
+template <int DY_DT, int VPL>
+__global__ __launch_bounds__(256) void layernorm_bwd_rowreg_kernel(int64_t rows, int width, const float* __restrict__ x,
+                                                                   const float* __restrict__ scale, const float* __restrict__ mean,
+                                                                   const float* __restrict__ rsig, const void* __restrict__ dy,
+                                                                   const float* __restrict__ dres, float* __restrict__ dx,
+                                                                   float* __restrict__ dparam_partial, float eps, int mode) {
+    extern __shared__ __attribute__((aligned(16))) float dp_lds[];  // [2*width]
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 2 * width; i += 256) dp_lds[i] = 0.f;
+    __syncthreads();
+    f32x4 sc[VPL], dsc[VPL], dsh[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        sc[v] = *reinterpret_cast<const f32x4*>(scale + (v * 64 + lane) * 4);
+        dsc[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        dsh[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+        const float mu = mean[row], rs = rsig[row];
+        f32x4 n[VPL], dn[VPL];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + row * width + c);
+            f32x4 g;
+            if constexpr (DY_DT == MI355_DT_BF16) {
+                const u32x2 gv = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(dy) + row * width + c);
+                g = (f32x4){__uint_as_float(gv[0] << 16), __uint_as_float(gv[0] & 0xffff0000u), __uint_as_float(gv[1] << 16), __uint_as_float(gv[1] & 0xffff0000u)};
+            } else {
+                g = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(dy) + row * width + c);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                n[v][e] = (xv[e] - mu) * rs;
+                dn[v][e] = g[e] * sc[v][e];
+                s1 += dn[v][e];
+                s2 += dn[v][e] * n[v][e];
+                dsc[v][e] += g[e] * n[v][e];
+                dsh[v][e] += g[e];
+            }
+        }
+        s1 = wave_sum(s1) / (float)width;
+        s2 = wave_sum(s2) / (float)width;
+        const float s_over_sigma = mode == 0 ? (1.0f / rs) / (1.0f / rs - eps) : 1.0f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = rs * (dn[v][e] - s1 - n[v][e] * s2 * s_over_sigma);
+            if (dres) o += *reinterpret_cast<const f32x4*>(dres + row * width + c);
+            *reinterpret_cast<f32x4*>(dx + row * width + c) = o;
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomicAdd(&dp_lds[(v * 64 + lane) * 4 + e], dsc[v][e]);
+            atomicAdd(&dp_lds[width + (v * 64 + lane) * 4 + e], dsh[v][e]);
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * width; i += 256) dparam_partial[(int64_t)blockIdx.x * 2 * width + i] = dp_lds[i];
+}
+
 inline int row_grid(int64_t rows) {
     int64_t g = (rows + 3) / 4;
     return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -579,10 +647,21 @@ extern "C" int mi355_layernorm_bwd(int64_t rows, int width, const float* x, cons
     MI355_REQUIRE(rows > 0 && width > 0 && width <= 8192 && parts > 0, "mi355_layernorm_bwd: bad shape");
     MI355_REQUIRE(x && scale && mean && rsig && dy && dx && dparam_partial, "mi355_layernorm_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    if (dy_dtype == MI355_DT_BF16)
-        hipLaunchKernelGGL(layernorm_bwd_kernel<MI355_DT_BF16>, dim3(parts), dim3(256), 2 * width * sizeof(float), s, rows, width, x, scale, mean, rsig, dy, dres, dx, dparam_partial, eps, mode);
-    else
-        hipLaunchKernelGGL(layernorm_bwd_kernel<MI355_DT_F32>, dim3(parts), dim3(256), 2 * width * sizeof(float), s, rows, width, x, scale, mean, rsig, dy, dres, dx, dparam_partial, eps, mode);
+#define LN_BWD(KERNEL) \
+    hipLaunchKernelGGL(KERNEL, dim3(parts), dim3(256), 2 * width * sizeof(float), s, rows, width, x, scale, mean, rsig, dy, dres, dx, dparam_partial, eps, mode)
+    const bool aligned = (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)dres | (uintptr_t)scale) & 15) == 0;
+    if (width == 768 && aligned) {
+        if (dy_dtype == MI355_DT_BF16) LN_BWD((layernorm_bwd_rowreg_kernel<MI355_DT_BF16, 3>));
+        else LN_BWD((layernorm_bwd_rowreg_kernel<MI355_DT_F32, 3>));
+    } else if (width == 1024 && aligned) {
+        if (dy_dtype == MI355_DT_BF16) LN_BWD((layernorm_bwd_rowreg_kernel<MI355_DT_BF16, 4>));
+        else LN_BWD((layernorm_bwd_rowreg_kernel<MI355_DT_F32, 4>));
+    } else if (dy_dtype == MI355_DT_BF16) {
+        LN_BWD(layernorm_bwd_kernel<MI355_DT_BF16>);
+    } else {
+        LN_BWD(layernorm_bwd_kernel<MI355_DT_F32>);
+    }
+#undef LN_BWD
     MI355_LAUNCH_CHECK("mi355_layernorm_bwd");
     return 0;
 }

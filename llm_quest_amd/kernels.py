@@ -393,7 +393,7 @@ def layernorm_bwd(x2d, scale, mean, rsig, dy, dres=None, eps=1e-5, dscale_out=No
     if dres is not None and (dres.dtype != F32 or not dres.is_contiguous() or dres.shape != x2d.shape):
         raise ValueError("layernorm_bwd: dres must be contiguous fp32 like x")
     dx = torch.empty_like(x2d)
-    parts = min(256, (rows + 3) // 4)
+    parts = min(1024, (rows + 3) // 4)
     part = torch.empty((parts, 2 * width), dtype=F32, device=x2d.device)
     L.call("mi355_layernorm_bwd", rows, width, L.ptr(x2d), L.ptr(scale), L.ptr(mean), L.ptr(rsig), L.ptr(dy), L.dt_code(dy.dtype), L.ptr(dres), L.ptr(dx), L.ptr(part), parts, eps, mode)
     both = torch.empty(2 * width, dtype=F32, device=x2d.device)

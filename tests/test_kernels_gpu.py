@@ -301,6 +301,29 @@ def test_layernorm(K, golden):
     assert rel_l2(yb, t["layernorm.y"]) < 3e-3
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("width", [768, 1024, 192])
+def test_layernorm_backward_row_in_registers(K, mode, width):
+    """LayerNorm backward (mode 0: the reference ViT's sigma + eps; mode 1: nn.LayerNorm) against autograd in fp64, for the
+    register-resident kernel (widths 768 / 1024) and the generic one (192), bf16 and fp32 upstream gradients, fused residual."""
+    g = torch.Generator().manual_seed(width + mode)
+    rows = 333
+    x = torch.randn(rows, width, generator=g) * 2 + 0.5
+    sc, sh = 1 + 0.2 * torch.randn(width, generator=g), 0.1 * torch.randn(width, generator=g)
+    dres = torch.randn(rows, width, generator=g)
+    eps = 1e-5 if mode == 0 else 1e-6
+    for dy in (torch.randn(rows, width, generator=g), torch.randn(rows, width, generator=g).to(BF16)):
+        xd, scd, shd = x.double().requires_grad_(True), sc.double().requires_grad_(True), sh.double().requires_grad_(True)
+        mu = xd.mean(-1, keepdim=True)
+        var = ((xd - mu) ** 2).mean(-1, keepdim=True)
+        y = scd * (xd - mu) / (var.sqrt() + eps) + shd if mode == 0 else scd * (xd - mu) / (var + eps).sqrt() + shd
+        y.backward(dy.double())
+        _, mean, rsig = K.layernorm_fwd(dev(x), dev(sc), dev(sh), out_dtype=F32, eps=eps, want_stats=True, mode=mode)
+        dx, dsc, dsh = K.layernorm_bwd(dev(x), dev(sc), mean, rsig, dev(dy), dres=dev(dres), eps=eps, mode=mode)
+        assert rel_l2(dx, xd.grad + dres.double()) < 2e-6
+        assert rel_l2(dsc, scd.grad) < 2e-6 and rel_l2(dsh, shd.grad) < 2e-6
+
+
 def test_swiglu(K, golden):
     g = torch.Generator().manual_seed(21)
     gu = torch.randn(300, 2 * 3072, generator=g).to(BF16)
