@@ -129,3 +129,42 @@ def test_param_arena_views_and_grad_targets():
     # .to()/rebinding is detected and the arena is rebuilt around the new storage
     lin_b.weight.data = lin_b.weight.data.clone()
     assert ar.ensure() is True and ar.fused(lin_a.weight, lin_c.weight).shape == (32, 8)
+
+
+def test_hf_qwen3_checkpoint_import_round_trip(tmp_path, capsys):
+    """HF parameter names -> this package's: a synthetic HF-named checkpoint built from one model loads
+    into a second model bit for bit, through a dict and through a .safetensors file; bad shapes / unknown names are reported."""
+    from safetensors.torch import save_file
+
+    from llm_quest_amd.qwen.qwen3.qwen3_model import Qwen3Model
+    from llm_quest_amd.qwen.qwen3.qwen3_weight_loading import get_remapping_rules, load_qwen3_weights
+
+    cfg = dict(vocab_size=96, emb_dim=32, n_layers=2, n_heads=4, num_kv_groups=2, head_dim=8, hidden_dim=64, context_length=16,
+               rope_base=10_000, dtype=torch.bfloat16, tie_embeddings=True, model_type="dense")
+    torch.manual_seed(0)
+    src, dst = Qwen3Model(cfg), Qwen3Model(cfg)
+    inverse = [(ours, hf) for hf, ours in get_remapping_rules(cfg)]
+    hf = {}
+    for name, w in src.state_dict().items():
+        if name in ("mask", "cos", "sin", "out_head.weight"):
+            continue
+        hf_name = name
+        for ours, theirs in inverse:
+            hf_name = hf_name.replace(ours, theirs)
+        hf[hf_name] = w.detach().clone()
+    assert "model.layers.1.self_attn.q_proj.weight" in hf and "model.layers.0.mlp.up_proj.weight" in hf
+    hf["model.layers.0.self_attn.rotary_emb.inv_freq"] = torch.zeros(4)  # unknown upstream tensor: reported, not loaded
+    load_qwen3_weights(dst, cfg, source=hf)
+    out = capsys.readouterr().out
+    assert "No match for HF weight 'model.layers.0.self_attn.rotary_emb.inv_freq'" in out
+    for (n1, p1), (n2, p2) in zip(src.named_parameters(), dst.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2), n1
+    assert dst.out_head.weight is dst.emb_dict.weight
+    # through a file, into a third model
+    path = tmp_path / "model.safetensors"
+    hf.pop("model.layers.0.self_attn.rotary_emb.inv_freq")
+    save_file({k: v.contiguous() for k, v in hf.items()}, str(path))
+    third = load_qwen3_weights(Qwen3Model(cfg), cfg, source=str(path), verbose=False)
+    assert all(torch.equal(a, b) for a, b in zip(src.parameters(), third.parameters()))
+    with pytest.raises(ValueError):
+        load_qwen3_weights(Qwen3Model(cfg), cfg)
