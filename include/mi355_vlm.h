@@ -184,6 +184,12 @@ int mi355_sumsq(int64_t n, const void* x, int dtype, float* out, void* stream);
 int mi355_clip_scale(int64_t n, void* x, int dtype, const float* sumsq, float max_norm, void* stream);
 /* y = x * (*scale), bf16, scale is a DEVICE fp32 scalar (autograd's incoming grad_output, no host sync) */
 int mi355_scale_bf16(int64_t n, const void* x, const float* scale, void* y, void* stream);
+/* One AdamW step (torch.optim.AdamW semantics: decoupled weight decay, bias correction by `step` >= 1) over a flat buffer
+ * of n elements -- one launch per parameter arena instead of one foreach chain per tensor (engine.py:444-450 optimizer.step()).
+ * param / grad bf16 or fp32, moments fp32.  sumsq != NULL: the gradient is scaled by min(1, max_norm / (sqrt(*sumsq) + 1e-6))
+ * on the fly (the global-norm clip of engine.py:441 fused in; *sumsq from mi355_sumsq over all gradients). */
+int mi355_adamw(int64_t n, void* param, int p_dtype, const void* grad, int g_dtype, float* exp_avg, float* exp_avg_sq, float lr,
+                float beta1, float beta2, float eps, float weight_decay, int step, const float* sumsq, float max_norm, void* stream);
 /* fp32 -> bf16 with add: dst_bf16 = bf16(a_f32 + (b_bf16 or 0)) */
 int mi355_add_f32_to_bf16(int64_t n, const float* a, const void* b_bf16, void* dst_bf16, void* stream);
 

@@ -25,6 +25,7 @@ _P, _I, _L, _F = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float
 SIGNATURES = {
     "mi355_gemm_bf16": [_I, _L, _L, _L, _P, _L, _P, _L, _P, _L, _I, _P, _P, _L, _I, _P, _L, _I, _P],
     "mi355_gemm_bf16_grouped": [_I, _I, _P, _I, _I, _P],
+    "mi355_adamw": [_L, _P, _I, _P, _I, _P, _P, _F, _F, _F, _F, _F, _I, _P, _F, _P],
     "mi355_colsum": [_L, _L, _P, _I, _L, _P, _I, _P],
     "mi355_rmsnorm_fwd": [_L, _I, _P, _P, _P, _P, _F, _P],
     "mi355_rmsnorm_bwd": [_L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],

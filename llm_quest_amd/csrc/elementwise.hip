@@ -430,6 +430,29 @@ __global__ __launch_bounds__(256) void clip_scale_kernel(int64_t n, void* __rest
     }
 }
 
+// AdamW over one flat buffer (a parameter arena): decoupled weight decay, fp32 moments, parameter and gradient in their own
+// dtype (bf16 or fp32); the optional device scalar `sumsq` applies the global-norm clip coefficient to the gradient on the
+// fly (torch.nn.utils.clip_grad_norm_ semantics) so the clip never costs a pass of its own.
+template <int P_DT, int G_DT>
+__global__ __launch_bounds__(256) void adamw_kernel(int64_t n, void* __restrict__ param, const void* __restrict__ grad,
+                                                    float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq, float lr, float beta1,
+                                                    float beta2, float eps, float weight_decay, float bc1, float bc2_sqrt,
+                                                    const float* __restrict__ sumsq, float max_norm) {
+    const float coef = sumsq ? fminf(1.0f, max_norm / (sqrtf(*sumsq) + 1e-6f)) : 1.0f;
+    const float step = lr / bc1, decay = 1.0f - lr * weight_decay;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float g = (G_DT == MI355_DT_BF16 ? bf2f(reinterpret_cast<const bf16_t*>(grad)[i]) : reinterpret_cast<const float*>(grad)[i]) * coef;
+        float p = P_DT == MI355_DT_BF16 ? bf2f(reinterpret_cast<bf16_t*>(param)[i]) : reinterpret_cast<float*>(param)[i];
+        const float m = beta1 * exp_avg[i] + (1.0f - beta1) * g;
+        const float v = beta2 * exp_avg_sq[i] + (1.0f - beta2) * g * g;
+        exp_avg[i] = m;
+        exp_avg_sq[i] = v;
+        p = p * decay - step * m / (sqrtf(v) / bc2_sqrt + eps);
+        if (P_DT == MI355_DT_BF16) reinterpret_cast<bf16_t*>(param)[i] = f2bf(p);
+        else reinterpret_cast<float*>(param)[i] = p;
+    }
+}
+
 }  // namespace
 
 #define STREAM ((hipStream_t)stream)
@@ -596,5 +619,22 @@ extern "C" int mi355_clip_scale(int64_t n, void* x, int dtype, const float* sums
     else
         hipLaunchKernelGGL(clip_scale_kernel<MI355_DT_F32>, dim3(grid_for(n, 256 * 4)), dim3(256), 0, STREAM, n, x, sumsq, max_norm);
     MI355_LAUNCH_CHECK("mi355_clip_scale");
+    return 0;
+}
+
+extern "C" int mi355_adamw(int64_t n, void* param, int p_dtype, const void* grad, int g_dtype, float* exp_avg, float* exp_avg_sq, float lr,
+                           float beta1, float beta2, float eps, float weight_decay, int step, const float* sumsq, float max_norm,
+                           void* stream) {
+    MI355_REQUIRE(n > 0 && param && grad && exp_avg && exp_avg_sq && step >= 1, "mi355_adamw: bad arguments");
+    MI355_REQUIRE((p_dtype == MI355_DT_BF16 || p_dtype == MI355_DT_F32) && (g_dtype == MI355_DT_BF16 || g_dtype == MI355_DT_F32), "mi355_adamw: bad dtype");
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+    const dim3 grid(grid_for(n, 256 * 4));
+#define ADAMW(P, G) hipLaunchKernelGGL((adamw_kernel<P, G>), grid, dim3(256), 0, STREAM, n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, sumsq, max_norm)
+    if (p_dtype == MI355_DT_BF16 && g_dtype == MI355_DT_BF16) ADAMW(MI355_DT_BF16, MI355_DT_BF16);
+    else if (p_dtype == MI355_DT_BF16) ADAMW(MI355_DT_BF16, MI355_DT_F32);
+    else if (g_dtype == MI355_DT_BF16) ADAMW(MI355_DT_F32, MI355_DT_BF16);
+    else ADAMW(MI355_DT_F32, MI355_DT_F32);
+#undef ADAMW
+    MI355_LAUNCH_CHECK("mi355_adamw");
     return 0;
 }

@@ -351,6 +351,19 @@ def clip_scale_(x, sumsq, max_norm):
     L.call("mi355_clip_scale", x.numel(), L.ptr(x), L.dt_code(x.dtype), L.ptr(sumsq), float(max_norm))
 
 
+def adamw_(param_flat, grad_flat, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, sumsq=None, max_norm=0.0):
+    """One AdamW step over a flat buffer (see include/mi355_vlm.h::mi355_adamw); sumsq = device scalar of the global squared
+    gradient norm fuses clip_grad_norm_(max_norm) into the update."""
+    L.require_gpu(param_flat, grad_flat, exp_avg, exp_avg_sq, sumsq)
+    n = param_flat.numel()
+    if not (param_flat.is_contiguous() and grad_flat.is_contiguous() and grad_flat.numel() == n):
+        raise ValueError("adamw_: parameter and gradient must be contiguous buffers of one size")
+    if exp_avg.dtype != F32 or exp_avg_sq.dtype != F32 or exp_avg.numel() != n or exp_avg_sq.numel() != n:
+        raise ValueError("adamw_: moments must be fp32 buffers of the parameter's size")
+    L.call("mi355_adamw", n, L.ptr(param_flat), L.dt_code(param_flat.dtype), L.ptr(grad_flat), L.dt_code(grad_flat.dtype), L.ptr(exp_avg),
+           L.ptr(exp_avg_sq), float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step), L.ptr(sumsq), float(max_norm))
+
+
 def add_f32_to_bf16(a_f32, b_bf16, dst_bf16):
     L.require_gpu(a_f32, dst_bf16)
     L.call("mi355_add_f32_to_bf16", a_f32.numel(), L.ptr(a_f32), L.ptr(b_bf16), L.ptr(dst_bf16))

@@ -355,3 +355,35 @@ def test_rccl_gradsync_single_rank(golden):
         dist.destroy_process_group()
         for m in list(llm.trf_blocks) + [ad]:
             object.__setattr__(m, "_grad_ready", None)
+
+
+def test_arena_adamw_matches_torch_adamw():
+    """Fused clip + AdamW over arenas (row f1) against clip_grad_norm_ + torch.optim.AdamW on an fp32 copy of the same model and
+    gradients, three steps; then bf16 parameters against the fp32 trajectory within bf16 resolution."""
+    from llm_quest_amd.optim import ArenaAdamW
+    from llm_quest_amd.qwen.qwen3.qwen3_model import Qwen3Model
+
+    cfg = dict(vocab_size=512, emb_dim=128, n_layers=2, n_heads=2, num_kv_groups=1, head_dim=64, hidden_dim=256, context_length=64,
+               rope_base=10_000, dtype=torch.bfloat16, tie_embeddings=True)
+    torch.manual_seed(3)
+    model = Qwen3Model(cfg).cuda().train()
+    ref = {n: p.detach().float().clone().requires_grad_(True) for n, p in model.named_parameters()}
+    topt = torch.optim.AdamW(list(ref.values()), lr=3e-3, weight_decay=0.1)
+    opt = ArenaAdamW(model.parameters(), lr=3e-3, weight_decay=0.1, max_grad_norm=1.0).attach(model)
+    ids = torch.randint(0, 512, (4, 48), device="cuda")
+    for step in range(3):
+        model.zero_grad(set_to_none=True)
+        h = model.forward_hidden(ids)
+        model.lm_loss(h.reshape(-1, h.shape[-1]), ids.reshape(-1)).backward()
+        for n, p in model.named_parameters():
+            ref[n].grad = p.grad.detach().float().clone()
+        total = torch.nn.utils.clip_grad_norm_(list(ref.values()), 1.0)
+        topt.step()
+        norm = opt.step()
+        assert abs(float(norm) - float(total)) < 2e-3 * float(total)
+        for n, p in model.named_parameters():
+            want = ref[n].detach()
+            err = (p.detach().float() - want).abs().max()
+            assert float(err) <= 2 ** -7 * float(want.abs().max()) + 1e-6, (step, n, float(err))
+            ref[n].data.copy_(p.detach().float())  # re-sync so bf16 rounding does not accumulate into the comparison
+    assert model.out_head.weight is model.emb_dict.weight
