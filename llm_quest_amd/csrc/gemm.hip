@@ -237,15 +237,18 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
             const int nst = (nxt - t0) % T::NS;
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph) {
-                if (ph == 0) {
+                auto read_frags = [&]() {
+                    if (ph == 0) {
 #pragma unroll
-                    for (int j = 0; j < T::FN; ++j) b[j] = B_TR ? frag_tr<T::BN>(sB, wc0 + j * 16, 0, lane) : frag_rowk<BK>(sB, wc0 + j * 16, 0, lane);
-                }
+                        for (int j = 0; j < T::FN; ++j) b[j] = B_TR ? frag_tr<T::BN>(sB, wc0 + j * 16, 0, lane) : frag_rowk<BK>(sB, wc0 + j * 16, 0, lane);
+                    }
 #pragma unroll
-                for (int i = 0; i < HM; ++i) {
-                    const int r0 = wr0 + (ph * HM + i) * 16;
-                    a[i] = A_TR ? frag_tr<T::BM>(sA, r0, 0, lane) : frag_rowk<BK>(sA, r0, 0, lane);
-                }
+                    for (int i = 0; i < HM; ++i) {
+                        const int r0 = wr0 + (ph * HM + i) * 16;
+                        a[i] = A_TR ? frag_tr<T::BM>(sA, r0, 0, lane) : frag_rowk<BK>(sA, r0, 0, lane);
+                    }
+                };
+                if (!(p.ablate & 2)) read_frags();
                 if (nxt < nt) {
                     const int64_t krem = p.K - (int64_t)nxt * BK;
                     if (ph == 0) {
@@ -260,6 +263,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
                         for (int j = 0; j < T::B_PPW; ++j) dma_piece(pb, kneedB[j] < krem ? voffB[j] : OOB, dB + j * 1024);
                     }
                 }
+                if (p.ablate & 2) read_frags();  // experiment: DMA issue in front of the fragment reads
                 if (ph == 0 && t + 1 < nt) {  // this wave's share of tile t+1 has landed; tile t+2 and the A pieces of t+3 may be in flight
                     if (nxt < nt) wait_vmcnt<6>(); else if (t + 2 < nt) wait_vmcnt<4>(); else wait_vmcnt<0>();
                 }
@@ -267,13 +271,13 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
+                if (p.ablate & 1) __builtin_amdgcn_s_setprio(1);  // measured: raising the cluster's priority costs 2-3 % in this loop
 #pragma unroll
                 for (int i = 0; i < HM; ++i)
 #pragma unroll
                     for (int j = 0; j < T::FN; ++j)
                         acc[ph * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[ph * HM + i][j], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
+                if (p.ablate & 1) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
