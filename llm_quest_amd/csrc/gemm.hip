@@ -748,9 +748,12 @@ extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const 
         // measured on MI355X over the VLM step's shapes (tools/gemm_sweep.py): the alternating-group 256x256 kernel wins for
         // forward / dgrad shapes and for the large weight gradients; small weight gradients (few tiles, K = tokens) do
         // better on 128x128 tiles with split-K; tiny problems stay on 128x128.
+        // Tile 4 (one barrier per phase, 5 stages) wins every isolated sweep (+5-14 % NT, +10-13 % TN on warm operands) but
+        // LOSES inside the training step, where operands arrive cold from the previous kernel: A/B in one process,
+        // per form, 246.2 ms/step with tile 3 everywhere vs +0.9 (NT) / +4.3 (NN) / +0.5 (TN) ms with tile 4.  The step decides.
         if (M < 256 || N < 256) cfg = 1;
-        else if (form == MI355_GEMM_TN) cfg = (M * N > 5 * 1024 * 1024) ? 4 : 1;
-        else cfg = 4;
+        else if (form == MI355_GEMM_TN) cfg = (M * N > 5 * 1024 * 1024) ? 3 : 1;
+        else cfg = 3;
     }
     switch (cfg) {
         case 2: return launch_form<Cfg256>(form, p, out_dtype, workspace, workspace_bytes, s);
@@ -782,7 +785,7 @@ extern "C" int mi355_gemm_bf16_grouped(int form, int count, const mi355_gemm_pro
     }
     for (int i = count; i < MAX_GROUP; ++i) tbl.g[i] = tbl.g[0];
     // 256x256 tiles (one workgroup per CU) once they cover most of the chip; otherwise 128x128 (two per CU, 4x the tiles)
-    const int cfg = tile_hint ? tile_hint : ((small || tiles256 < 160) ? 1 : 4);
+    const int cfg = tile_hint ? tile_hint : ((small || tiles256 < 160) ? 1 : 3);
     hipStream_t s = (hipStream_t)stream;
     if (cfg == 4) return launch_grouped_form<Cfg256b>(form, tbl, out_dtype, s);
     if (cfg == 3) return launch_grouped_form<Cfg256a>(form, tbl, out_dtype, s);

@@ -21,6 +21,7 @@ def _rowmajor(t, name):
 import os
 
 _TILE_OVERRIDE = int(os.environ.get("MI355_GEMM_TILE", "0"))  # profiling knob: force a GEMM tile configuration
+_TILE_BY_FORM = {f: int(os.environ.get("MI355_GEMM_TILE_" + n, "0")) for f, n in ((L.GEMM_NT, "NT"), (L.GEMM_NN, "NN"), (L.GEMM_TN, "TN"))}
 _WS = {}
 WS_BYTES = 512 << 20  # split-K scratch per device (fp32 slabs of the largest weight-gradient GEMM)
 
@@ -67,7 +68,7 @@ def gemm(form, a, b, out=None, out_dtype=BF16, bias=None, residual=None, gelu=Fa
     L.call(
         "mi355_gemm_bf16", form, M, N, K, L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), L.ptr(out), out.stride(0),
         L.dt_code(out.dtype), L.ptr(bias), L.ptr(residual), ldr, L.EPI_GELU if gelu else L.EPI_NONE,
-        L.ptr(_workspace(a.device)) if allow_split_k else None, WS_BYTES if allow_split_k else 0, tile or _TILE_OVERRIDE,
+        L.ptr(_workspace(a.device)) if allow_split_k else None, WS_BYTES if allow_split_k else 0, tile or _TILE_BY_FORM[form] or _TILE_OVERRIDE,
     )
     return out
 
@@ -108,7 +109,7 @@ def gemm_grouped(form, problems, tile=0):
             if residual.dtype != odt or tuple(residual.shape) != (M, N):
                 raise ValueError("gemm_grouped: residual must match the output's shape and dtype")
             q.residual, q.ldr = residual.data_ptr(), residual.stride(0)
-    L.call("mi355_gemm_bf16_grouped", form, len(problems), _c.cast(table, _c.c_void_p), L.dt_code(odt), tile)
+    L.call("mi355_gemm_bf16_grouped", form, len(problems), _c.cast(table, _c.c_void_p), L.dt_code(odt), tile or _TILE_BY_FORM[form] or (_TILE_OVERRIDE if _TILE_OVERRIDE in (1, 3, 4) else 0))
 
 
 def colsum(x, out=None, accumulate=False):
