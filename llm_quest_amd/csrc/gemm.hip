@@ -751,8 +751,11 @@ extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const 
         // Tile 4 (one barrier per phase, 5 stages) wins every isolated sweep (+5-14 % NT, +10-13 % TN on warm operands) but
         // LOSES inside the training step, where operands arrive cold from the previous kernel: A/B in one process,
         // per form, 246.2 ms/step with tile 3 everywhere vs +0.9 (NT) / +4.3 (NN) / +0.5 (TN) ms with tile 4.  The step decides.
+        // The same A/B puts the forward projections (NT) on tile 2 (BK 64, two stages, fragments prefetched one phase ahead):
+        // 239.3 vs 243.8-246 ms/step with NT on tile 3, although tile 3 is 10-20 % faster on every isolated NT shape.
         if (M < 256 || N < 256) cfg = 1;
         else if (form == MI355_GEMM_TN) cfg = (M * N > 5 * 1024 * 1024) ? 3 : 1;
+        else if (form == MI355_GEMM_NT) cfg = 2;
         else cfg = 3;
     }
     switch (cfg) {
