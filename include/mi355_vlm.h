@@ -193,6 +193,90 @@ int mi355_adamw(int64_t n, void* param, int p_dtype, const void* grad, int g_dty
 /* fp32 -> bf16 with add: dst_bf16 = bf16(a_f32 + (b_bf16 or 0)) */
 int mi355_add_f32_to_bf16(int64_t n, const float* a, const void* b_bf16, void* dst_bf16, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Qwen3.5 hybrid text stack (BASELINE config 5): csrc/qwen35.hip, csrc/attention_generic.hip.
+ * "proj" below is the token-major output of ONE fused projection GEMM; column blocks of it are passed as pointer + ld.
+ * ------------------------------------------------------------------------------------------------------------------- */
+
+/* w_eff = bf16(1 + scale): the (1.0 + self.scale) factor of ZeroCenteredRMSNorm (qwen3_next_attention.py:38-46), rounded to
+ * bf16 where the reference rounds it.  Feeds mi355_rmsnorm_fwd/bwd and mi355_headnorm_rope_*; d(scale) = d(w_eff). */
+int mi355_zc_weight(int64_t n, const void* scale, void* w_eff, void* stream);
+
+/* Per-token interleaved MRoPE coefficient rows (RoPE.apply_mrope / interleave_mrope_coeffs, common/rope.py:246-343):
+ * cos_t[t, j] = cos_t[t, j + R/2] = cos[position_ids[axis(j)][t], j], axis(j) = H for j = 1,4,7.. < 3*sec_h, W for
+ * j = 2,5,8.. < 3*sec_w, else T.  cos/sin fp32 [ctx, R]; position_ids int64 [3, tokens]; outputs fp32 [tokens, R]. */
+int mi355_mrope_table(int64_t tokens, int R, int64_t ctx, const float* cos, const float* sin, const int64_t* position_ids, int sec_h,
+                      int sec_w, float* cos_t, float* sin_t, void* stream);
+
+/* y = x * mask[row]  (the in-place `x *= attn_mask` of FusedGatedDeltaNet, qwen3_5_text_model.py:109-110, and its backward). */
+int mi355_rowmask(int64_t rows, int width, const void* x, const uint8_t* mask, void* y, void* stream);
+
+/* Per-head ZeroCenteredRMSNorm + partial rotary embedding on heads that sit STRIDED inside a fused projection
+ * (GatedAttention / MRoPEGatedAttention, qwen3_next_attention.py:224-236, qwen3_5_text_model.py:227-233):
+ * head h of token t = src[t*ld + h*head_stride .. +D].  w = mi355_zc_weight(scale) bf16 [D].  The first R (<= 64) features
+ * rotate with rows pos[t] of cos_t/sin_t fp32 [*, R] (R = 0: no rotation).  out bf16 [tokens, H*D], rstd fp32 [tokens, H]. */
+int mi355_headnorm_rope_fwd(int64_t tokens, int H, int D, int R, const void* src, int64_t ld, int64_t head_stride, const void* w,
+                            const float* cos_t, const float* sin_t, const int32_t* pos, void* out, float* rstd, float eps, void* stream);
+/* dout bf16 [tokens, H*D] -> dsrc (strided like src, own ld / head stride); dw_partial fp32 [parts, D] (sum: mi355_reduce_rows_f32). */
+int mi355_headnorm_rope_bwd(int64_t tokens, int H, int D, int R, const void* src, int64_t ld, int64_t head_stride, const void* w,
+                            const float* cos_t, const float* sin_t, const int32_t* pos, const float* rstd, const void* dout, void* dsrc,
+                            int64_t ldd, int64_t dhead_stride, float* dw_partial, int parts, void* stream);
+
+/* out = ctx * sigmoid(gate)  (qwen3_next_attention.py:221,257); gate head h of token t at gate[t*ldg + h*gate_head_stride .. +D]. */
+int mi355_sigmoid_gate_fwd(int64_t tokens, int H, int D, const void* ctx, const void* gate, int64_t ldg, int64_t gate_head_stride, void* out,
+                           void* stream);
+int mi355_sigmoid_gate_bwd(int64_t tokens, int H, int D, const void* ctx, const void* gate, int64_t ldg, int64_t gate_head_stride,
+                           const void* dout, void* dctx, void* dgate, int64_t lddg, int64_t dgate_head_stride, void* stream);
+
+/* Attention with F.scaled_dot_product_attention's boolean-mask semantics as the Qwen3-Next / Qwen3.5 layers call it
+ * (qwen3_next_attention.py:238-254, qwen3_5_text_model.py:244-259): causal, -inf fill, and -- as upstream -- padded keys
+ * (key_mask == 0) visible to every query.  D in {32, 64, 128, 256}.  Operand layout as mi355_attn_fwd/bwd. */
+int mi355_attn_generic_fwd(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
+                           int64_t ldv, void* o, int64_t ldo, float* lse, const uint8_t* key_mask, float scale, void* stream);
+int mi355_attn_generic_bwd(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
+                           int64_t ldv, const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* lse, float* delta, void* dq,
+                           int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, const uint8_t* key_mask, float scale, void* stream);
+
+/* GDN gates (qwen3_5_text_model.py:115-117, compute_alpha_factor qwen3_next_attention.py:71-100): b_lin / a_lin = the w_beta /
+ * w_alpha columns of proj (bf16, row pitch ld).  beta = sigmoid(b_lin) (bf16-rounded), alpha = exp(-exp(log_A) *
+ * softplus(a_lin + dt_bias)); both fp32 [tokens, Hv]. */
+int mi355_gdn_gates_fwd(int64_t tokens, int Hv, const void* b_lin, const void* a_lin, int64_t ld, const float* log_A, const void* dt_bias,
+                        float* beta, float* alpha, void* stream);
+/* dparam_partial fp32 [parts, 2*Hv] = (dlog_A | ddt_bias) per block. */
+int mi355_gdn_gates_bwd(int64_t tokens, int Hv, const void* b_lin, const void* a_lin, int64_t ld, const float* log_A, const void* dt_bias,
+                        const float* dbeta, const float* dalpha, void* db_lin, void* da_lin, int64_t ldd, float* dparam_partial, int parts,
+                        void* stream);
+
+/* Depthwise causal Conv1d(kernel 4, left padding 3, cropped to S) + SiLU over the sequence axis of the token-major fused QKV
+ * projection (qwen3_5_text_model.py:81-90,138-140).  x bf16 [B*S, C] row pitch ldx; w bf16 [C, 4]; y bf16 [B*S, C]. */
+int mi355_causal_conv_silu_fwd(int B, int S, int C, int ksize, const void* x, int64_t ldx, const void* w, void* y, void* stream);
+/* dc_ws bf16 [B*S, C] scratch; dx row pitch lddx; dw_partial fp32 [B*ceil(S/token_chunk), C*4]. */
+int mi355_causal_conv_silu_bwd(int B, int S, int C, int ksize, const void* x, int64_t ldx, const void* w, const void* dy, void* dc_ws, void* dx,
+                               int64_t lddx, float* dw_partial, int token_chunk, void* stream);
+
+/* l2_norm of q / k heads (qwen3_next_attention.py:51-60): x heads at x[t*ldx + h*D]; y bf16 [tokens, H*D]. */
+int mi355_l2norm_fwd(int64_t tokens, int H, int D, const void* x, int64_t ldx, void* y, void* stream);
+int mi355_l2norm_bwd(int64_t tokens, int H, int D, const void* x, int64_t ldx, const void* dy, void* dx, int64_t lddx, void* stream);
+
+/* gated_delta_rule (qwen3_next_attention.py:103-159), fp32 state, q/k bf16 [B*S, Hqk*Dk] (already l2-normalised), v bf16
+ * [B*S, Hv*Dv] row pitch ldv, beta/alpha fp32 [B*S, Hv]; value head h uses q/k head h / (Hv/Hqk) (repeat_interleave).
+ * o bf16 [B*S, Hv*Dv].  checkpoints (training): fp32 [B, Hv, ceil(S/chunk), Dv, Dk], chunk = mi355_gated_delta_rule_chunk().
+ * final_state (optional): fp32 [B, Hv, Dv, Dk].  Dk in {16, 128}; Dv % 16 == 0. */
+int mi355_gated_delta_rule_chunk(void);
+int mi355_gated_delta_rule_fwd(int B, int S, int Hqk, int Hv, int Dk, int Dv, const void* q, const void* k, const void* v, int64_t ldv,
+                               const float* beta, const float* alpha, void* o, float* checkpoints, float* final_state, void* stream);
+int64_t mi355_gated_delta_rule_bwd_workspace_bytes(int B, int S, int Hv, int Dk, int Dv);
+int mi355_gated_delta_rule_bwd(int B, int S, int Hqk, int Hv, int Dk, int Dv, const void* q, const void* k, const void* v, int64_t ldv,
+                               const float* beta, const float* alpha, const float* checkpoints, const void* d_o, void* dq, void* dk, void* dv,
+                               int64_t lddv, float* dbeta, float* dalpha, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* out = bf16(silu(float(gate)) * RMSNorm_fp32(float(o)))  (post_norm + output gate, qwen3_5_text_model.py:181-187): o bf16
+ * [tokens, H*D], w fp32 [D], gate bf16 at gate[t*ldg + h*D]. */
+int mi355_gated_rmsnorm_fwd(int64_t tokens, int H, int D, const void* o, const float* w, const void* gate, int64_t ldg, void* out, float* rstd,
+                            float eps, void* stream);
+int mi355_gated_rmsnorm_bwd(int64_t tokens, int H, int D, const void* o, const float* w, const void* gate, int64_t ldg, const float* rstd,
+                            const void* dout, void* d_o, void* dgate, int64_t lddg, float* dw_partial, int parts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

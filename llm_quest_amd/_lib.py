@@ -55,6 +55,31 @@ SIGNATURES = {
     "mi355_patchify3d": [_I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "mi355_merge_patches": [_L, _I, _I, _I, _L, _P, _P, _I, _P],
     "mi355_scatter_rows": [_L, _L, _P, _P, _P, _P, _P, _P, _I, _P],
+    # Qwen3.5 text stack (csrc/qwen35.hip, csrc/attention_generic.hip)
+    "mi355_zc_weight": [_L, _P, _P, _P],
+    "mi355_mrope_table": [_L, _I, _L, _P, _P, _P, _I, _I, _P, _P, _P],
+    "mi355_rowmask": [_L, _I, _P, _P, _P, _P],
+    "mi355_headnorm_rope_fwd": [_L, _I, _I, _I, _P, _L, _L, _P, _P, _P, _P, _P, _P, _F, _P],
+    "mi355_headnorm_rope_bwd": [_L, _I, _I, _I, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _L, _L, _P, _I, _P],
+    "mi355_sigmoid_gate_fwd": [_L, _I, _I, _P, _P, _L, _L, _P, _P],
+    "mi355_sigmoid_gate_bwd": [_L, _I, _I, _P, _P, _L, _L, _P, _P, _P, _L, _L, _P],
+    "mi355_attn_generic_fwd": [_I, _I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _F, _P],
+    "mi355_attn_generic_bwd": [_I, _I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _L, _P, _L, _P, _L, _P, _F, _P],
+    "mi355_gdn_gates_fwd": [_L, _I, _P, _P, _L, _P, _P, _P, _P, _P],
+    "mi355_gdn_gates_bwd": [_L, _I, _P, _P, _L, _P, _P, _P, _P, _P, _P, _L, _P, _I, _P],
+    "mi355_causal_conv_silu_fwd": [_I, _I, _I, _I, _P, _L, _P, _P, _P],
+    "mi355_causal_conv_silu_bwd": [_I, _I, _I, _I, _P, _L, _P, _P, _P, _P, _L, _P, _I, _P],
+    "mi355_l2norm_fwd": [_L, _I, _I, _P, _L, _P, _P],
+    "mi355_l2norm_bwd": [_L, _I, _I, _P, _L, _P, _P, _L, _P],
+    "mi355_gated_delta_rule_fwd": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P],
+    "mi355_gated_delta_rule_bwd": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _P],
+    "mi355_gated_rmsnorm_fwd": [_L, _I, _I, _P, _P, _P, _L, _P, _P, _F, _P],
+    "mi355_gated_rmsnorm_bwd": [_L, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _L, _P, _I, _P],
+}
+# size / constant queries: no stream argument, the return value is the answer (name -> (argtypes, restype))
+QUERIES = {
+    "mi355_gated_delta_rule_chunk": ([], _I),
+    "mi355_gated_delta_rule_bwd_workspace_bytes": ([_I, _I, _I, _I, _I], _L),
 }
 
 _lib = None
@@ -89,6 +114,10 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
+    for name, (argtypes, restype) in QUERIES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
     _lib = lib
     return lib
 

@@ -13,14 +13,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def header_functions():
     text = open(os.path.join(ROOT, "include", "mi355_vlm.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|const char\*)\s+(mi355_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(?:int|int64_t|const char\*)\s+(mi355_\w+)\s*\(", text)))
 
 
 def test_header_and_binding_agree():
     from llm_quest_amd import _lib
 
     declared = set(header_functions())
-    bound = set(_lib.SIGNATURES) | {"mi355_last_error", "mi355_abi_version"}
+    bound = set(_lib.SIGNATURES) | set(_lib.QUERIES) | {"mi355_last_error", "mi355_abi_version"}
     assert declared == bound, f"header-only: {declared - bound}; binding-only: {bound - declared}"
 
 
@@ -40,10 +40,11 @@ def test_argument_counts_match_header():
 
     text = open(os.path.join(ROOT, "include", "mi355_vlm.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    for name, argtypes in _lib.SIGNATURES.items():
+    queries = {n: a for n, (a, _) in _lib.QUERIES.items()}
+    for name, argtypes in {**_lib.SIGNATURES, **queries}.items():
         m = re.search(r"\b" + name + r"\s*\((.*?)\)\s*;", text, flags=re.S)
         assert m, name
-        nargs = len([a for a in m.group(1).split(",") if a.strip()])
+        nargs = len([a for a in m.group(1).split(",") if a.strip() and a.strip() != "void"])
         assert nargs == len(argtypes) + 0, f"{name}: header has {nargs} args, binding {len(argtypes)}"
 
 
