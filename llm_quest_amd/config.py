@@ -49,3 +49,19 @@ def qwen3_config_creator(model_size="0.6B", base_model=True):
     }
     cfg.update(_QWEN3_DENSE[model_size])
     return cfg
+
+
+# Qwen3.5-0.8B, vision + text (reference config.py:361-416; keys are the constructor API of Qwen3_5VLM / Qwen3_5TextModel)
+QWEN3_5_08B_CONFIG = {
+    "model_path": "Qwen/Qwen3.5-0.8B",
+    "vocab_size": 248_320, "emb_dim": 1024, "hidden_dim": 3584, "n_layers": 24, "linear_sdpa_ratio": 4, "n_heads": 8, "num_kv_groups": 2,
+    "head_dim": 256, "rope_base": 10_000_000, "partial_rope_factor": 0.25, "context_length": 8192,
+    "linear_num_qk_heads": 16, "linear_num_value_heads": 16, "linear_qk_head_dim": 128, "linear_value_head_dim": 128,
+    "linear_conv_kernel_size": 4, "tie_embeddings": True, "dtype": torch.bfloat16, "p_dropout": 0.0, "training": False,
+    "mrope_section": [11, 11, 10],
+    "vision_n_layers": 12, "vision_emb_dim": 768, "vision_hidden_act": "gelu_pytorch_tanh", "vision_hidden_dim": 3072, "vision_num_heads": 12,
+    "llm_d_in": 1024, "in_channels": 3, "patch_size": 16, "spatial_merge_size": 2, "temporal_patch_size": 2, "num_position_embeddings": 2304,
+    "img_width": 384, "img_height": 384, "vision_rope_base": 10_000,
+    "image_token_id": 248056, "vision_start_token_id": 248053, "vision_end_token_id": 248054, "video_token_id": 248057,
+    "image_mean": [0.5, 0.5, 0.5], "image_std": [0.5, 0.5, 0.5],
+}

@@ -1,9 +1,8 @@
 """Qwen3.5 multimodal wrapper pieces on HIP kernels -- API of ``llm_quest/qwen/qwen3_5/qwen3_5_vlm_model.py``.
 
-Native so far (BASELINE config 5): the vision tower, the masked-scatter early fusion
-and the 3-D MRoPE position ids.  The hybrid text stack (gated delta net + gated attention, row a24) is not built yet, so
-``Qwen3_5VLM`` takes the language model as an argument: anything with ``emb_dict`` and a
-``forward(inputs_embs=..., position_ids=..., attn_mask=...)`` of the reference's ``Qwen3_5TextModel`` signature.
+BASELINE config 5: the vision tower, the masked-scatter early fusion, the 3-D MRoPE position
+ids and the hybrid text stack (``Qwen3_5TextModel``: gated delta net + gated attention) all run on HIP kernels.  ``language_model``
+may still be passed in (anything with ``emb_dict`` and the reference's ``forward(inputs_embs=..., position_ids=..., attn_mask=...)``).
 """
 
 import torch
@@ -53,10 +52,9 @@ class Qwen3_5VLM(nn.Module):
         self.cfg = cfg
         self.vision_model = Qwen3_5VisionModel(cfg)
         if language_model is None:
-            raise NotImplementedError(
-                "the Qwen3.5 hybrid text stack (FusedGatedDeltaNet / MRoPEGatedAttention) is not built natively yet "
-                "(DESIGN.md section 7); pass a language_model with the reference's Qwen3_5TextModel interface"
-            )
+            from llm_quest_amd.qwen.qwen3_5.qwen3_5_text_model import Qwen3_5TextModel
+
+            language_model = Qwen3_5TextModel(cfg)
         self.language_model = language_model
 
     def get_feeds_3d_shape(self, image_pixels):

@@ -333,3 +333,190 @@ def test_attention_generic_forward_backward(B, S, Hq, Hkv, D, masked):
     # determinism
     o2, _ = Q.attn_generic_fwd(qd, kd, vd, B, S, Hq, Hkv, D, key_mask=km)
     assert torch.equal(o, o2)
+
+
+# ------------------------------------------------------------------------------------------------- layers and the tiny hybrid model
+from oracle.gen_golden import TINY_Q35_TEXT
+
+
+def _fp32_twin(sd):
+    return {k: (v.float() if v.dtype == BF16 else v) for k, v in sd.items()}
+
+
+def _twin_forward_backward(sd, cfg, ids, am, pid, gout):
+    """fp32 twin of the reference model (same weights upcast) through the oracle, with autograd: logits + parameter gradients."""
+    tw = _fp32_twin(sd)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in tw.items() if v.dtype == F32 and k not in ("cos", "sin")}
+    full = {**tw, **leaves}
+    full["mask"] = sd["mask"].bool()
+    if cfg["tie_embeddings"]:
+        full["out_head.weight"] = full["emb_dict.weight"]
+    logits = OT.text_model_forward(full, cfg, x=ids, attn_mask=am, position_ids=pid)
+    (logits * gout).sum().backward()
+    return logits.detach(), {k: v.grad for k, v in leaves.items() if v.grad is not None}
+
+
+def test_tiny_hybrid_model_forward_backward_vs_reference(golden):
+    from llm_quest_amd.qwen.qwen3_5.qwen3_5_text_model import Qwen3_5TextModel
+
+    t = golden("qwen35_text_tiny")
+    cfg = {**TINY_Q35_TEXT, "dtype": BF16}
+    sd = sub_dict(t, "txt.bf16.sd.")
+    ids, am, pid, gout = t["txt.ids"], t["txt.attn_mask"].bool(), t["txt.pid"], t["txt.gout"]
+    m = Qwen3_5TextModel(cfg)
+    assert set(m.state_dict()) == set(sd)
+    m.load_state_dict({k: (v.bool() if k == "mask" else v) for k, v in sd.items()})
+    m = m.cuda().train()
+    twin_logits, twin_grads = _twin_forward_backward(sd, cfg, ids, am, pid, gout)
+    logits = m(ids.cuda(), attn_mask=am.cuda(), position_ids=pid.cuda())
+    assert logits.dtype == BF16 and logits.shape == t["txt.bf16.logits"].shape
+    floor = rel_l2(t["txt.bf16.logits"], twin_logits)  # the reference's own bf16 noise vs its fp32 twin
+    mine = rel_l2(logits, twin_logits)
+    assert mine <= 1.5 * floor + 1e-3, f"logits vs fp32 twin {mine:.3e}, reference floor {floor:.3e}"
+    assert rel_l2(logits, t["txt.bf16.logits"]) <= 2.0 * floor + 1e-3
+    (logits.float() * gout.cuda()).sum().backward()
+    report, bad = [], []
+    for name, p in m.named_parameters():
+        if name == "out_head.weight":
+            continue
+        ref = t["txt.bf16.grad." + name]
+        assert p.grad is not None and p.grad.dtype == ref.dtype and p.grad.shape == ref.shape, name
+        tg = twin_grads[name]
+        floor_g = rel_l2(ref, tg)
+        mine_g = rel_l2(p.grad, tg)
+        # gate parameters with a handful of elements (log_A, dt_bias, w_alpha: 4 value heads here) carry the bf16 rounding of
+        # softplus / sigmoid in both implementations; their noise is not averaged over many elements, hence the wider factor
+        factor = 2.5 if ref.numel() <= 256 and ("log_A" in name or "dt_bias" in name or "w_alpha" in name or "w_beta" in name) else 1.5
+        report.append(f"{name}: mine {mine_g:.3e} floor {floor_g:.3e}")
+        if mine_g > factor * floor_g + 4e-3:
+            bad.append(report[-1])
+    print("\n".join(report))
+    assert not bad, bad
+    # text-only path (no position ids, no mask): 1-D RoPE through GatedAttention.forward
+    with torch.no_grad():
+        lt = m.eval()(ids.cuda())
+    tw = _fp32_twin(sd)
+    tw["mask"] = sd["mask"].bool()
+    tw["out_head.weight"] = tw["emb_dict.weight"]
+    twin_t = OT.text_model_forward(tw, cfg, x=ids)
+    floor_t = rel_l2(t["txt.bf16.logits_text_only"], twin_t)
+    assert rel_l2(lt, twin_t) <= 1.5 * floor_t + 1e-3
+
+
+def _layer_cfg():
+    return dict(emb_dim=1024, hidden_dim=3584, n_heads=8, num_kv_groups=2, head_dim=256, rope_base=10_000_000, partial_rope_factor=0.25,
+                context_length=256, linear_num_qk_heads=16, linear_num_value_heads=16, linear_qk_head_dim=128, linear_value_head_dim=128,
+                linear_conv_kernel_size=4, p_dropout=0.0, training=False, mrope_section=[11, 11, 10], dtype=BF16, linear_sdpa_ratio=4,
+                vocab_size=512, n_layers=1, tie_embeddings=True)
+
+
+@pytest.mark.parametrize("kind", ["gdn", "attention"])
+def test_real_width_blocks_vs_oracle(kind):
+    """One Qwen3.5-0.8B-sized block (d 1024, GDN 16x128 heads / gated attention 8x256 heads over 2 kv groups, ffn 3584) forward and
+    backward vs the oracle: bf16 oracle for the output (reference arithmetic), fp32 twin for gradients."""
+    from llm_quest_amd.common.buffers import GlobalBuffers
+    from llm_quest_amd.qwen.qwen3_5.qwen3_5_text_model import Qwen3_5TransformerBlock
+
+    torch.manual_seed(11)
+    cfg = _layer_cfg()
+    layer_idx = 0 if kind == "gdn" else 3
+    blk = Qwen3_5TransformerBlock(cfg, layer_idx)
+    with torch.no_grad():
+        for n_, p_ in blk.named_parameters():
+            if n_.endswith("scale") or n_.endswith("post_norm.weight") or n_.endswith("dt_bias"):
+                p_.add_((0.1 * torch.randn(p_.shape)).to(p_.dtype))
+    sd = {"trf_blocks.0." + k: v.detach().clone() for k, v in blk.state_dict().items()}
+    b, s = 2, 75
+    x = torch.randn(b, s, 1024).to(BF16)
+    am = torch.ones(b, s, dtype=torch.bool)
+    am[1, 70:] = False
+    pid = torch.arange(s).view(1, 1, s).repeat(3, b, 1)
+    pid[1, :, 10:30] = 10 + torch.arange(20) // 5
+    pid[2, :, 10:30] = 10 + torch.arange(20) % 5
+    cos, sin = GlobalBuffers.get_rope_params(256, cfg["rope_base"], 256, rotation_factor=0.25)
+    allow = ~GlobalBuffers.get_causal_mask(256)
+    ocfg = {**cfg, "linear_sdpa_ratio": 1 if kind == "attention" else 4}  # oracle decides the layer kind from the index
+    want = OT.block(sd, "trf_blocks.0.", ocfg, 0, x, allow, cos, sin, pid, am)
+    tw = {k: (v.float().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    xf = x.float().requires_grad_(True)
+    ref32 = OT.block(tw, "trf_blocks.0.", ocfg, 0, xf, allow, cos, sin, pid, am)
+    g = torch.randn(b, s, 1024).to(BF16)
+    ref32.backward(g.float())
+    blk = blk.cuda().train()
+    xd = x.cuda().requires_grad_(True)
+    y = blk(xd, allow.cuda(), cos.cuda(), sin.cuda(), pid.cuda(), am.cuda())
+    floor = rel_l2(want, ref32)
+    assert rel_l2(y, ref32) <= 1.5 * floor + 1e-3, (rel_l2(y, ref32), floor)
+    y.backward(g.cuda())
+    assert rel_l2(xd.grad, xf.grad) < 2e-2
+    for name, p in blk.named_parameters():
+        tg = tw["trf_blocks.0." + name].grad
+        assert p.grad is not None, name
+        err = float((p.grad.double().cpu() - tg.double()).norm())
+        assert err <= 3e-2 * float(tg.double().norm()) + 1e-4, f"{name}: |err| {err:.3e} |ref| {float(tg.norm()):.3e}"
+
+
+def test_functional_gated_delta_rule_has_the_reference_signature(golden):
+    from llm_quest_amd.qwen.qwen3_next.qwen3_next_attention import gated_delta_rule
+
+    t = golden("qwen35_text_tiny")
+    q, k, v, beta, alpha = (t["gdr." + n].cuda().requires_grad_(True) for n in ("q", "k", "v", "beta", "alpha"))
+    o, state = gated_delta_rule(q, k, v, beta, alpha)
+    assert o.dtype == BF16 and ulp_diff(o, t["gdr.out"]) <= 1 and rel_l2(state, t["gdr.state"]) < 1e-5
+    (o.float() * t["gdr.gout"].cuda()).sum().backward()
+    for ten, name in ((q, "q"), (k, "k"), (v, "v"), (beta, "beta"), (alpha, "alpha")):
+        assert ten.grad.dtype == t["gdr.grad." + name].dtype and rel_l2(ten.grad, t["gdr.grad." + name]) < 8e-3, name
+
+
+def test_text_model_loss_path_and_determinism():
+    """forward_hidden + lm_loss == CE of forward()'s logits; two identical steps give bit-identical gradients."""
+    from llm_quest_amd.qwen.qwen3_5.qwen3_5_text_model import Qwen3_5TextModel
+
+    torch.manual_seed(12)
+    cfg = {**TINY_Q35_TEXT, "dtype": BF16}
+    m = Qwen3_5TextModel(cfg).cuda().train()
+    ids = torch.randint(0, 256, (3, 33)).cuda()
+    tgt = torch.randint(0, 256, (3, 33)).cuda()
+
+    def step():
+        m.zero_grad(set_to_none=True)
+        h = m.forward_hidden(ids)
+        loss = m.lm_loss(h.reshape(-1, h.shape[-1]), tgt)
+        loss.backward()
+        return loss.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if n != "out_head.weight"}
+
+    l1, g1 = step()
+    l2, g2 = step()
+    assert torch.equal(l1, l2) and all(torch.equal(g1[n], g2[n]) for n in g1)
+    with torch.no_grad():
+        logits = m(ids)
+    ref = F.cross_entropy(logits.float().flatten(0, 1), tgt.flatten())
+    assert abs(float(l1) - float(ref)) / float(ref) < 1e-3
+
+
+def test_qwen35_vlm_composes_vision_scatter_mrope_and_text_stack():
+    """Qwen3_5VLM.forward == text model on (scatter(emb, vision tower), 3-D position ids): every piece is pinned on its own above
+    and in test_qwen35_gpu.py; this checks the composition, bit for bit, and that a loss reaches every parameter."""
+    from oracle.gen_golden import TINY_Q35_VISION
+    from llm_quest_amd.qwen.qwen3_5.qwen3_5_vlm_model import Qwen3_5VLM, fuse_vision_embeddings
+
+    torch.manual_seed(13)
+    cfg = {**TINY_Q35_TEXT, **TINY_Q35_VISION, "dtype": BF16, "emb_dim": 128, "llm_d_in": 128, "image_token_id": 255, "n_heads": 2, "head_dim": 32}
+    vlm = Qwen3_5VLM(cfg).cuda().train()
+    n_img = (4 // 2) * (4 // 2) * (4 // 2)  # frames/2 x (32/8/2)^2 merged rows
+    ids = torch.randint(0, 250, (2, 30))
+    ids[:, 5 : 5 + n_img] = 255
+    pix = torch.randn(2, 3, 4, 32, 32)
+    logits = vlm(ids.cuda(), image_pixels=pix.cuda())
+    assert logits.shape == (2, 30, 256) and logits.dtype == BF16
+    lm = vlm.language_model
+    with torch.no_grad():
+        emb = fuse_vision_embeddings(lm.emb_dict(ids.cuda()), (ids == 255).cuda(), vlm.vision_model(pix.cuda()))
+        pos = vlm.compute_3d_position_ids(ids.cuda(), vlm.get_feeds_3d_shape(pix.cuda()))
+        manual = lm(inputs_embs=emb, position_ids=pos)
+    assert torch.equal(logits.detach(), manual)
+    F.cross_entropy(logits.float().flatten(0, 1), torch.randint(0, 256, (60,)).cuda()).backward()
+    for name, p in vlm.named_parameters():
+        if name.endswith("out_head.weight"):
+            continue
+        assert p.grad is not None and torch.isfinite(p.grad.float()).all(), name
