@@ -37,11 +37,33 @@ __device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
     for (int e = 0; e < 4; ++e) o[e] = pack_bf2(f[2 * e], f[2 * e + 1]);
     return o;
 }
+// Cross-lane sums on the VALU (DPP / permlane swaps), not through the LDS crossbar: ds_bpermute (what __shfl_xor compiles to)
+// costs an LDS round trip per step of every reduction, and the recurrence kernels below are one dependent chain per time step.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
 template <int W>
-__device__ __forceinline__ float lanes_sum(float v) {  // all-reduce over aligned groups of W lanes
-#pragma unroll
-    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+__device__ __forceinline__ float lanes_sum(float v) {  // all-reduce over aligned groups of W (4, 8 or 16) lanes
+    static_assert(W == 4 || W == 8 || W == 16, "lanes_sum: 4, 8 or 16");
+    if constexpr (W == 16) {
+        v += dpp_f<0x128>(v);  // row_ror:8
+        v += dpp_f<0x124>(v);  // row_ror:4
+        v += dpp_f<0x122>(v);  // row_ror:2
+        v += dpp_f<0x121>(v);  // row_ror:1
+    } else {
+        v += dpp_f<0xB1>(v);  // quad_perm:[1,0,3,2]
+        v += dpp_f<0x4E>(v);  // quad_perm:[2,3,0,1]
+        if constexpr (W == 8) v += dpp_f<0x141>(v);  // row_half_mirror: the other quad of the 8-lane group
+    }
     return v;
+}
+// v[lane] + v[lane ^ 16] + v[lane ^ 32] + v[lane ^ 48]: the same element of the wave's four 16-lane rows
+__device__ __forceinline__ float rows_sum(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
 // ------------------------------------------------------------------------------------------- small helpers
@@ -478,36 +500,51 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(int64_t tokens, int H, 
 // ------------------------------------------------------------------------------------------- gated delta rule
 // Reference: qwen3_next_attention.py:103-159 (fp32 recurrence on bf16 operands).  Row i of the state obeys
 //     G_i = a S_i ;  u_i = G_i . k ;  c_i = b (v_i - u_i) ;  S_i <- G_i + c_i k ;  o_i = S_i . (q / sqrt(dk))
-// independently of every other row, so the kernel spreads rows over lanes and keeps the time loop inside.
-// Forward layout: 4 lanes per row (CPL = Dk/4 columns each), 16 rows per wave; the two dot products close with two
-// quad-permute adds.  Checkpoints of S every CH steps feed the backward pass.
-template <int CPL>
-struct GdrVec {
-    float k[CPL], q[CPL];
+// independently of every other row, so the kernels spread rows over lanes and keep the time loop inside.  A time step is one
+// dependent chain; what hides its latencies is (1) operands of step t+1 requested as RAW bf16 words before step t's arithmetic
+// and unpacked only when used, (2) cross-lane sums on DPP / permlane, (3) in the forward, two waves per SIMD.
+template <int N>
+struct RawVec {  // N bf16 values as they come from memory
+    unsigned w[(N + 1) / 2];
 };
-template <int CPL>
-__device__ __forceinline__ void load_bf16_vec(const bf16_t* p, float (&f)[CPL]) {
-    if constexpr (CPL % 8 == 0) {
+template <int N>
+__device__ __forceinline__ void raw_load(RawVec<N>& r, const bf16_t* p) {
+    if constexpr (N % 8 == 0) {
 #pragma unroll
-        for (int i = 0; i < CPL / 8; ++i) unpack8(*reinterpret_cast<const u32x4*>(p + 8 * i), *reinterpret_cast<float(*)[8]>(&f[8 * i]));
+        for (int i = 0; i < N / 8; ++i) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(p + 8 * i);
+            r.w[4 * i] = v[0];
+            r.w[4 * i + 1] = v[1];
+            r.w[4 * i + 2] = v[2];
+            r.w[4 * i + 3] = v[3];
+        }
+    } else if constexpr (N % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) r.w[i] = *reinterpret_cast<const unsigned*>(p + 2 * i);
     } else {
-#pragma unroll
-        for (int i = 0; i < CPL; ++i) f[i] = bf2f(p[i]);
+        static_assert(N == 1, "odd vectors: one element only");
+        r.w[0] = *p;
     }
 }
+template <int N>
+__device__ __forceinline__ float raw_get(const RawVec<N>& r, int i) {
+    return (i & 1) ? __uint_as_float(r.w[i >> 1] & 0xffff0000u) : __uint_as_float(r.w[i >> 1] << 16);
+}
 
-template <int CPL>
+// Forward layout: LPR lanes per row (CPL = DK / LPR columns each), 64 / LPR rows per wave; the two dot products of a step close
+// with log2(LPR) DPP adds.  Checkpoints of S every CH steps feed the backward pass.
+template <int DK, int LPR>
 __global__ __launch_bounds__(256) void gdr_fwd_kernel(int B, int S, int Hqk, int Hv, int Dv, const bf16_t* __restrict__ q,
                                                       const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t ldv,
                                                       const float* __restrict__ beta, const float* __restrict__ alpha,
                                                       bf16_t* __restrict__ o, float* __restrict__ ckpt, int CH, int nchunk,
                                                       float* __restrict__ final_state, float qscale) {
-    constexpr int DK = 4 * CPL;
+    constexpr int CPL = DK / LPR, RPW = 64 / LPR;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int row0 = blockIdx.x * 64 + wave * 16;
-    if (row0 >= Dv) return;  // whole wave out of range (Dv is a multiple of 16); no block-level synchronisation below
-    const int row = row0 + (lane >> 2), cg = lane & 3;
+    const int row0 = (blockIdx.x * 4 + wave) * RPW;
+    if (row0 >= Dv) return;  // whole wave out of range (Dv is a multiple of 16 >= RPW); no block-level synchronisation below
+    const int row = row0 + lane / LPR, cg = lane % LPR;
     const int hq = h / (Hv / Hqk);
     const int64_t tok0 = (int64_t)b * S;
     const int64_t ldqk = (int64_t)Hqk * DK;
@@ -520,20 +557,21 @@ __global__ __launch_bounds__(256) void gdr_fwd_kernel(int B, int S, int Hqk, int
     float st[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) st[j] = 0.f;
-    float kc[CPL], qc[CPL], kn[CPL], qn[CPL];
-    float a_c, b_c, v_c, a_n = 0.f, b_n = 0.f, v_n = 0.f;
-    load_bf16_vec<CPL>(kp, kc);
-    load_bf16_vec<CPL>(qp, qc);
+    RawVec<CPL> kc, qc, kn, qn;
+    float a_c, b_c, a_n = 0.f, b_n = 0.f;
+    bf16_t v_c, v_n = 0;
+    raw_load<CPL>(kc, kp);
+    raw_load<CPL>(qc, qp);
     a_c = ap[0];
     b_c = bp[0];
-    v_c = bf2f(vp[0]);
+    v_c = vp[0];
     for (int t = 0; t < S; ++t) {
-        if (t + 1 < S) {  // next step's operands are in flight under this step's arithmetic
-            load_bf16_vec<CPL>(kp + (t + 1) * ldqk, kn);
-            load_bf16_vec<CPL>(qp + (t + 1) * ldqk, qn);
+        if (t + 1 < S) {
+            raw_load<CPL>(kn, kp + (t + 1) * ldqk);
+            raw_load<CPL>(qn, qp + (t + 1) * ldqk);
             a_n = ap[(int64_t)(t + 1) * Hv];
             b_n = bp[(int64_t)(t + 1) * Hv];
-            v_n = bf2f(vp[(t + 1) * ldv]);
+            v_n = vp[(t + 1) * ldv];
         }
         if (ckpt && t % CH == 0) {
             float* c = ckpt + ((((int64_t)b * Hv + h) * nchunk + t / CH) * Dv + row) * DK + cg * CPL;
@@ -544,23 +582,20 @@ __global__ __launch_bounds__(256) void gdr_fwd_kernel(int B, int S, int Hqk, int
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
             st[j] *= a_c;
-            u = fmaf(st[j], kc[j], u);
+            u = fmaf(st[j], raw_get<CPL>(kc, j), u);
         }
-        u = lanes_sum<4>(u);
-        const float c = b_c * (v_c - u);
+        u = lanes_sum<LPR>(u);
+        const float c = b_c * (bf2f(v_c) - u);
         float oo = 0.f;
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
-            st[j] = fmaf(c, kc[j], st[j]);
-            oo = fmaf(st[j], qc[j] * qscale, oo);
+            st[j] = fmaf(c, raw_get<CPL>(kc, j), st[j]);
+            oo = fmaf(st[j], raw_get<CPL>(qc, j), oo);
         }
-        oo = lanes_sum<4>(oo);
-        if (cg == 0) op[(int64_t)t * Hv * Dv] = f2bf(oo);
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-            kc[j] = kn[j];
-            qc[j] = qn[j];
-        }
+        oo = lanes_sum<LPR>(oo);
+        if (cg == 0) op[(int64_t)t * Hv * Dv] = f2bf(oo * qscale);
+        kc = kn;
+        qc = qn;
         a_c = a_n;
         b_c = b_n;
         v_c = v_n;
@@ -575,25 +610,29 @@ __global__ __launch_bounds__(256) void gdr_fwd_kernel(int B, int S, int Hqk, int
 // Backward layout: a lane owns 4 rows x CPL columns, 16 lanes span Dk = 16*CPL, a wave owns 16 rows (4 row quads).  Row dot
 // products close inside 16-lane groups, the sums over rows (dq, dk, dbeta, dalpha) inside the lane and across the 4 quads;
 // each wave writes its partial sums for its 16 rows, a second kernel adds the row groups (and the value heads that share a
-// q/k head).  Per chunk of CH steps (last chunk first): phase A replays the forward from the chunk's checkpoint and parks
-// S_{t-1} of every step in the wave's scratch, phase B walks the chunk backwards.
+// q/k head).  The reverse step t needs S_{t-1}.  Parking every S_{t-1} in HBM made the first version of this kernel purely
+// bandwidth-bound (2 x 5.9 GB per layer at B = 8: 3.1 ms); now the forward leaves a checkpoint every GDR_CH = 4 steps
+// (1.45 GB per layer), and per chunk (last first) phase A replays the 4 steps from the checkpoint parking S_{t-1} in LDS
+// (each lane's own 16-byte slots, [step][vector][lane]: conflict-free, no barrier -- nobody else reads them), phase B walks
+// the chunk backwards.  Operands and checkpoint of the NEXT chunk are requested before the current chunk's arithmetic.
+constexpr int GDR_CH = 4;
 template <int CPL>
-struct GdrStep {
-    float k[CPL], q[CPL];
-    float a, b, v[4], g[4];
+struct GdrOps {
+    RawVec<CPL> k, q;
+    float a, b;
+    bf16_t v[4], g[4];
 };
-template <int CPL, bool WITH_G>
-__device__ __forceinline__ void gdr_load_step(GdrStep<CPL>& s, const bf16_t* kp, const bf16_t* qp, const bf16_t* vp, const bf16_t* gp,
-                                              const float* ap, const float* bp) {
-    load_bf16_vec<CPL>(kp, s.k);
+template <int CPL>
+__device__ __forceinline__ void gdr_load_ops(GdrOps<CPL>& s, const bf16_t* kp, const bf16_t* qp, const bf16_t* vp, const bf16_t* gp,
+                                             const float* ap, const float* bp) {
+    raw_load<CPL>(s.k, kp);
+    raw_load<CPL>(s.q, qp);
     s.a = *ap;
     s.b = *bp;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) s.v[r] = bf2f(vp[r]);
-    if constexpr (WITH_G) {
-        load_bf16_vec<CPL>(qp, s.q);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s.g[r] = bf2f(gp[r]);
+    for (int r = 0; r < 4; ++r) {
+        s.v[r] = vp[r];
+        s.g[r] = gp[r];
     }
 }
 
@@ -601,11 +640,11 @@ template <int CPL>
 __global__ __launch_bounds__(256) void gdr_bwd_kernel(int B, int S, int Hqk, int Hv, int Dv, const bf16_t* __restrict__ q,
                                                       const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t ldv,
                                                       const float* __restrict__ beta, const float* __restrict__ alpha,
-                                                      const float* __restrict__ ckpt, int CH, int nchunk, const bf16_t* __restrict__ d_o,
-                                                      bf16_t* __restrict__ dv, int64_t lddv, float* __restrict__ states,
-                                                      float* __restrict__ pdq, float* __restrict__ pdk, float* __restrict__ pdb,
-                                                      float* __restrict__ pda, float qscale) {
+                                                      const float* __restrict__ ckpt, int nchunk, const bf16_t* __restrict__ d_o,
+                                                      bf16_t* __restrict__ dv, int64_t lddv, float* __restrict__ pdq,
+                                                      float* __restrict__ pdk, float* __restrict__ pdb, float* __restrict__ pda, float qscale) {
     constexpr int DK = 16 * CPL;
+    __shared__ f32x4 park[4][GDR_CH][CPL][64];  // [wave][step][vector of the lane's 4*CPL state floats][lane]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.z, h = blockIdx.y;
     const int rg = blockIdx.x * 4 + wave, RG = Dv / 16;
@@ -622,130 +661,150 @@ __global__ __launch_bounds__(256) void gdr_bwd_kernel(int B, int S, int Hqk, int
     const bf16_t* gp = d_o + tok0 * Hv * Dv + (int64_t)h * Dv + row;
     const float* ap = alpha + tok0 * Hv + h;
     const float* bp = beta + tok0 * Hv + h;
+    const float* ckp = ckpt + ((((int64_t)b * Hv + h) * nchunk) * Dv + row) * DK + col;  // + chunk*Dv*DK + r*DK + j
     const int64_t slot = ((int64_t)b * Hv + h) * RG + rg;
-    float* st = states + slot * (int64_t)CH * 16 * DK + (rq * 4) * DK + col;  // + step*16*DK + r*DK + j
     float* wq = pdq + slot * (int64_t)S * DK + col;
     float* wk = pdk + slot * (int64_t)S * DK + col;
-    float dS[4][CPL];
+    float dS[4 * CPL];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int e = 0; e < 4 * CPL; ++e) dS[e] = 0.f;
+
+    GdrOps<CPL> cur[GDR_CH], nxt[GDR_CH];
+    float ck[4 * CPL], ckN[4 * CPL];
+    auto load_chunk = [&](GdrOps<CPL>(&ops)[GDR_CH], float(&c)[4 * CPL], int chunk) {
+        const int t0 = chunk * GDR_CH;
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) dS[r][j] = 0.f;
+        for (int i = 0; i < GDR_CH; ++i) {
+            const int t = t0 + i < S ? t0 + i : S - 1;  // a ragged last chunk re-reads the last step; the copies are not used
+            gdr_load_ops<CPL>(ops[i], kp + t * ldqk, qp + t * ldqk, vp + t * ldv, gp + (int64_t)t * Hv * Dv, ap + (int64_t)t * Hv, bp + (int64_t)t * Hv);
+        }
+        const float* cp = ckp + (int64_t)chunk * Dv * DK;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) c[r * CPL + j] = cp[r * DK + j];
+    };
+    load_chunk(cur, ck, nchunk - 1);
 
     for (int chunk = nchunk - 1; chunk >= 0; --chunk) {
-        const int t0 = chunk * CH, t1 = t0 + CH < S ? t0 + CH : S;
-        // ---- phase A: replay forward, park S_{t-1}
-        float sreg[4][CPL];
-        {
-            const float* c = ckpt + ((((int64_t)b * Hv + h) * nchunk + chunk) * Dv + row) * DK + col;
+        const int t0 = chunk * GDR_CH;
+        const int n = S - t0 < GDR_CH ? S - t0 : GDR_CH;
+        if (chunk > 0) load_chunk(nxt, ckN, chunk - 1);
+        // ---- phase A: replay forward from the checkpoint, park S_{t-1} of each step
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+        for (int i = 0; i < GDR_CH; ++i) {
+            if (i < n) {
 #pragma unroll
-                for (int j = 0; j < CPL; ++j) sreg[r][j] = c[r * DK + j];
-        }
-        GdrStep<CPL> cur, nxt;
-        gdr_load_step<CPL, false>(cur, kp + t0 * ldqk, nullptr, vp + t0 * ldv, nullptr, ap + (int64_t)t0 * Hv, bp + (int64_t)t0 * Hv);
-        for (int t = t0; t < t1; ++t) {
-            if (t + 1 < t1)
-                gdr_load_step<CPL, false>(nxt, kp + (t + 1) * ldqk, nullptr, vp + (t + 1) * ldv, nullptr, ap + (int64_t)(t + 1) * Hv, bp + (int64_t)(t + 1) * Hv);
-            float* sp = st + (int64_t)(t - t0) * 16 * DK;
+                for (int vi = 0; vi < CPL; ++vi) park[wave][i][vi][lane] = f32x4{ck[4 * vi], ck[4 * vi + 1], ck[4 * vi + 2], ck[4 * vi + 3]};
+                float kf[CPL];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+                for (int j = 0; j < CPL; ++j) kf[j] = raw_get<CPL>(cur[i].k, j);
 #pragma unroll
-                for (int j = 0; j < CPL; ++j) sp[r * DK + j] = sreg[r][j];
-                float u = 0.f;
+                for (int r = 0; r < 4; ++r) {
+                    float u = 0.f;
 #pragma unroll
-                for (int j = 0; j < CPL; ++j) {
-                    sreg[r][j] *= cur.a;
-                    u = fmaf(sreg[r][j], cur.k[j], u);
+                    for (int j = 0; j < CPL; ++j) {
+                        ck[r * CPL + j] *= cur[i].a;
+                        u = fmaf(ck[r * CPL + j], kf[j], u);
+                    }
+                    u = lanes_sum<16>(u);
+                    const float c = cur[i].b * (bf2f(cur[i].v[r]) - u);
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) ck[r * CPL + j] = fmaf(c, kf[j], ck[r * CPL + j]);
                 }
-                u = lanes_sum<16>(u);
-                const float c = cur.b * (cur.v[r] - u);
-#pragma unroll
-                for (int j = 0; j < CPL; ++j) sreg[r][j] = fmaf(c, cur.k[j], sreg[r][j]);
             }
-            cur = nxt;
         }
         // ---- phase B: reverse walk
-        gdr_load_step<CPL, true>(cur, kp + (t1 - 1) * ldqk, qp + (t1 - 1) * ldqk, vp + (t1 - 1) * ldv, gp + (int64_t)(t1 - 1) * Hv * Dv,
-                                 ap + (int64_t)(t1 - 1) * Hv, bp + (int64_t)(t1 - 1) * Hv);
-        for (int t = t1 - 1; t >= t0; --t) {
-            if (t - 1 >= t0)
-                gdr_load_step<CPL, true>(nxt, kp + (t - 1) * ldqk, qp + (t - 1) * ldqk, vp + (t - 1) * ldv, gp + (int64_t)(t - 1) * Hv * Dv,
-                                         ap + (int64_t)(t - 1) * Hv, bp + (int64_t)(t - 1) * Hv);
-            const float* sp = st + (int64_t)(t - t0) * 16 * DK;
-            float pq[CPL], pk[CPL];
 #pragma unroll
-            for (int j = 0; j < CPL; ++j) pq[j] = pk[j] = 0.f;
-            float dbp = 0.f, dap = 0.f;
-            float dvr[4];
+        for (int i = GDR_CH - 1; i >= 0; --i) {
+            if (i < n) {
+                const int t = t0 + i;
+                float Sp[4 * CPL];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float Sp[CPL], G[CPL];
-                float u = 0.f;
+                for (int vi = 0; vi < CPL; ++vi) {
+                    const f32x4 x = park[wave][i][vi][lane];
+                    Sp[4 * vi] = x[0];
+                    Sp[4 * vi + 1] = x[1];
+                    Sp[4 * vi + 2] = x[2];
+                    Sp[4 * vi + 3] = x[3];
+                }
+                const GdrOps<CPL>& op = cur[i];
+                float kf[CPL], qf[CPL], pq[CPL], pk[CPL];
 #pragma unroll
                 for (int j = 0; j < CPL; ++j) {
-                    Sp[j] = sp[r * DK + j];
-                    G[j] = Sp[j] * cur.a;
-                    u = fmaf(G[j], cur.k[j], u);
+                    kf[j] = raw_get<CPL>(op.k, j);
+                    qf[j] = raw_get<CPL>(op.q, j);
+                    pq[j] = pk[j] = 0.f;
                 }
-                u = lanes_sum<16>(u);
-                const float resid = cur.v[r] - u;
-                const float c = cur.b * resid;
-                float dc = 0.f;
+                float dbp = 0.f, dap = 0.f;
+                float dvr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float G[CPL];
+                    const float gr = bf2f(op.g[r]) * qscale;  // d(o_i)/d(S_ij) = q_j / sqrt(dk)
+                    float u = 0.f;
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) {
+                        G[j] = Sp[r * CPL + j] * op.a;
+                        u = fmaf(G[j], kf[j], u);
+                    }
+                    u = lanes_sum<16>(u);
+                    const float resid = bf2f(op.v[r]) - u;
+                    const float c = op.b * resid;
+                    float dc = 0.f;
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) {
+                        const float Sn = fmaf(c, kf[j], G[j]);                      // S_t
+                        dS[r * CPL + j] = fmaf(gr, qf[j], dS[r * CPL + j]);         // dS += do q~^T
+                        pq[j] = fmaf(gr, Sn, pq[j]);                                // dq = S^T do / sqrt(dk)
+                        dc = fmaf(dS[r * CPL + j], kf[j], dc);
+                    }
+                    dc = lanes_sum<16>(dc);
+                    const float du = -op.b * dc;
+                    dbp += dc * resid;
+                    dvr[r] = op.b * dc;
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) {
+                        pk[j] = fmaf(c, dS[r * CPL + j], fmaf(du, G[j], pk[j]));
+                        const float dG = fmaf(du, kf[j], dS[r * CPL + j]);
+                        dap = fmaf(dG, Sp[r * CPL + j], dap);
+                        dS[r * CPL + j] = op.a * dG;
+                    }
+                }
+                // sums over this wave's 16 rows: across the 4 row quads; dap also across the 16 column lanes
+                dap = lanes_sum<16>(dap);
 #pragma unroll
                 for (int j = 0; j < CPL; ++j) {
-                    const float Sn = fmaf(c, cur.k[j], G[j]);                  // S_t
-                    dS[r][j] = fmaf(cur.g[r], cur.q[j] * qscale, dS[r][j]);    // dS += do q~^T
-                    pq[j] = fmaf(cur.g[r], Sn, pq[j]);                         // dq~ = S^T do
-                    dc = fmaf(dS[r][j], cur.k[j], dc);
+                    pq[j] = rows_sum(pq[j]);
+                    pk[j] = rows_sum(pk[j]);
                 }
-                dc = lanes_sum<16>(dc);
-                const float du = -cur.b * dc;
-                dbp += dc * resid;
-                dvr[r] = cur.b * dc;
+                dbp = rows_sum(dbp);
+                dap = rows_sum(dap);
+                if (rq == 0) {
 #pragma unroll
-                for (int j = 0; j < CPL; ++j) {
-                    pk[j] = fmaf(c, dS[r][j], fmaf(du, G[j], pk[j]));
-                    const float dG = fmaf(du, cur.k[j], dS[r][j]);
-                    dap = fmaf(dG, Sp[j], dap);
-                    dS[r][j] = cur.a * dG;
+                    for (int j = 0; j < CPL; ++j) {
+                        wq[(int64_t)t * DK + j] = pq[j];
+                        wk[(int64_t)t * DK + j] = pk[j];
+                    }
                 }
-            }
-            // sums over this wave's 16 rows: across the 4 row quads (lanes ^16, ^32); dap also across the 16 column lanes
-            dap = lanes_sum<16>(dap);
+                if (lane == 0) {
+                    pdb[slot * S + t] = dbp;
+                    pda[slot * S + t] = dap;
+                }
+                if (cl == 0) {
 #pragma unroll
-            for (int j = 0; j < CPL; ++j) {
-                pq[j] += __shfl_xor(pq[j], 16, 64);
-                pq[j] += __shfl_xor(pq[j], 32, 64);
-                pk[j] += __shfl_xor(pk[j], 16, 64);
-                pk[j] += __shfl_xor(pk[j], 32, 64);
-            }
-            dbp += __shfl_xor(dbp, 16, 64);
-            dbp += __shfl_xor(dbp, 32, 64);
-            dap += __shfl_xor(dap, 16, 64);
-            dap += __shfl_xor(dap, 32, 64);
-            if (rq == 0) {
-#pragma unroll
-                for (int j = 0; j < CPL; ++j) {
-                    wq[(int64_t)t * DK + j] = pq[j];
-                    wk[(int64_t)t * DK + j] = pk[j];
+                    for (int r = 0; r < 4; ++r) dv[(tok0 + t) * lddv + (int64_t)h * Dv + row + r] = f2bf(dvr[r]);
                 }
             }
-            if (lane == 0) {
-                pdb[slot * S + t] = dbp;
-                pda[slot * S + t] = dap;
-            }
-            if (cl == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dv[(tok0 + t) * lddv + (int64_t)h * Dv + row + r] = f2bf(dvr[r]);
-            }
-            cur = nxt;
         }
+#pragma unroll
+        for (int i = 0; i < GDR_CH; ++i) cur[i] = nxt[i];
+#pragma unroll
+        for (int e = 0; e < 4 * CPL; ++e) ck[e] = ckN[e];
     }
 }
 
-// dq[b,t,hq,:] = qscale * sum over the value heads of hq and their row groups of pdq;  dk likewise (no scale);
+// dq[b,t,hq,:] = sum over the value heads of hq and their row groups of pdq (the 1/sqrt(dk) is already in);  dk likewise;
 // dbeta / dalpha [tokens, Hv] = sum over row groups.
 __global__ __launch_bounds__(256) void gdr_bwd_reduce_kernel(int B, int S, int Hqk, int Hv, int RG, int DK, const float* __restrict__ pdq,
                                                              const float* __restrict__ pdk, const float* __restrict__ pdb,
@@ -766,7 +825,7 @@ __global__ __launch_bounds__(256) void gdr_bwd_reduce_kernel(int B, int S, int H
                 sq += pdq[o];
                 sk += pdk[o];
             }
-        dq[idx] = f2bf(sq * qscale);
+        dq[idx] = f2bf(sq);
         dk[idx] = f2bf(sk);
     } else if (idx < nqk + (int64_t)B * S * Hv) {
         const int64_t e = idx - nqk;
@@ -1013,26 +1072,27 @@ static int check_gdr(int B, int S, int Hqk, int Hv, int Dk, int Dv) {
     MI355_REQUIRE(Hv <= 65535 && B <= 65535, "gated_delta_rule: grid limits");
     return 0;
 }
-extern "C" int mi355_gated_delta_rule_chunk(void) { return 64; }
+extern "C" int mi355_gated_delta_rule_chunk(void) { return GDR_CH; }
 
 extern "C" int mi355_gated_delta_rule_fwd(int B, int S, int Hqk, int Hv, int Dk, int Dv, const void* q, const void* k, const void* v, int64_t ldv,
                                           const float* beta, const float* alpha, void* o, float* checkpoints, float* final_state, void* stream) {
     if (check_gdr(B, S, Hqk, Hv, Dk, Dv)) return 1;
     MI355_REQUIRE(q && k && v && beta && alpha && o && ldv >= (int64_t)Hv * Dv, "gated_delta_rule_fwd: bad arguments");
     const int CH = mi355_gated_delta_rule_chunk(), nchunk = (S + CH - 1) / CH;
-    dim3 grid((Dv + 63) / 64, Hv, B);
     const float qs = 1.0f / sqrtf((float)Dk);
+    const int rows_per_block = Dk == 128 ? 4 * (64 / 8) : 4 * (64 / 4);
+    dim3 grid((Dv + rows_per_block - 1) / rows_per_block, Hv, B);
     if (Dk == 128)
-        gdr_fwd_kernel<32><<<grid, 256, 0, ST(stream)>>>(B, S, Hqk, Hv, Dv, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldv, beta, alpha, (bf16_t*)o, checkpoints, CH, nchunk, final_state, qs);
+        gdr_fwd_kernel<128, 8><<<grid, 256, 0, ST(stream)>>>(B, S, Hqk, Hv, Dv, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldv, beta, alpha, (bf16_t*)o, checkpoints, CH, nchunk, final_state, qs);
     else
-        gdr_fwd_kernel<4><<<grid, 256, 0, ST(stream)>>>(B, S, Hqk, Hv, Dv, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldv, beta, alpha, (bf16_t*)o, checkpoints, CH, nchunk, final_state, qs);
+        gdr_fwd_kernel<16, 4><<<grid, 256, 0, ST(stream)>>>(B, S, Hqk, Hv, Dv, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldv, beta, alpha, (bf16_t*)o, checkpoints, CH, nchunk, final_state, qs);
     MI355_LAUNCH_CHECK("gated_delta_rule_fwd");
     return 0;
 }
 
 extern "C" int64_t mi355_gated_delta_rule_bwd_workspace_bytes(int B, int S, int Hv, int Dk, int Dv) {
-    const int64_t CH = mi355_gated_delta_rule_chunk(), RG = Dv / 16, slots = (int64_t)B * Hv * RG;
-    return 4 * (slots * CH * 16 * Dk + 2 * slots * S * Dk + 2 * slots * S);
+    const int64_t RG = Dv / 16, slots = (int64_t)B * Hv * RG;
+    return 4 * (2 * slots * S * Dk + 2 * slots * S);
 }
 
 extern "C" int mi355_gated_delta_rule_bwd(int B, int S, int Hqk, int Hv, int Dk, int Dv, const void* q, const void* k, const void* v, int64_t ldv,
@@ -1043,19 +1103,18 @@ extern "C" int mi355_gated_delta_rule_bwd(int B, int S, int Hqk, int Hv, int Dk,
     MI355_REQUIRE(q && k && v && beta && alpha && checkpoints && d_o && dq && dk && dv && dbeta && dalpha && workspace, "gated_delta_rule_bwd: null pointer");
     MI355_REQUIRE(ldv >= (int64_t)Hv * Dv && lddv >= (int64_t)Hv * Dv, "gated_delta_rule_bwd: ld too small");
     MI355_REQUIRE(workspace_bytes >= mi355_gated_delta_rule_bwd_workspace_bytes(B, S, Hv, Dk, Dv), "gated_delta_rule_bwd: workspace too small (%lld bytes)", (long long)workspace_bytes);
-    const int CH = mi355_gated_delta_rule_chunk(), nchunk = (S + CH - 1) / CH, RG = Dv / 16;
+    const int nchunk = (S + GDR_CH - 1) / GDR_CH, RG = Dv / 16;
     const int64_t slots = (int64_t)B * Hv * RG;
-    float* states = (float*)workspace;
-    float* pdq = states + slots * CH * 16 * Dk;
+    float* pdq = (float*)workspace;
     float* pdk = pdq + slots * S * Dk;
     float* pdb = pdk + slots * S * Dk;
     float* pda = pdb + slots * S;
     dim3 grid((RG + 3) / 4, Hv, B);
     const float qs = 1.0f / sqrtf((float)Dk);
     if (Dk == 128)
-        gdr_bwd_kernel<8><<<grid, 256, 0, ST(stream)>>>(B, S, Hqk, Hv, Dv, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldv, beta, alpha, checkpoints, CH, nchunk, (const bf16_t*)d_o, (bf16_t*)dv, lddv, states, pdq, pdk, pdb, pda, qs);
+        gdr_bwd_kernel<8><<<grid, 256, 0, ST(stream)>>>(B, S, Hqk, Hv, Dv, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldv, beta, alpha, checkpoints, nchunk, (const bf16_t*)d_o, (bf16_t*)dv, lddv, pdq, pdk, pdb, pda, qs);
     else
-        gdr_bwd_kernel<1><<<grid, 256, 0, ST(stream)>>>(B, S, Hqk, Hv, Dv, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldv, beta, alpha, checkpoints, CH, nchunk, (const bf16_t*)d_o, (bf16_t*)dv, lddv, states, pdq, pdk, pdb, pda, qs);
+        gdr_bwd_kernel<1><<<grid, 256, 0, ST(stream)>>>(B, S, Hqk, Hv, Dv, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldv, beta, alpha, checkpoints, nchunk, (const bf16_t*)d_o, (bf16_t*)dv, lddv, pdq, pdk, pdb, pda, qs);
     MI355_LAUNCH_CHECK("gated_delta_rule_bwd");
     const int64_t n = (int64_t)B * S * Hqk * Dk + (int64_t)B * S * Hv;
     gdr_bwd_reduce_kernel<<<grid1d(n), 256, 0, ST(stream)>>>(B, S, Hqk, Hv, RG, Dk, pdq, pdk, pdb, pda, (bf16_t*)dq, (bf16_t*)dk, dbeta, dalpha, qs);
