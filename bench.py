@@ -128,6 +128,17 @@ def cpu_baseline(vit, ad, llm, seed, budget_s=240):
     }
 
 
+def pmc_traffic():
+    """TCC counters of the dominant kernel, collected with rocprofv3 --pmc in separate passes and committed (PMC cannot be read
+    from inside the timed process)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_tcc_gemm.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["kernels"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def dominant_kernel_rate(batch, device):
     """HIP-event timing of the step's dominant kernel class (gemm_bf16_kernel) on its largest shapes, on the stream the
     kernels are launched on (torch's current stream)."""
@@ -233,7 +244,7 @@ def main():
             "roofline": {
                 "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                "traffic_note": "TCC/FETCH_SIZE PMC collection hangs on this pool (rocprofv3 timed out twice); SQ counters in profiles/",
+                "traffic_note": "PMC bytes of the dominant kernel are in roofline.dominant_kernel (collected per kernel, profiles/r01_pmc_tcc_gemm.json)",
                 "basis": "algorithmic 2.566 TFLOP/sample (SURVEY 8d) x per-GPU batch / step time; device-side (HIP events) "
                          f"{dev_ms / args.steps:.3f} ms/step",
             },
@@ -241,6 +252,16 @@ def main():
         }
         if world == 1:
             line["roofline"]["dominant_kernel"] = {"name": "gemm_bf16_kernel", "hip_event_timing": dominant_kernel_rate(args.batch, device)}
+            pmc = pmc_traffic()
+            if pmc is not None and args.batch == 64:  # the PMC passes were taken at this batch's shapes
+                line["roofline"]["traffic"] = pmc["NT"]["hbm_bytes"]
+                line["roofline"]["traffic_note"] = (
+                    "bytes per launch of the dominant kernel (gemm_bf16_kernel, NT gate-up forward at this batch): 2 x FETCH_SIZE (gfx950 correction) "
+                    f"+ WRITE_SIZE from separate rocprofv3 --pmc passes (profiles/r01_pmc_tcc_gemm.json), {pmc['NT']['over_algorithmic']}x its algorithmic "
+                    "bytes; Infinity-Cache hits are counted in FETCH_SIZE, the kernel is MFMA-bound")
+                line["roofline"]["dominant_kernel"]["pmc_bytes_per_launch"] = {f: pmc[f]["hbm_bytes"] for f in ("NT", "NN", "TN")}
+                line["roofline"]["dominant_kernel"]["algorithmic_bytes_per_launch"] = {
+                    f: pmc[f]["algorithmic_read_bytes"] + pmc[f]["algorithmic_write_bytes"] for f in ("NT", "NN", "TN")}
         if world == 1 and args.cpu_baseline == "auto":
             try:
                 line["cpu_baseline"] = cpu_baseline(vit, ad, llm, seed=123)
