@@ -277,6 +277,25 @@ int mi355_gated_rmsnorm_fwd(int64_t tokens, int H, int D, const void* o, const f
 int mi355_gated_rmsnorm_bwd(int64_t tokens, int H, int D, const void* o, const float* w, const void* gate, int64_t ldg, const float* rstd,
                             const void* dout, void* d_o, void* dgate, int64_t lddg, float* dw_partial, int parts, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Input pipeline on the step's left edge: MultimodalDataset's per-sample work, dataset.py:295-383.
+ * ------------------------------------------------------------------------------------------------------------------- */
+
+/* transforms.Resize((s, s)) on a PIL image = Pillow's fixed-point two-pass bilinear resampler (Resample.c), bit-exact.  bounds
+ * int32 [out, 2] = (first input index, count) and kk int32 [out, ksize] = weights * 2^22 are the tables of precompute_coeffs /
+ * normalize_coeffs_8bpc (built on the host, llm_quest_amd/dataset.py::resize_tables).  Horizontal pass: src uint8 (H, W_in, C)
+ * rows `src_pitch` bytes apart -> dst uint8 (H, W_out, C).  C <= 4. */
+int mi355_resize_h_u8(int H, int W_in, int W_out, int C, const uint8_t* src, int64_t src_pitch, const int32_t* bounds, const int32_t* kk, int ksize,
+                      uint8_t* dst, void* stream);
+/* Vertical pass fused with transforms.ToTensor and transforms.Normalize (dataset.py:343-349): src uint8 (H_in, W, C) contiguous ->
+ * dst fp32 (C, H_out, W) = ((u8 / 255) - mean[c]) / std[c]; mean == std == NULL: ToTensor only (standardize=False). */
+int mi355_resize_v_normalize(int H_in, int H_out, int W, int C, const uint8_t* src, const int32_t* bounds, const int32_t* kk, int ksize,
+                             const float* mean, const float* stdv, float* dst, void* stream);
+/* tokenizer(..., truncation=True, max_length=L, padding="max_length") with pad = eos (dataset.py:337,367-373) on already
+ * tokenised captions: flat_ids int64 = all captions back to back, offsets int64 [B+1]; ids_out int64 [B, L], mask_out uint8 [B, L]. */
+int mi355_pad_tokens(int B, int L, const int64_t* flat_ids, const int64_t* offsets, int64_t pad_id, int64_t* ids_out, uint8_t* mask_out,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

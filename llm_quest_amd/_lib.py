@@ -75,6 +75,10 @@ SIGNATURES = {
     "mi355_gated_delta_rule_bwd": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _P],
     "mi355_gated_rmsnorm_fwd": [_L, _I, _I, _P, _P, _P, _L, _P, _P, _F, _P],
     "mi355_gated_rmsnorm_bwd": [_L, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _L, _P, _I, _P],
+    # input pipeline (csrc/pipeline.hip)
+    "mi355_resize_h_u8": [_I, _I, _I, _I, _P, _L, _P, _P, _I, _P, _P],
+    "mi355_resize_v_normalize": [_I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P],
+    "mi355_pad_tokens": [_I, _I, _P, _P, _L, _P, _P, _P],
 }
 # size / constant queries: no stream argument, the return value is the answer (name -> (argtypes, restype))
 QUERIES = {

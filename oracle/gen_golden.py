@@ -432,6 +432,25 @@ def gen_qwen35_text(out):
     _save(os.path.join(out, "qwen35_text_tiny.safetensors"), t, "Qwen3.5 text stack (tiny hybrid GDN / gated attention) + per-op vectors")
 
 
+def gen_pipeline(out):
+    """Input pipeline: Pillow's bilinear resize -- the third-party arithmetic behind
+    transforms.Resize in MultimodalDataset (dataset.py:341-349) -- on seeded random RGB images."""
+    import numpy as np
+    import PIL
+    from PIL import Image
+
+    rng = np.random.default_rng(SEED)
+    t = {}
+    for name, (h, w, s_) in {"down": (97, 131, 64), "up": (40, 30, 64), "one_pass": (64, 100, 64), "to224": (300, 200, 224)}.items():
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        t[f"resize.{name}.in"] = torch.from_numpy(img)
+        t[f"resize.{name}.out"] = torch.from_numpy(np.array(Image.fromarray(img).resize((s_, s_), Image.BILINEAR)))
+    from safetensors.torch import save_file
+
+    save_file(t, os.path.join(out, "pipeline.safetensors"), metadata={"what": "Pillow bilinear resize vectors", "pillow": PIL.__version__, "torch": torch.__version__})
+    print("wrote pipeline.safetensors", len(t), "tensors")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -442,7 +461,7 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
     only = os.environ.get("GOLDEN_ONLY")
-    for fn in (gen_index, gen_ops, gen_qwen, gen_vit, gen_vlm, gen_gpt, gen_qwen35, gen_qwen35_text):
+    for fn in (gen_index, gen_ops, gen_qwen, gen_vit, gen_vlm, gen_gpt, gen_qwen35, gen_qwen35_text, gen_pipeline):
         if only and fn.__name__ != only:
             continue
         fn(args.out)
