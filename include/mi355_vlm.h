@@ -296,6 +296,23 @@ int mi355_resize_v_normalize(int H_in, int H_out, int W, int C, const uint8_t* s
 int mi355_pad_tokens(int B, int L, const int64_t* flat_ids, const int64_t* offsets, int64_t pad_id, int64_t* ids_out, uint8_t* mask_out,
                      void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * KV-cache decoding on the step's right edge: generate_loop_kv_cache (generate.py:97-151) with
+ * utils.KVCache (utils.py:409-531).  csrc/decode.hip.
+ * ------------------------------------------------------------------------------------------------------------------- */
+
+/* y[m, n] = sum_k x[m, k] W[n, k] (+ residual[m, n]) for M <= 8 rows: nn.Linear on one new token per sequence -- a weight
+ * stream, one wave per output column.  bf16 in / out, fp32 accumulate. */
+int mi355_gemv_bf16(int M, int64_t N, int K, const void* x, int64_t ldx, const void* W, int64_t ldw, void* y, int64_t ldy, const void* residual,
+                    int64_t ldr, void* stream);
+/* One query row per (batch, head) against `len` cached keys / values (qwen3_attention.py:117-146 with a KV cache and q_seq_len 1):
+ * q, o bf16 [B, Hq*D]; caches bf16 token-major, sequence b at k_cache + b*batch_stride, key j at + j*ld, kv head g at + g*D.
+ * key_mask uint8 [B, >= len] row pitch ldm (1 = real token) or NULL; masked keys take the reference's finite fill. D in {64,128,256}. */
+int mi355_attn_decode(int B, int Hq, int Hkv, int D, const void* q, const void* k_cache, const void* v_cache, int64_t batch_stride, int64_t ld,
+                      int len, const uint8_t* key_mask, int64_t ldm, void* o, float scale, void* stream);
+/* Greedy sampling (generate.py:472-476, temp == 0): out[r] = index of the row maximum of bf16 logits [rows, V] (first on ties). */
+int mi355_argmax_rows(int64_t rows, int64_t V, const void* logits, int64_t ld, int64_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,90 @@
+"""Text generation loops -- API of ``llm_quest/generate.py`` for the paths on SURVEY.md section 8 row f4: ``generate_loop``
+(full re-forward per token), ``generate_loop_kv_cache`` (prefill + one-token decode steps through ``KVCache``) and ``sampling``.
+
+Greedy sampling (``temp == 0``, the default) is a HIP kernel (first index of the row maximum).  Stochastic sampling (temperature /
+top-k / top-p / min-p) is control logic on a (batch, vocab) tensor per generated token, outside the measured path: it is restated
+here with torch device ops so the loops are complete, and says so.
+"""
+
+import torch
+
+from . import ops_decode
+from .utils import KVCache
+
+
+def _top_k(probs, k):
+    top, idx = torch.topk(probs, k)
+    return torch.zeros_like(probs).scatter_(-1, idx, top)
+
+
+def _top_p(probs, p, top_k=None):
+    if top_k:
+        kth = torch.topk(probs, top_k)[0][..., -1].unsqueeze(-1)
+        probs = probs.masked_fill(probs < kth, 0.0)
+    sp, idx = torch.sort(probs, dim=-1, descending=True)
+    mask = torch.cumsum(sp, dim=-1) > p
+    mask[..., 1:] = mask[..., :-1].clone()
+    mask[..., 0] = False
+    return torch.zeros_like(probs).scatter_(-1, idx, sp.masked_fill(mask, 0.0))
+
+
+def _min_p(probs, min_p, min_tokens_to_keep=1):
+    remove = probs < min_p * torch.amax(probs, dim=-1, keepdim=True)
+    keep_idx = torch.topk(probs, min_tokens_to_keep)[1]
+    remove.scatter_(-1, keep_idx, False)
+    return probs.masked_fill(remove, 0.0)
+
+
+def sampling(logits, top_k=None, top_p=None, min_p=None, temp=0.0):
+    """logits (b, v) -> next token ids (b, 1) (reference: generate.py:472-514)."""
+    assert top_p is None or min_p is None, "Cannot use top_p and min_p together"
+    if temp == 0.0:
+        return ops_decode.argmax_rows(logits if logits.stride(-1) == 1 else logits.contiguous()).unsqueeze(-1)
+    probs = torch.softmax(logits.float() / temp, dim=-1)
+    if min_p:
+        probs = _min_p(probs, min_p, 1 if top_k is None else top_k)
+    elif top_p:
+        probs = _top_p(probs, top_p, top_k)
+    elif top_k:
+        probs = _top_k(probs, top_k)
+    probs = probs / probs.sum(dim=-1, keepdim=True)
+    return torch.multinomial(probs, num_samples=1)
+
+
+def generate_loop(input_tensor, model, max_gen, context_length, top_k=None, top_p=None, min_p=None, temp=0.0, eos_ids=None, device=torch.device("cuda")):
+    """Re-runs the model on the growing sequence for every token (reference: generate.py:29-94)."""
+    input_tensor = input_tensor.to(device)
+    eos = None
+    if eos_ids is not None:
+        eos = torch.tensor(eos_ids if isinstance(eos_ids, list) else [eos_ids], device=device, dtype=torch.long)
+    for _ in range(max_gen):
+        with torch.inference_mode():
+            logits = model(input_tensor[:, -context_length:])[:, -1, :]
+        next_token = sampling(logits, top_k, top_p, min_p, temp)
+        if eos is not None and torch.isin(next_token, eos).any():
+            break
+        input_tensor = torch.cat((input_tensor, next_token), dim=-1)
+    return input_tensor
+
+
+def generate_loop_kv_cache(input_tensor, model, max_gen, context_length, top_k=None, top_p=None, min_p=None, temp=0.0, eos_ids=None,
+                           device=torch.device("cuda")):
+    """Prefill once, then one-token decode steps through the KV cache (reference: generate.py:97-151)."""
+    token_ids = []
+    kv_cache = KVCache(num_layers=len(model.trf_blocks), prompt_len=input_tensor.shape[-1], context_len=context_length)
+    input_tensor = input_tensor.to(device)
+    eos = None
+    if eos_ids is not None:
+        eos = torch.tensor(eos_ids if isinstance(eos_ids, list) else [eos_ids], device=device, dtype=torch.long)
+    trunc_input = input_tensor[:, -context_length:]
+    next_position_id = torch.tensor([[trunc_input.shape[-1]]], dtype=torch.long, device=device)
+    with torch.inference_mode():
+        logits = model(trunc_input, kv_cache=kv_cache)[:, -1, :]
+        for _ in range(max_gen):
+            next_token = sampling(logits, top_k, top_p, min_p, temp)
+            if eos is not None and torch.isin(next_token, eos).any():
+                break
+            token_ids.append(next_token)
+            logits = model(next_token, kv_cache=kv_cache, position_ids=next_position_id).squeeze(1)
+            next_position_id += 1
+    return torch.cat([input_tensor] + token_ids, dim=-1)

@@ -1,0 +1,106 @@
+"""Inference with a KV cache through Qwen3: ``Qwen3Model.forward(x, kv_cache=...)`` as
+``generate_loop_kv_cache`` drives it (llm_quest/generate.py:97-151, qwen3_attention.py:117-146).
+
+Two shapes of call, both without autograd:
+  * prefill -- the whole prompt, cache empty: the training-path kernels (MFMA GEMMs, flash attention over the prompt), plus a
+    strided copy of each layer's post-norm / post-RoPE K rows and V rows into the token-major cache;
+  * decode  -- one new token per sequence: every linear layer is a weight stream (``mi355_gemv_bf16``, <= 8 sequences; larger
+    batches fall back to the GEMM), attention is one query row per head over the cache (``mi355_attn_decode``).
+"""
+
+import torch
+
+from . import _lib as L
+from . import kernels as K
+from . import ops
+
+BF16 = torch.bfloat16
+
+
+def gemv(x2d, w, residual=None):
+    """x [M <= 8, K] @ w[N, K]^T (+ residual); larger M goes through the MFMA GEMM."""
+    M = x2d.shape[0]
+    if M > 8:
+        return K.gemm(L.GEMM_NT, x2d, w, residual=residual)
+    L.require_gpu(x2d, w, residual)
+    if x2d.dtype != BF16 or w.dtype != BF16 or x2d.stride(1) != 1 or w.stride(1) != 1 or x2d.shape[1] != w.shape[1]:
+        raise ValueError("gemv: bf16 operands with unit inner stride and a common K")
+    y = torch.empty((M, w.shape[0]), dtype=BF16, device=x2d.device)
+    L.call("mi355_gemv_bf16", M, w.shape[0], w.shape[1], L.ptr(x2d), x2d.stride(0), L.ptr(w), w.stride(0), L.ptr(y), y.stride(0),
+           L.ptr(residual), residual.stride(0) if residual is not None else 0)
+    return y
+
+
+def attn_decode(q, kc, vc, length, Hq, Hkv, D, key_mask=None, scale=None):
+    """q [B, Hq*D]; kc / vc [B, capacity, Hkv*D]; attends to keys [0, length)."""
+    L.require_gpu(q, kc, vc, key_mask)
+    B = q.shape[0]
+    if not (q.is_contiguous() and q.dtype == BF16 and kc.dtype == BF16 and kc.shape == vc.shape and kc.stride() == vc.stride() and kc.stride(2) == 1):
+        raise ValueError("attn_decode: contiguous bf16 q, caches [B, capacity, Hkv*D] of one layout")
+    if length > kc.shape[1]:
+        raise ValueError("attn_decode: length exceeds the cache capacity")
+    ldm = 0
+    if key_mask is not None:
+        if key_mask.dtype != torch.uint8 or key_mask.shape[0] != B or key_mask.shape[1] < length or key_mask.stride(1) != 1:
+            raise ValueError("attn_decode: key_mask uint8 [B, >= length]")
+        ldm = key_mask.stride(0)
+    o = torch.empty_like(q)
+    L.call("mi355_attn_decode", B, Hq, Hkv, D, L.ptr(q), L.ptr(kc), L.ptr(vc), kc.stride(0), kc.stride(1), length, L.ptr(key_mask), ldm, L.ptr(o),
+           D ** -0.5 if scale is None else scale)
+    return o
+
+
+def argmax_rows(logits2d):
+    L.require_gpu(logits2d)
+    if logits2d.dtype != BF16 or logits2d.dim() != 2 or logits2d.stride(1) != 1:
+        raise ValueError("argmax_rows: bf16 [rows, V] with unit inner stride")
+    out = torch.empty(logits2d.shape[0], dtype=torch.int64, device=logits2d.device)
+    L.call("mi355_argmax_rows", logits2d.shape[0], logits2d.shape[1], L.ptr(logits2d), logits2d.stride(0), L.ptr(out))
+    return out
+
+
+@torch.no_grad()
+def qwen3_forward_cached(model, x, kv_cache, attn_mask=None, position_ids=None, input_embedded=False):
+    """Logits (b, s, vocab) of ``Qwen3Model`` with ``kv_cache`` updated in place (reference: qwen3_model.py:60-94)."""
+    model._build_arenas()
+    L.require_gpu(x)
+    emb_w = model.emb_dict.weight
+    if input_embedded:
+        B, S, d = x.shape
+        h = x.reshape(B * S, d).contiguous()
+    else:
+        B, S = x.shape
+        h = K.embedding_fwd(x, emb_w)
+    start = kv_cache.start_pos
+    decode = start > 0
+    if decode and S != 1:
+        raise NotImplementedError("with a filled KV cache one new token per sequence is decoded (q_seq_len 1, generate.py:139-148)")
+    if position_ids is not None:
+        pos = position_ids.to(device=h.device, dtype=torch.int32).expand(B, S).reshape(-1).contiguous()
+    else:
+        pos = (start + torch.arange(S, dtype=torch.int32, device=h.device)).repeat(B)
+    km = None
+    if attn_mask is not None:
+        km = attn_mask.to(device=h.device, dtype=torch.uint8).contiguous()
+        if km.shape[0] != B or km.shape[1] < start + S:
+            raise ValueError(f"attn_mask must cover the cached sequence: (b, >= {start + S}), got {tuple(km.shape)}")
+    lin = gemv if decode else (lambda a, w, residual=None: K.gemm(L.GEMM_NT, a, w, residual=residual))
+    for blk in model.trf_blocks:
+        arena = ops.arena_for(blk)
+        att, ffn = blk.att, blk.ffn
+        Hq, Hkv, D = att.num_heads, att.num_kv_groups, att.head_dim
+        h1, _ = K.rmsnorm_fwd(h, blk.norm1.weight, want_rstd=False)
+        qkv = lin(h1, arena.fused(att.w_queries.weight, att.w_values.weight))
+        q, k, _ = K.qknorm_rope_fwd(qkv, att.q_norm.weight, att.k_norm.weight, model.cos, model.sin, pos, Hq, Hkv, D)
+        v = qkv[:, (Hq + Hkv) * D :]
+        kc, vc, end = kv_cache.append_rows(k, v, att.layer_idx, B, S)
+        if decode:
+            ctx = attn_decode(q, kc, vc, end, Hq, Hkv, D, key_mask=km, scale=att.att_scaling)
+        else:
+            ctx, _ = K.attn_fwd(q, k, v, B, S, Hq, Hkv, D, key_mask=None if km is None else km[:, :S].contiguous(), causal=True, scale=att.att_scaling)
+        h = lin(ctx, att.out_proj.weight, residual=h)
+        h2, _ = K.rmsnorm_fwd(h, blk.norm2.weight, want_rstd=False)
+        gu = lin(h2, arena.fused(ffn.lin1.weight, ffn.lin_gate.weight))
+        h = lin(K.swiglu_fwd(gu, ffn.lin1.weight.shape[0]), ffn.lin2.weight, residual=h)
+    hn, _ = K.rmsnorm_fwd(h, model.final_norm.weight, want_rstd=False)
+    return lin(hn, model.out_head.weight).view(B, S, -1)

@@ -103,8 +103,10 @@ class Qwen3Model(nn.Module):
 
     def forward(self, x, attn_mask=None, kv_cache=None, position_ids=None, input_embedded=False):
         """Logits (b, s, vocab) in the model dtype (reference: qwen3_model.py:60-94)."""
-        if kv_cache is not None:
-            raise NotImplementedError("KV-cache decoding is outside the training hot path (SURVEY.md section 8f)")
+        if kv_cache is not None:  # inference: prefill / one-token decode through utils.KVCache (SURVEY.md section 8 row f4)
+            from llm_quest_amd import ops_decode
+
+            return ops_decode.qwen3_forward_cached(self, x, kv_cache, attn_mask, position_ids, input_embedded)
         return self.out_head(self.forward_hidden(x, attn_mask, position_ids, input_embedded))
 
     def lm_loss(self, hidden_rows, targets):

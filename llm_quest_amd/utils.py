@@ -1,0 +1,82 @@
+"""``KVCache`` of the reference (llm_quest/utils.py:409-531) with an MI355X-first layout.
+
+Same constructor, growth policy (``prompt_len + initial_chunk_size``, then whole ``chunk_size`` steps up to ``context_len``) and
+bookkeeping (``start_pos`` / ``end_pos`` advance after the last layer) as upstream, but the cached keys / values are kept
+TOKEN-MAJOR -- ``[batch, capacity, kv_heads * head_dim]`` bf16, exactly the rows the fused QKV projection and the QK-norm + RoPE
+kernel produce -- so appending is a strided row copy and the decode attention kernel streams contiguous 256-byte head rows;
+upstream's ``(batch, heads, capacity, head_dim)`` would need a transpose per token.  ``get_updated_cache`` keeps the reference's
+call signature on ``(b, heads, s, d)`` tensors for code that uses the cache directly.
+"""
+
+import math
+
+import torch
+
+from . import _lib as L
+from . import kernels as K
+
+
+class KVCache:
+    def __init__(self, num_layers, prompt_len, context_len, initial_chunk_size=512, chunk_size=256):
+        self.num_layers = num_layers
+        self.prompt_len = prompt_len
+        self.context_len = context_len
+        self.chunk_size = chunk_size
+        self.kv_capacity = self.prompt_len + initial_chunk_size
+        self.keys_cache = []
+        self.values_cache = []
+        self.start_pos = 0
+        self.end_pos = 0
+
+    # ------------------------------------------------------------------ storage
+    def _initialize(self, batch_size, width, device, dtype):
+        for _ in range(self.num_layers):
+            self.keys_cache.append(torch.zeros(batch_size, self.kv_capacity, width, device=device, dtype=dtype))
+            self.values_cache.append(torch.zeros(batch_size, self.kv_capacity, width, device=device, dtype=dtype))
+
+    def _grow_kv_capacity(self, layer_idx):
+        if self.kv_capacity < self.end_pos:
+            if self.end_pos < self.context_len:
+                self.kv_capacity += math.ceil((self.end_pos - self.kv_capacity) / self.chunk_size) * self.chunk_size
+            else:
+                self.kv_capacity = self.context_len
+        for cache in (self.keys_cache, self.values_cache):
+            old = cache[layer_idx]
+            new = torch.empty(old.shape[0], self.kv_capacity, old.shape[2], device=old.device, dtype=old.dtype)
+            if self.start_pos:
+                for b in range(old.shape[0]):  # bit-exact strided row copies
+                    K.copy2d(old[b, : self.start_pos], new[b, : self.start_pos])
+            cache[layer_idx] = new
+
+    def append_rows(self, k_rows, v_rows, layer_idx, batch_size, new_seq_len):
+        """k_rows / v_rows: token-major [batch*new_seq_len, kv_heads*head_dim] (row-strided views allowed).  Returns
+        (k_cache [batch, capacity, width], v_cache, end_pos) with the new rows in place at [start_pos, end_pos)."""
+        L.require_gpu(k_rows, v_rows)
+        width = k_rows.shape[1]
+        if not self.keys_cache:
+            self.batch_size, self.device, self.dtype = batch_size, k_rows.device, k_rows.dtype
+            self._initialize(batch_size, width, k_rows.device, k_rows.dtype)
+        self.end_pos = self.start_pos + new_seq_len
+        if self.end_pos > self.context_len:
+            raise ValueError(f"KVCache: sequence length {self.end_pos} exceeds context_len {self.context_len}")
+        if self.end_pos > self.keys_cache[layer_idx].shape[1]:
+            self._grow_kv_capacity(layer_idx)
+        kc, vc = self.keys_cache[layer_idx], self.values_cache[layer_idx]
+        for b in range(batch_size):
+            K.copy2d(k_rows[b * new_seq_len : (b + 1) * new_seq_len], kc[b, self.start_pos : self.end_pos])
+            K.copy2d(v_rows[b * new_seq_len : (b + 1) * new_seq_len], vc[b, self.start_pos : self.end_pos])
+        end = self.end_pos
+        if layer_idx == self.num_layers - 1:
+            self.start_pos += new_seq_len
+        return kc, vc, end
+
+    # ------------------------------------------------------------------ reference signature
+    def get_updated_cache(self, keys, values, layer_idx):
+        """keys / values (batch, heads, new_seq_len, head_dim) -> the cached (batch, heads, end_pos, head_dim) tensors (views of
+        the token-major storage), as utils.py:496-531."""
+        b, h, s, d = keys.shape
+        self.num_heads, self.head_dim = h, d
+        tm = lambda t: t.permute(0, 2, 1, 3).reshape(b * s, h * d).contiguous()
+        kc, vc, end = self.append_rows(tm(keys), tm(values), layer_idx, b, s)
+        hm = lambda c: c[:, :end].view(b, end, h, d).permute(0, 2, 1, 3)
+        return hm(kc), hm(vc)

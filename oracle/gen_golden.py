@@ -432,6 +432,37 @@ def gen_qwen35_text(out):
     _save(os.path.join(out, "qwen35_text_tiny.safetensors"), t, "Qwen3.5 text stack (tiny hybrid GDN / gated attention) + per-op vectors")
 
 
+def gen_decode(out):
+    """KV-cache decoding: the reference's tiny Qwen3 (weights of qwen3_tiny.safetensors) driven exactly
+    as generate_loop_kv_cache does -- prefill with a KVCache, then one-token steps with position_ids -- teacher-forced with seeded
+    tokens so every step's logits are comparable, plus the greedy loop itself."""
+    from safetensors.torch import load_file
+
+    from llm_quest.generate import generate_loop_kv_cache
+    from llm_quest.qwen.qwen3.qwen3_model import Qwen3Model
+    from llm_quest.utils import KVCache
+
+    src = load_file(os.path.join(out, "qwen3_tiny.safetensors"))
+    sd = {k[3:]: v for k, v in src.items() if k.startswith("sd.")}
+    t = {}
+    torch.manual_seed(SEED + 11)
+    prompt = torch.randint(0, 512, (2, 10))
+    forced = torch.randint(0, 512, (6, 2, 1))
+    for tag, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+        m = Qwen3Model(dict(TINY_QWEN, dtype=dt)).eval()
+        m.load_state_dict({k: (v.to(dt) if v.is_floating_point() and k not in ("cos", "sin") else v) for k, v in sd.items()}, strict=False)
+        with torch.inference_mode():
+            kv = KVCache(num_layers=2, prompt_len=10, context_len=64)
+            t[f"{tag}.prefill"] = m(prompt, kv_cache=kv).clone()
+            for i in range(6):
+                t[f"{tag}.step{i}"] = m(forced[i], kv_cache=kv, position_ids=torch.tensor([[10 + i]])).clone()
+        if tag == "bf16":
+            one = prompt[:1]
+            t["greedy.ids"] = generate_loop_kv_cache(one, m, max_gen=8, context_length=64, device=torch.device("cpu"))
+    t["prompt"], t["forced"] = prompt, forced
+    _save(os.path.join(out, "decode_tiny.safetensors"), t, "tiny Qwen3 KV-cache decode: reference logits per step (bf16 + fp32 twin), greedy ids")
+
+
 def gen_pipeline(out):
     """Input pipeline: Pillow's bilinear resize -- the third-party arithmetic behind
     transforms.Resize in MultimodalDataset (dataset.py:341-349) -- on seeded random RGB images."""
@@ -461,7 +492,7 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
     only = os.environ.get("GOLDEN_ONLY")
-    for fn in (gen_index, gen_ops, gen_qwen, gen_vit, gen_vlm, gen_gpt, gen_qwen35, gen_qwen35_text, gen_pipeline):
+    for fn in (gen_index, gen_ops, gen_qwen, gen_vit, gen_vlm, gen_gpt, gen_qwen35, gen_qwen35_text, gen_pipeline, gen_decode):
         if only and fn.__name__ != only:
             continue
         fn(args.out)
