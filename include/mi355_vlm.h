@@ -307,11 +307,17 @@ int mi355_gemv_bf16(int M, int64_t N, int K, const void* x, int64_t ldx, const v
                     int64_t ldr, void* stream);
 /* One query row per (batch, head) against `len` cached keys / values (qwen3_attention.py:117-146 with a KV cache and q_seq_len 1):
  * q, o bf16 [B, Hq*D]; caches bf16 token-major, sequence b at k_cache + b*batch_stride, key j at + j*ld, kv head g at + g*D.
- * key_mask uint8 [B, >= len] row pitch ldm (1 = real token) or NULL; masked keys take the reference's finite fill. D in {64,128,256}. */
+ * key_mask uint8 [B, >= len] row pitch ldm (1 = real token) or NULL; masked keys take the reference's finite fill. D in {64,128,256}.
+ * len_dev != NULL: the number of valid keys is min(len, *len_dev) read on the device (hipGraph replay), len is then the capacity bound. */
 int mi355_attn_decode(int B, int Hq, int Hkv, int D, const void* q, const void* k_cache, const void* v_cache, int64_t batch_stride, int64_t ld,
-                      int len, const uint8_t* key_mask, int64_t ldm, void* o, float scale, void* stream);
-/* Greedy sampling (generate.py:472-476, temp == 0): out[r] = index of the row maximum of bf16 logits [rows, V] (first on ties). */
-int mi355_argmax_rows(int64_t rows, int64_t V, const void* logits, int64_t ld, int64_t* out, void* stream);
+                      int len, const int32_t* len_dev, const uint8_t* key_mask, int64_t ldm, void* o, float scale, void* stream);
+/* KVCache append of ONE decoded token per sequence with the write position on the device (so a captured hipGraph of the decode
+ * step can be replayed): cache[b, *pos, :] = rows[b, :] for keys and values; width = kv_heads * head_dim. */
+int mi355_kv_append(int B, int width, const void* k_rows, int64_t ldk, const void* v_rows, int64_t ldv, void* k_cache, void* v_cache,
+                    int64_t batch_stride, int64_t ld, int capacity, const int32_t* pos, void* stream);
+/* Greedy sampling (generate.py:472-476, temp == 0): out[r] = index of the row maximum of bf16 logits [rows, V] (first on ties).
+ * workspace: rows * 64 * 12 bytes (+8), 8-byte aligned: 64 column ranges per row are scanned in parallel, then merged. */
+int mi355_argmax_rows(int64_t rows, int64_t V, const void* logits, int64_t ld, int64_t* out, void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

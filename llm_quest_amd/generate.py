@@ -68,8 +68,11 @@ def generate_loop(input_tensor, model, max_gen, context_length, top_k=None, top_
 
 
 def generate_loop_kv_cache(input_tensor, model, max_gen, context_length, top_k=None, top_p=None, min_p=None, temp=0.0, eos_ids=None,
-                           device=torch.device("cuda")):
-    """Prefill once, then one-token decode steps through the KV cache (reference: generate.py:97-151)."""
+                           device=torch.device("cuda"), use_graph=True):
+    """Prefill once, then one-token decode steps through the KV cache (reference: generate.py:97-151).  Greedy decoding
+    (``temp == 0``) replays one captured hipGraph per token (``use_graph``); sampling runs the steps eagerly."""
+    if use_graph and temp == 0.0 and max_gen > 0 and hasattr(model, "trf_blocks") and input_tensor.shape[-1] + max_gen <= context_length:
+        return _generate_greedy_graph(input_tensor, model, max_gen, context_length, eos_ids, device)
     token_ids = []
     kv_cache = KVCache(num_layers=len(model.trf_blocks), prompt_len=input_tensor.shape[-1], context_len=context_length)
     input_tensor = input_tensor.to(device)
@@ -87,4 +90,31 @@ def generate_loop_kv_cache(input_tensor, model, max_gen, context_length, top_k=N
             token_ids.append(next_token)
             logits = model(next_token, kv_cache=kv_cache, position_ids=next_position_id).squeeze(1)
             next_position_id += 1
+    return torch.cat([input_tensor] + token_ids, dim=-1)
+
+
+def _generate_greedy_graph(input_tensor, model, max_gen, context_length, eos_ids, device):
+    token_ids = []
+    kv_cache = KVCache(num_layers=len(model.trf_blocks), prompt_len=input_tensor.shape[-1], context_len=context_length)
+    input_tensor = input_tensor.to(device)
+    eos = None
+    if eos_ids is not None:
+        eos = torch.tensor(eos_ids if isinstance(eos_ids, list) else [eos_ids], device=device, dtype=torch.long)
+    with torch.inference_mode():
+        logits = model(input_tensor[:, -context_length:], kv_cache=kv_cache)[:, -1, :]
+        next_token = sampling(logits)
+        dec = None
+        try:
+            for _ in range(max_gen):
+                if eos is not None and torch.isin(next_token, eos).any():
+                    break
+                token_ids.append(next_token)
+                if len(token_ids) == max_gen:
+                    break
+                if dec is None:
+                    dec = ops_decode.GraphDecoder(model, kv_cache, next_token, max_gen)
+                next_token = dec.step()
+        finally:
+            if dec is not None:
+                dec.close()
     return torch.cat([input_tensor] + token_ids, dim=-1)

@@ -31,8 +31,9 @@ def gemv(x2d, w, residual=None):
     return y
 
 
-def attn_decode(q, kc, vc, length, Hq, Hkv, D, key_mask=None, scale=None):
-    """q [B, Hq*D]; kc / vc [B, capacity, Hkv*D]; attends to keys [0, length)."""
+def attn_decode(q, kc, vc, length, Hq, Hkv, D, key_mask=None, scale=None, len_dev=None):
+    """q [B, Hq*D]; kc / vc [B, capacity, Hkv*D]; attends to keys [0, length) -- or [0, min(length, *len_dev)) with the length read
+    on the device (graph replay)."""
     L.require_gpu(q, kc, vc, key_mask)
     B = q.shape[0]
     if not (q.is_contiguous() and q.dtype == BF16 and kc.dtype == BF16 and kc.shape == vc.shape and kc.stride() == vc.stride() and kc.stride(2) == 1):
@@ -45,7 +46,7 @@ def attn_decode(q, kc, vc, length, Hq, Hkv, D, key_mask=None, scale=None):
             raise ValueError("attn_decode: key_mask uint8 [B, >= length]")
         ldm = key_mask.stride(0)
     o = torch.empty_like(q)
-    L.call("mi355_attn_decode", B, Hq, Hkv, D, L.ptr(q), L.ptr(kc), L.ptr(vc), kc.stride(0), kc.stride(1), length, L.ptr(key_mask), ldm, L.ptr(o),
+    L.call("mi355_attn_decode", B, Hq, Hkv, D, L.ptr(q), L.ptr(kc), L.ptr(vc), kc.stride(0), kc.stride(1), length, L.ptr(len_dev), L.ptr(key_mask), ldm, L.ptr(o),
            D ** -0.5 if scale is None else scale)
     return o
 
@@ -55,13 +56,28 @@ def argmax_rows(logits2d):
     if logits2d.dtype != BF16 or logits2d.dim() != 2 or logits2d.stride(1) != 1:
         raise ValueError("argmax_rows: bf16 [rows, V] with unit inner stride")
     out = torch.empty(logits2d.shape[0], dtype=torch.int64, device=logits2d.device)
-    L.call("mi355_argmax_rows", logits2d.shape[0], logits2d.shape[1], L.ptr(logits2d), logits2d.stride(0), L.ptr(out))
+    ws = torch.empty(logits2d.shape[0] * 64 * 12 // 8 + 2, dtype=torch.int64, device=logits2d.device)
+    L.call("mi355_argmax_rows", logits2d.shape[0], logits2d.shape[1], L.ptr(logits2d), logits2d.stride(0), L.ptr(out), L.ptr(ws))
     return out
 
 
+def kv_append_dev(k_rows, v_rows, kc, vc, write_pos_dev):
+    """cache[b, *write_pos, :] = rows[b, :] (one decoded token per sequence, position on the device)."""
+    L.require_gpu(k_rows, v_rows, kc, vc, write_pos_dev)
+    B, width = k_rows.shape
+    if kc.shape != vc.shape or kc.stride() != vc.stride() or kc.shape[0] != B or kc.shape[2] != width or write_pos_dev.dtype != torch.int32:
+        raise ValueError("kv_append_dev: caches [B, capacity, width] of one layout, position int32 on the device")
+    L.call("mi355_kv_append", B, width, L.ptr(k_rows), k_rows.stride(0), L.ptr(v_rows), v_rows.stride(0), L.ptr(kc), L.ptr(vc), kc.stride(0), kc.stride(1),
+           kc.shape[1], L.ptr(write_pos_dev))
+
+
 @torch.no_grad()
-def qwen3_forward_cached(model, x, kv_cache, attn_mask=None, position_ids=None, input_embedded=False):
-    """Logits (b, s, vocab) of ``Qwen3Model`` with ``kv_cache`` updated in place (reference: qwen3_model.py:60-94)."""
+def qwen3_forward_cached(model, x, kv_cache, attn_mask=None, position_ids=None, input_embedded=False, dev_state=None):
+    """Logits (b, s, vocab) of ``Qwen3Model`` with ``kv_cache`` updated in place (reference: qwen3_model.py:60-94).
+
+    ``dev_state = (rope_pos int32 [b], write_pos int32 [1], length int32 [1])`` (all on the device) switches the one-token step to
+    device-side bookkeeping -- nothing the kernels are launched with changes from token to token, so the step can be captured in a
+    hipGraph and replayed (``GraphDecoder``); the cache object's host counters are then advanced by the caller."""
     model._build_arenas()
     L.require_gpu(x)
     emb_w = model.emb_dict.weight
@@ -75,7 +91,11 @@ def qwen3_forward_cached(model, x, kv_cache, attn_mask=None, position_ids=None, 
     decode = start > 0
     if decode and S != 1:
         raise NotImplementedError("with a filled KV cache one new token per sequence is decoded (q_seq_len 1, generate.py:139-148)")
-    if position_ids is not None:
+    if dev_state is not None:
+        if not decode:
+            raise ValueError("device-side bookkeeping applies to one-token decode steps only")
+        pos, write_pos, len_dev = dev_state
+    elif position_ids is not None:
         pos = position_ids.to(device=h.device, dtype=torch.int32).expand(B, S).reshape(-1).contiguous()
     else:
         pos = (start + torch.arange(S, dtype=torch.int32, device=h.device)).repeat(B)
@@ -93,8 +113,15 @@ def qwen3_forward_cached(model, x, kv_cache, attn_mask=None, position_ids=None, 
         qkv = lin(h1, arena.fused(att.w_queries.weight, att.w_values.weight))
         q, k, _ = K.qknorm_rope_fwd(qkv, att.q_norm.weight, att.k_norm.weight, model.cos, model.sin, pos, Hq, Hkv, D)
         v = qkv[:, (Hq + Hkv) * D :]
-        kc, vc, end = kv_cache.append_rows(k, v, att.layer_idx, B, S)
-        if decode:
+        if dev_state is not None:
+            kc, vc = kv_cache.keys_cache[att.layer_idx], kv_cache.values_cache[att.layer_idx]
+            kv_append_dev(k, v, kc, vc, write_pos)
+            ctx = attn_decode(q, kc, vc, kc.shape[1], Hq, Hkv, D, key_mask=km, scale=att.att_scaling, len_dev=len_dev)
+        else:
+            kc, vc, end = kv_cache.append_rows(k, v, att.layer_idx, B, S)
+        if dev_state is not None:
+            pass
+        elif decode:
             ctx = attn_decode(q, kc, vc, end, Hq, Hkv, D, key_mask=km, scale=att.att_scaling)
         else:
             ctx, _ = K.attn_fwd(q, k, v, B, S, Hq, Hkv, D, key_mask=None if km is None else km[:, :S].contiguous(), causal=True, scale=att.att_scaling)
@@ -104,3 +131,85 @@ def qwen3_forward_cached(model, x, kv_cache, attn_mask=None, position_ids=None, 
         h = lin(K.swiglu_fwd(gu, ffn.lin1.weight.shape[0]), ffn.lin2.weight, residual=h)
     hn, _ = K.rmsnorm_fwd(h, model.final_norm.weight, want_rstd=False)
     return lin(hn, model.out_head.weight).view(B, S, -1)
+
+
+class GraphDecoder:
+    """Greedy one-token decode steps of ``Qwen3Model`` as ONE captured hipGraph, replayed per token.
+
+    A decode step is ~340 small launches (28 layers x 12 kernels); launched one by one from Python the step is launch-bound
+    (3.9 ms at batch 1 for 2.4 ms of kernels).  Everything that changes from token to token -- the token ids, the rotary position,
+    the cache write position and length -- lives in device buffers that the graph's own tail updates, so replay needs no host work.
+    The cache must already hold the prompt (prefill) and have room for every token to come (``reserve``): its buffers may not move.
+    """
+
+    def __init__(self, model, kv_cache, first_token, max_new_tokens):
+        L.require_gpu(first_token)
+        self.model, self.kv = model, kv_cache
+        B = first_token.shape[0]
+        start = kv_cache.start_pos
+        need = start + max_new_tokens
+        if need > kv_cache.context_len:
+            raise ValueError(f"GraphDecoder: {need} tokens exceed context_len {kv_cache.context_len}")
+        kv_cache.reserve(need)
+        dev = first_token.device
+        self.tok = first_token.reshape(B, 1).to(torch.int64).clone()
+        self.rope_pos = torch.full((B,), start, dtype=torch.int32, device=dev)
+        self.write_pos = torch.tensor([start], dtype=torch.int32, device=dev)
+        self.length = torch.tensor([start + 1], dtype=torch.int32, device=dev)
+        self.graph = None
+
+    def _step(self):
+        logits = qwen3_forward_cached(self.model, self.tok, self.kv, dev_state=(self.rope_pos, self.write_pos, self.length))
+        nxt = argmax_rows(logits.view(logits.shape[0], -1))
+        self.tok.copy_(nxt.unsqueeze(-1))
+        self.rope_pos.add_(1)
+        self.write_pos.add_(1)
+        self.length.add_(1)
+
+    def step(self):
+        """Consumes ``self.tok`` (the token chosen last), leaves the next greedy token in ``self.tok`` and returns a copy of it."""
+        if self.graph is None:
+            self._step()  # first step eagerly: loads every kernel before capture
+            self._advance_host()
+            out = self.tok.clone()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._step()
+            self.graph = g
+            _live.add(self)
+            # capture does not execute: state is still the one after the eager step
+            return out
+        self.graph.replay()
+        self._advance_host()
+        return self.tok.clone()
+
+    def _advance_host(self):
+        self.kv.start_pos += 1
+        self.kv.end_pos = self.kv.start_pos
+
+    def close(self):
+        """Destroy the captured graph NOW.  A hipGraph that is still alive when the interpreter shuts down is torn down after the
+        HIP runtime's own teardown has begun and costs about a minute on ROCm 7.2 (measured); released here it takes 60 ms."""
+        if self.graph is not None:
+            torch.cuda.synchronize()
+            self.graph = None
+        _live.discard(self)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_live = set()
+
+
+def _close_all():
+    for d in list(_live):
+        d.close()
+
+
+import atexit  # noqa: E402
+
+atexit.register(_close_all)

@@ -48,6 +48,23 @@ class KVCache:
                     K.copy2d(old[b, : self.start_pos], new[b, : self.start_pos])
             cache[layer_idx] = new
 
+    def reserve(self, capacity):
+        """Grow every layer's buffers to at least ``capacity`` rows now (contents kept), so that later appends never reallocate --
+        required before a decode step is captured in a hipGraph."""
+        capacity = min(int(capacity), self.context_len)
+        if not self.keys_cache:
+            self.kv_capacity = max(self.kv_capacity, capacity)
+            return
+        if capacity <= min(c.shape[1] for c in self.keys_cache):
+            return
+        self.kv_capacity = max(self.kv_capacity, capacity)
+        saved_end = self.end_pos
+        self.end_pos = self.kv_capacity
+        for layer_idx in range(self.num_layers):
+            if self.keys_cache[layer_idx].shape[1] < self.kv_capacity:
+                self._grow_kv_capacity(layer_idx)
+        self.end_pos = saved_end
+
     def append_rows(self, k_rows, v_rows, layer_idx, batch_size, new_seq_len):
         """k_rows / v_rows: token-major [batch*new_seq_len, kv_heads*head_dim] (row-strided views allowed).  Returns
         (k_cache [batch, capacity, width], v_cache, end_pos) with the new rows in place at [start_pos, end_pos)."""
