@@ -51,11 +51,14 @@ class GradSync:
     (Qwen3 TransformerBlocks, ViTAdapter); ``tail_arenas`` are reduced in ``finish_step`` (embedding / LM-head arena).
     """
 
-    def __init__(self, owners, tail_arenas=(), group=None):
+    def __init__(self, owners, tail_arenas=(), group=None, tail_params=()):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.group = group
         self.owners = list(owners)
         self.tail = list(tail_arenas)
+        # stand-alone parameters outside every arena (the fp32 log_A / post_norm.weight of the Qwen3.5 GDN layers, a fp32 vision
+        # tower): their gradients travel as ONE coalesced buffer in finish_step
+        self.tail_params = [p for p in tail_params if p.requires_grad]
         self._pending = []
         self._done = set()
         self.comm_stream = None
@@ -118,8 +121,31 @@ class GradSync:
                 self._done.add(id(ar))
                 ar.untouched_to_zero()
                 self._reduce(ar)
+        self._reduce_tail_params()
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    def _reduce_tail_params(self):
+        ps = self.tail_params
+        if not ps:
+            return
+        by_dtype = {}
+        for p in ps:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            by_dtype.setdefault(p.grad.dtype, []).append(p)
+        for group_ps in by_dtype.values():
+            flat = torch.cat([p.grad.reshape(-1) for p in group_ps])  # bucket assembly (communication plumbing)
+            if self.backend == "nccl":
+                dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+            else:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+                flat.div_(self.world)
+            off = 0
+            for p in group_ps:
+                n = p.grad.numel()
+                p.grad.copy_(flat[off : off + n].view_as(p.grad))
+                off += n
 
     def broadcast_parameters(self, modules, src=0):
         """Make every replica start from rank ``src``'s weights (one broadcast per arena / parameter)."""
@@ -139,3 +165,16 @@ def sync_for_vlm(vlm_model, adapter):
     vlm_model._build_arenas()
     owners = list(reversed(list(vlm_model.trf_blocks))) + [adapter]
     return GradSync(owners, tail_arenas=[vlm_model._top_arena])
+
+
+def sync_for_qwen35(vlm):
+    """GradSync for ``Qwen3_5VLM`` / ``Qwen3_5TextModel`` (BASELINE config 5): the text blocks' bf16 arenas fire last -> first during
+    backward, the embedding / head arena and every parameter outside an arena (fp32 GDN parameters, the fp32 vision tower) follow in
+    ``finish_step``."""
+    lm = getattr(vlm, "language_model", vlm)
+    lm._build_arenas()
+    in_arena = set()
+    for ar in lm.arenas():
+        in_arena.update(id(p) for p in ar.params)
+    tail_params = [p for p in vlm.parameters() if id(p) not in in_arena]
+    return GradSync(list(reversed(list(lm.trf_blocks))), tail_arenas=[lm._top_arena], tail_params=tail_params)

@@ -37,7 +37,8 @@ def _worker(rank, world, port, out):
     assert (r, w) == (rank, world)
     owners = [_Owner(100 + rank + i) for i in range(3)]  # different init per rank on purpose
     tail_owner = _Owner(50 + rank)
-    sync = GradSync(owners, tail_arenas=[arena_for(tail_owner)])
+    loose = [torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(2, 3))]  # parameters outside every arena
+    sync = GradSync(owners, tail_arenas=[arena_for(tail_owner)], tail_params=loose)
     sync.broadcast_parameters(owners + [tail_owner])
     ref0 = _Owner(100)  # rank 0's first owner
     assert torch.equal(owners[0].a, ref0.a)
@@ -54,6 +55,7 @@ def _worker(rank, world, port, out):
         ar = arena_for(tail_owner)
         view, acc = ar.grad_target(tail_owner.a)
         view.copy_(torch.full_like(view, 10.0 * (rank + 1)))
+        loose[0].grad = torch.full((5,), float(rank + 1))  # loose[1] gets no gradient on purpose: reduced as zeros
         sync.finish_step()
 
     fake_backward(0)
@@ -65,10 +67,14 @@ def _worker(rank, world, port, out):
     ok &= owners[2].a.grad is not None and float(owners[2].a.grad.abs().sum()) == 0.0
     ok &= bool(torch.allclose(tail_owner.a.grad, torch.full_like(tail_owner.a, 10.0 * sum(range(1, world + 1)) / world)))
     ok &= float(tail_owner.b.grad.abs().sum()) == 0.0
+    ok &= bool(torch.allclose(loose[0].grad, torch.full((5,), sum(range(1, world + 1)) / world)))
+    ok &= loose[1].grad is not None and float(loose[1].grad.abs().sum()) == 0.0
     # second step after zero_grad(set_to_none=True): buckets are overwritten, not accumulated
     for m in owners + [tail_owner]:
         for p in m.parameters():
             p.grad = None
+    for p in loose:
+        p.grad = None
     fake_backward(1)
     ok &= bool(torch.allclose(owners[0].a.grad, torch.full_like(owners[0].a, expect(0, 1))))
     out.put((rank, ok))
