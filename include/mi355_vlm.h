@@ -254,6 +254,10 @@ int mi355_causal_conv_silu_fwd(int B, int S, int C, int ksize, const void* x, in
 int mi355_causal_conv_silu_bwd(int B, int S, int C, int ksize, const void* x, int64_t ldx, const void* w, const void* dy, void* dc_ws, void* dx,
                                int64_t lddx, float* dw_partial, int token_chunk, void* stream);
 
+/* One decoded token of the same conv (_causal_conv1d_update, qwen3_5_text_model.py:425-456, + SiLU): conv_state bf16 [B, 4, C] TOKEN-MAJOR
+ * (the last 4 pre-conv inputs; upstream keeps (b, C, 4)) is shifted by one and takes x_new [B, C] (row pitch ldx); y bf16 [B, C]. */
+int mi355_causal_conv_silu_step(int B, int C, int ksize, const void* x_new, int64_t ldx, void* conv_state, const void* w, void* y, void* stream);
+
 /* l2_norm of q / k heads (qwen3_next_attention.py:51-60): x heads at x[t*ldx + h*D]; y bf16 [tokens, H*D]. */
 int mi355_l2norm_fwd(int64_t tokens, int H, int D, const void* x, int64_t ldx, void* y, void* stream);
 int mi355_l2norm_bwd(int64_t tokens, int H, int D, const void* x, int64_t ldx, const void* dy, void* dx, int64_t lddx, void* stream);
@@ -261,10 +265,12 @@ int mi355_l2norm_bwd(int64_t tokens, int H, int D, const void* x, int64_t ldx, c
 /* gated_delta_rule (qwen3_next_attention.py:103-159), fp32 state, q/k bf16 [B*S, Hqk*Dk] (already l2-normalised), v bf16
  * [B*S, Hv*Dv] row pitch ldv, beta/alpha fp32 [B*S, Hv]; value head h uses q/k head h / (Hv/Hqk) (repeat_interleave).
  * o bf16 [B*S, Hv*Dv].  checkpoints (training): fp32 [B, Hv, ceil(S/chunk), Dv, Dk], chunk = mi355_gated_delta_rule_chunk().
- * final_state (optional): fp32 [B, Hv, Dv, Dk].  Dk in {16, 128}; Dv % 16 == 0. */
+ * initial_state / final_state (optional): fp32 [B, Hv, Dv, Dk], the recurrent state of Qwen3_5Cache (utils.py:535-624); they may be the same
+ * buffer (decode: S = 1, _gated_delta_rule_step of qwen3_5_text_model.py:459-507).  Dk in {16, 128}; Dv % 16 == 0. */
 int mi355_gated_delta_rule_chunk(void);
 int mi355_gated_delta_rule_fwd(int B, int S, int Hqk, int Hv, int Dk, int Dv, const void* q, const void* k, const void* v, int64_t ldv,
-                               const float* beta, const float* alpha, void* o, float* checkpoints, float* final_state, void* stream);
+                               const float* beta, const float* alpha, void* o, float* checkpoints, const float* initial_state, float* final_state,
+                               void* stream);
 int64_t mi355_gated_delta_rule_bwd_workspace_bytes(int B, int S, int Hv, int Dk, int Dv);
 int mi355_gated_delta_rule_bwd(int B, int S, int Hqk, int Hv, int Dk, int Dv, const void* q, const void* k, const void* v, int64_t ldv,
                                const float* beta, const float* alpha, const float* checkpoints, const void* d_o, void* dq, void* dk, void* dv,

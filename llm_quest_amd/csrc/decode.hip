@@ -24,7 +24,7 @@ __device__ __forceinline__ void unpack8(const u32x4 v, float (&f)[8]) {
 
 // ------------------------------------------------------------------------------------------- skinny GEMM (NT), M <= 8
 template <int MT>
-__global__ __launch_bounds__(256) void gemv_kernel(int64_t N, int K, const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ W,
+__global__ __launch_bounds__(256) void gemv_kernel(int M, int64_t N, int K, const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ W,
                                                    int64_t ldw, bf16_t* __restrict__ y, int64_t ldy, const bf16_t* __restrict__ res, int64_t ldr) {
     const int lane = threadIdx.x & 63;
     const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(int64_t N, int K, const bf16_
         unpack8(*reinterpret_cast<const u32x4*>(w + k0), wf);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
+            if (m >= M) break;  // MT is the next power of two: rows M..MT-1 do not exist
             float xf[8];
             unpack8(*reinterpret_cast<const u32x4*>(x + m * ldx + k0), xf);
 #pragma unroll
@@ -46,6 +47,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(int64_t N, int K, const bf16_
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
+        if (m >= M) break;
         const float s = wave_sum(acc[m]);
         if (lane == 0) y[m * ldy + n] = f2bf(res ? s + bf2f(res[m * ldr + n]) : s);
     }
@@ -206,7 +208,7 @@ extern "C" int mi355_gemv_bf16(int M, int64_t N, int K, const void* x, int64_t l
     MI355_REQUIRE(N > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldx >= K && ldw >= K && ldy >= N, "gemv_bf16: K and the leading dimensions of x / W must be multiples of 8");
     MI355_REQUIRE(x && W && y && (!residual || ldr >= N), "gemv_bf16: null pointer or residual pitch too small");
     const int grid = (int)((N + 3) / 4);
-#define LAUNCH(MT) gemv_kernel<MT><<<grid, 256, 0, ST(stream)>>>(N, K, (const bf16_t*)x, ldx, (const bf16_t*)W, ldw, (bf16_t*)y, ldy, (const bf16_t*)residual, ldr)
+#define LAUNCH(MT) gemv_kernel<MT><<<grid, 256, 0, ST(stream)>>>(M, N, K, (const bf16_t*)x, ldx, (const bf16_t*)W, ldw, (bf16_t*)y, ldy, (const bf16_t*)residual, ldr)
     if (M == 1) LAUNCH(1); else if (M == 2) LAUNCH(2); else if (M <= 4) LAUNCH(4); else LAUNCH(8);
 #undef LAUNCH
     MI355_LAUNCH_CHECK("gemv_bf16");
@@ -225,13 +227,13 @@ extern "C" int mi355_kv_append(int B, int width, const void* k_rows, int64_t ldk
 extern "C" int mi355_attn_decode(int B, int Hq, int Hkv, int D, const void* q, const void* k_cache, const void* v_cache, int64_t batch_stride,
                                  int64_t ld, int len, const int32_t* len_dev, const uint8_t* key_mask, int64_t ldm, void* o, float scale, void* stream) {
     MI355_REQUIRE(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && len > 0, "attn_decode: bad sizes");
-    MI355_REQUIRE(D == 64 || D == 128 || D == 256, "attn_decode: head_dim %d not built (64, 128, 256)", D);
+    MI355_REQUIRE(D == 32 || D == 64 || D == 128 || D == 256, "attn_decode: head_dim %d not built (32, 64, 128, 256)", D);
     MI355_REQUIRE(q && k_cache && v_cache && o && ld >= (int64_t)Hkv * D && ld % 8 == 0 && batch_stride >= (int64_t)len * ld, "attn_decode: cache pitch / stride too small");
     MI355_REQUIRE(!key_mask || ldm >= len, "attn_decode: key mask pitch smaller than the cache length");
     MI355_REQUIRE(B <= 65535, "attn_decode: grid limits");
     dim3 grid(Hq, B);
 #define LAUNCH(DD) attn_decode_kernel<DD><<<grid, 64 * DEC_WAVES, 0, ST(stream)>>>(Hq, Hkv, (const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)v_cache, batch_stride, ld, len, len_dev, key_mask, ldm, (bf16_t*)o, scale * LOG2E)
-    if (D == 64) LAUNCH(64); else if (D == 128) LAUNCH(128); else LAUNCH(256);
+    if (D == 32) LAUNCH(32); else if (D == 64) LAUNCH(64); else if (D == 128) LAUNCH(128); else LAUNCH(256);
 #undef LAUNCH
     MI355_LAUNCH_CHECK("attn_decode");
     return 0;

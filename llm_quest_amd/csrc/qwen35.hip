@@ -436,6 +436,36 @@ __global__ __launch_bounds__(256) void conv_silu_bwd_dx_kernel(int B, int S, int
     *reinterpret_cast<u32x4*>(dx + tok * lddx + c0) = pack8(acc);
 }
 
+// one decoded token (torch_causal_conv1d_update of the reference, qwen3_5_text_model.py:425-456 + SiLU): the state holds the last
+// KS pre-conv inputs token-major [B, KS, C]; shift it by one, append x_new, y = silu(bf16(sum_j w[c, j] state[j, c])).  A thread owns
+// 8 channels of one sequence and all KS rows of them, so the in-place update has no race.
+template <int KS>
+__global__ __launch_bounds__(256) void conv_silu_step_kernel(int B, int C, const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ state,
+                                                             const bf16_t* __restrict__ w, bf16_t* __restrict__ y) {
+    const int cvec = C >> 3;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)B * cvec) return;
+    const int b = (int)(idx / cvec), c0 = (int)(idx % cvec) * 8;
+    float tmp[8 * KS];
+#pragma unroll
+    for (int i = 0; i < KS; ++i) unpack8(*reinterpret_cast<const u32x4*>(w + (int64_t)c0 * KS + i * 8), *reinterpret_cast<float(*)[8]>(tmp + 8 * i));
+    bf16_t* st = state + (int64_t)b * KS * C + c0;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+        const u32x4 raw = j + 1 < KS ? *reinterpret_cast<const u32x4*>(st + (int64_t)(j + 1) * C) : *reinterpret_cast<const u32x4*>(x + (int64_t)b * ldx + c0);
+        float xv[8];
+        unpack8(raw, xv);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = fmaf(tmp[c * KS + j], xv[c], acc[c]);
+        *reinterpret_cast<u32x4*>(st + (int64_t)j * C) = raw;
+    }
+    float o[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] = silu_f(rbf(acc[c]));
+    *reinterpret_cast<u32x4*>(y + (int64_t)b * C + c0) = pack8(o);
+}
+
 // ------------------------------------------------------------------------------------------- l2 norm of q / k heads
 // y = bf16(x * bf16(1 / max(bf16(||x||), 1e-6)))   (qwen3_next_attention.py:51-60 on bf16 tensors)
 template <int EPL>
@@ -538,7 +568,7 @@ __global__ __launch_bounds__(256) void gdr_fwd_kernel(int B, int S, int Hqk, int
                                                       const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t ldv,
                                                       const float* __restrict__ beta, const float* __restrict__ alpha,
                                                       bf16_t* __restrict__ o, float* __restrict__ ckpt, int CH, int nchunk,
-                                                      float* __restrict__ final_state, float qscale) {
+                                                      const float* __restrict__ initial_state, float* __restrict__ final_state, float qscale) {
     constexpr int CPL = DK / LPR, RPW = 64 / LPR;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.z, h = blockIdx.y;
@@ -557,6 +587,11 @@ __global__ __launch_bounds__(256) void gdr_fwd_kernel(int B, int S, int Hqk, int
     float st[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) st[j] = 0.f;
+    if (initial_state) {  // decode / continued prefill: the recurrent state of Qwen3_5Cache (may alias final_state: each lane reads, then writes, its own slice)
+        const float* c = initial_state + (((int64_t)b * Hv + h) * Dv + row) * DK + cg * CPL;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) st[j] = c[j];
+    }
     RawVec<CPL> kc, qc, kn, qn;
     float a_c, b_c, a_n = 0.f, b_n = 0.f;
     bf16_t v_c, v_n = 0;
@@ -1046,6 +1081,16 @@ extern "C" int mi355_causal_conv_silu_bwd(int B, int S, int C, int ksize, const 
     return 0;
 }
 
+extern "C" int mi355_causal_conv_silu_step(int B, int C, int ksize, const void* x_new, int64_t ldx, void* conv_state, const void* w, void* y,
+                                           void* stream) {
+    MI355_REQUIRE(B > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0 && ldx >= C, "causal_conv_silu_step: channels and ld must be multiples of 8");
+    MI355_REQUIRE(ksize == 4, "causal_conv_silu_step: kernel size %d not built (4 only)", ksize);
+    MI355_REQUIRE(x_new && conv_state && w && y, "causal_conv_silu_step: null pointer");
+    conv_silu_step_kernel<4><<<grid1d((int64_t)B * (C / 8)), 256, 0, ST(stream)>>>(B, C, (const bf16_t*)x_new, ldx, (bf16_t*)conv_state, (const bf16_t*)w, (bf16_t*)y);
+    MI355_LAUNCH_CHECK("causal_conv_silu_step");
+    return 0;
+}
+
 extern "C" int mi355_l2norm_fwd(int64_t tokens, int H, int D, const void* x, int64_t ldx, void* y, void* stream) {
     MI355_REQUIRE(tokens > 0 && H > 0 && D > 0 && D <= 256 && x && y && ldx >= (int64_t)H * D, "l2norm_fwd: bad arguments (head_dim <= 256)");
     const int grid = wave_grid(tokens * H, 8192);
@@ -1075,7 +1120,8 @@ static int check_gdr(int B, int S, int Hqk, int Hv, int Dk, int Dv) {
 extern "C" int mi355_gated_delta_rule_chunk(void) { return GDR_CH; }
 
 extern "C" int mi355_gated_delta_rule_fwd(int B, int S, int Hqk, int Hv, int Dk, int Dv, const void* q, const void* k, const void* v, int64_t ldv,
-                                          const float* beta, const float* alpha, void* o, float* checkpoints, float* final_state, void* stream) {
+                                          const float* beta, const float* alpha, void* o, float* checkpoints, const float* initial_state,
+                                          float* final_state, void* stream) {
     if (check_gdr(B, S, Hqk, Hv, Dk, Dv)) return 1;
     MI355_REQUIRE(q && k && v && beta && alpha && o && ldv >= (int64_t)Hv * Dv, "gated_delta_rule_fwd: bad arguments");
     const int CH = mi355_gated_delta_rule_chunk(), nchunk = (S + CH - 1) / CH;
@@ -1083,9 +1129,9 @@ extern "C" int mi355_gated_delta_rule_fwd(int B, int S, int Hqk, int Hv, int Dk,
     const int rows_per_block = Dk == 128 ? 4 * (64 / 8) : 4 * (64 / 4);
     dim3 grid((Dv + rows_per_block - 1) / rows_per_block, Hv, B);
     if (Dk == 128)
-        gdr_fwd_kernel<128, 8><<<grid, 256, 0, ST(stream)>>>(B, S, Hqk, Hv, Dv, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldv, beta, alpha, (bf16_t*)o, checkpoints, CH, nchunk, final_state, qs);
+        gdr_fwd_kernel<128, 8><<<grid, 256, 0, ST(stream)>>>(B, S, Hqk, Hv, Dv, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldv, beta, alpha, (bf16_t*)o, checkpoints, CH, nchunk, initial_state, final_state, qs);
     else
-        gdr_fwd_kernel<16, 4><<<grid, 256, 0, ST(stream)>>>(B, S, Hqk, Hv, Dv, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldv, beta, alpha, (bf16_t*)o, checkpoints, CH, nchunk, final_state, qs);
+        gdr_fwd_kernel<16, 4><<<grid, 256, 0, ST(stream)>>>(B, S, Hqk, Hv, Dv, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldv, beta, alpha, (bf16_t*)o, checkpoints, CH, nchunk, initial_state, final_state, qs);
     MI355_LAUNCH_CHECK("gated_delta_rule_fwd");
     return 0;
 }

@@ -197,6 +197,18 @@ def causal_conv_silu_fwd(x, w, B, S):
     return y
 
 
+def causal_conv_silu_step(x_new, conv_state, w):
+    """x_new [B, C] view; conv_state bf16 [B, k, C] (updated in place); returns y [B, C]."""
+    L.require_gpu(x_new, conv_state, w)
+    _cols(x_new, "causal_conv_silu_step")
+    B, C = x_new.shape
+    if not (conv_state.dtype == BF16 and conv_state.is_contiguous() and tuple(conv_state.shape) == (B, w.shape[-1], C)):
+        raise ValueError("causal_conv_silu_step: conv_state must be contiguous bf16 [B, k, C]")
+    y = torch.empty((B, C), dtype=BF16, device=x_new.device)
+    L.call("mi355_causal_conv_silu_step", B, C, w.shape[-1], L.ptr(x_new), x_new.stride(0), L.ptr(conv_state), L.ptr(w), L.ptr(y))
+    return y
+
+
 CONV_TOKEN_CHUNK = 32
 
 
@@ -250,8 +262,9 @@ def _check_gdr(q, k, v, beta, alpha, B, S, Hqk, Hv, Dk, Dv):
             raise ValueError(f"gated_delta_rule: {n} must be contiguous fp32 [B*S, Hv]")
 
 
-def gated_delta_rule_fwd(q, k, v, beta, alpha, B, S, Hqk, Hv, Dk, Dv, keep=True, want_state=False):
-    """Returns (o bf16 [B*S, Hv*Dv], checkpoints or None, final_state or None)."""
+def gated_delta_rule_fwd(q, k, v, beta, alpha, B, S, Hqk, Hv, Dk, Dv, keep=True, want_state=False, state=None):
+    """Returns (o bf16 [B*S, Hv*Dv], checkpoints or None, final_state or None).  ``state`` fp32 [B, Hv, Dv, Dk]: carried-in recurrent
+    state, updated IN PLACE (and returned as final_state)."""
     L.require_gpu(q, k, v, beta, alpha)
     _check_gdr(q, k, v, beta, alpha, B, S, Hqk, Hv, Dk, Dv)
     o = torch.empty((B * S, Hv * Dv), dtype=BF16, device=q.device)
@@ -259,8 +272,14 @@ def gated_delta_rule_fwd(q, k, v, beta, alpha, B, S, Hqk, Hv, Dk, Dv, keep=True,
     if keep:
         ch = gdr_chunk()
         ck = torch.empty((B, Hv, (S + ch - 1) // ch, Dv, Dk), dtype=F32, device=q.device)
-    fin = torch.empty((B, Hv, Dv, Dk), dtype=F32, device=q.device) if want_state else None
-    L.call("mi355_gated_delta_rule_fwd", B, S, Hqk, Hv, Dk, Dv, L.ptr(q), L.ptr(k), L.ptr(v), v.stride(0), L.ptr(beta), L.ptr(alpha), L.ptr(o), L.ptr(ck), L.ptr(fin))
+    if state is not None:
+        L.require_gpu(state)
+        if not (state.dtype == F32 and state.is_contiguous() and tuple(state.shape) == (B, Hv, Dv, Dk)):
+            raise ValueError("gated_delta_rule_fwd: state must be contiguous fp32 [B, Hv, Dv, Dk]")
+        fin = state
+    else:
+        fin = torch.empty((B, Hv, Dv, Dk), dtype=F32, device=q.device) if want_state else None
+    L.call("mi355_gated_delta_rule_fwd", B, S, Hqk, Hv, Dk, Dv, L.ptr(q), L.ptr(k), L.ptr(v), v.stride(0), L.ptr(beta), L.ptr(alpha), L.ptr(o), L.ptr(ck), L.ptr(state), L.ptr(fin))
     return o, ck, fin
 
 

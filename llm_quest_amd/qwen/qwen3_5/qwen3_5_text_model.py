@@ -2,8 +2,8 @@
 SURVEY.md section 8 row a24): ``FusedGatedDeltaNet``, ``MRoPEGatedAttention``, ``Qwen3_5TransformerBlock``, ``Qwen3_5TextModel``
 with the reference's constructor keys, forward signatures and ``state_dict`` keys.
 
-One autograd node per block (llm_quest_amd/ops_q35.py).  Training / prefill only: the ``cache`` arguments are the decode path
- and raise.  Extensions as on Qwen3Model: ``forward_hidden`` / ``lm_loss`` (LM head + cross entropy on
+One autograd node per block (llm_quest_amd/ops_q35.py).  ``Qwen3_5TextModel.forward(..., cache=Qwen3_5Cache)`` decodes through
+``ops_decode.qwen35_forward_cached``; the ``cache`` arguments of the individual layers still raise.  Extensions as on Qwen3Model: ``forward_hidden`` / ``lm_loss`` (LM head + cross entropy on
 just the rows that feed the loss).
 """
 
@@ -169,8 +169,11 @@ class Qwen3_5TextModel(nn.Module):
         return self.final_norm(x)
 
     def forward(self, x=None, attn_mask=None, inputs_embs=None, position_ids=None, cache=None):
-        """Logits (b, s, vocab) bf16 (reference :388-417)."""
-        _no_cache(cache)
+        """Logits (b, s, vocab) bf16 (reference :388-417).  ``cache`` (utils.Qwen3_5Cache): inference, prefill / one-token steps."""
+        if cache is not None:
+            from llm_quest_amd import ops_decode
+
+            return ops_decode.qwen35_forward_cached(self, x, cache, attn_mask, inputs_embs, position_ids)
         return self.out_head(self.forward_hidden(x, attn_mask, inputs_embs, position_ids))
 
     def lm_loss(self, hidden_rows, targets):

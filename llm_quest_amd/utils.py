@@ -97,3 +97,42 @@ class KVCache:
         kc, vc, end = self.append_rows(tm(keys), tm(values), layer_idx, b, s)
         hm = lambda c: c[:, :end].view(b, end, h, d).permute(0, 2, 1, 3)
         return hm(kc), hm(vc)
+
+
+class Qwen3_5Cache:
+    """Hybrid cache of the Qwen3.5 text stack (reference: llm_quest/utils.py:535-624): a ``KVCache`` for the full-attention layers
+    (indexed by their position among the full-attention layers) and, per linear-attention layer, two fixed-size states --
+    ``conv_states[i]`` bf16 [batch, kernel_size, fused_dim] (TOKEN-MAJOR here; upstream keeps (batch, fused_dim, kernel_size)) and
+    ``recurrent_states[i]`` fp32 [batch, value_heads, v_head_dim, qk_head_dim] -- both updated in place by the decode kernels."""
+
+    def __init__(self, n_layers, linear_sdpa_ratio, prompt_len, context_len):
+        self.n_layers = n_layers
+        self.linear_sdpa_ratio = linear_sdpa_ratio
+        self.layer_types = ["full_attention" if (i + 1) % linear_sdpa_ratio == 0 else "linear_attention" for i in range(n_layers)]
+        self.full_attn_indices = [i for i, t in enumerate(self.layer_types) if t == "full_attention"]
+        self._full_attn_to_kv_idx = {g: i for i, g in enumerate(self.full_attn_indices)}
+        self.kv_cache = KVCache(num_layers=len(self.full_attn_indices), prompt_len=prompt_len, context_len=context_len)
+        self.conv_states = [None] * n_layers
+        self.recurrent_states = [None] * n_layers
+
+    def get_updated_kv_cache(self, keys, values, layer_idx):
+        return self.kv_cache.get_updated_cache(keys, values, self._full_attn_to_kv_idx[layer_idx])
+
+    def append_kv_rows(self, k_rows, v_rows, layer_idx, batch_size, new_seq_len):
+        return self.kv_cache.append_rows(k_rows, v_rows, self._full_attn_to_kv_idx[layer_idx], batch_size, new_seq_len)
+
+    @property
+    def has_previous_state(self):
+        return any(s is not None for t, s in zip(self.layer_types, self.conv_states) if t == "linear_attention")
+
+    def get_conv_state(self, layer_idx):
+        return self.conv_states[layer_idx]
+
+    def set_conv_state(self, layer_idx, conv_state):
+        self.conv_states[layer_idx] = conv_state
+
+    def get_recurrent_state(self, layer_idx):
+        return self.recurrent_states[layer_idx]
+
+    def set_recurrent_state(self, layer_idx, recurrent_state):
+        self.recurrent_states[layer_idx] = recurrent_state

@@ -463,6 +463,37 @@ def gen_decode(out):
     _save(os.path.join(out, "decode_tiny.safetensors"), t, "tiny Qwen3 KV-cache decode: reference logits per step (bf16 + fp32 twin), greedy ids")
 
 
+def gen_decode35(out):
+    """Qwen3_5Cache decoding (second half): the reference's tiny hybrid text model (bf16 weights of
+    qwen35_text_tiny.safetensors; fp32 twin = the same weights upcast) driven as qwen3_5_generate_text_only.py does -- prefill with
+    MRoPE position ids + cache, then teacher-forced one-token steps."""
+    from safetensors.torch import load_file
+
+    from llm_quest.qwen.qwen3_5.qwen3_5_text_model import Qwen3_5TextModel
+    from llm_quest.utils import Qwen3_5Cache
+
+    src = load_file(os.path.join(out, "qwen35_text_tiny.safetensors"))
+    sd = {k[len("txt.bf16.sd."):]: v for k, v in src.items() if k.startswith("txt.bf16.sd.")}
+    sd["mask"] = sd["mask"].bool()
+    t = {}
+    torch.manual_seed(SEED + 13)
+    prompt = torch.randint(0, 256, (2, 9))
+    forced = torch.randint(0, 256, (5, 2, 1))
+    for tag, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+        m = Qwen3_5TextModel({**TINY_Q35_TEXT, "dtype": dt}).eval()
+        keep32 = ("cos", "sin", "mask")
+        m.load_state_dict({k: (v if k in keep32 or not v.is_floating_point() or v.dtype == torch.float32 else v.to(dt)) for k, v in sd.items()})
+        with torch.inference_mode():
+            cache = Qwen3_5Cache(n_layers=4, linear_sdpa_ratio=2, prompt_len=9, context_len=64)
+            pid = torch.arange(9).view(1, 1, 9).expand(3, 2, 9)
+            t[f"{tag}.prefill"] = m(prompt, position_ids=pid, cache=cache).clone()
+            for i in range(5):
+                pid = torch.full((3, 2, 1), 9 + i)
+                t[f"{tag}.step{i}"] = m(forced[i], position_ids=pid, cache=cache).clone()
+    t["prompt"], t["forced"] = prompt, forced
+    _save(os.path.join(out, "decode35_tiny.safetensors"), t, "tiny Qwen3.5 text model, Qwen3_5Cache decode: reference logits per step (bf16 + fp32 twin)")
+
+
 def gen_pipeline(out):
     """Input pipeline: Pillow's bilinear resize -- the third-party arithmetic behind
     transforms.Resize in MultimodalDataset (dataset.py:341-349) -- on seeded random RGB images."""
@@ -492,7 +523,7 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
     only = os.environ.get("GOLDEN_ONLY")
-    for fn in (gen_index, gen_ops, gen_qwen, gen_vit, gen_vlm, gen_gpt, gen_qwen35, gen_qwen35_text, gen_pipeline, gen_decode):
+    for fn in (gen_index, gen_ops, gen_qwen, gen_vit, gen_vlm, gen_gpt, gen_qwen35, gen_qwen35_text, gen_pipeline, gen_decode, gen_decode35):
         if only and fn.__name__ != only:
             continue
         fn(args.out)
