@@ -645,12 +645,10 @@ __global__ __launch_bounds__(256) void gdr_fwd_kernel(int B, int S, int Hqk, int
 // Backward layout: a lane owns 4 rows x CPL columns, 16 lanes span Dk = 16*CPL, a wave owns 16 rows (4 row quads).  Row dot
 // products close inside 16-lane groups, the sums over rows (dq, dk, dbeta, dalpha) inside the lane and across the 4 quads;
 // each wave writes its partial sums for its 16 rows, a second kernel adds the row groups (and the value heads that share a
-// q/k head).  The reverse step t needs S_{t-1}.  Parking every S_{t-1} in HBM made the first version of this kernel purely
-// bandwidth-bound (2 x 5.9 GB per layer at B = 8: 3.1 ms); now the forward leaves a checkpoint every GDR_CH = 4 steps
-// (1.45 GB per layer), and per chunk (last first) phase A replays the 4 steps from the checkpoint parking S_{t-1} in LDS
-// (each lane's own 16-byte slots, [step][vector][lane]: conflict-free, no barrier -- nobody else reads them), phase B walks
-// the chunk backwards.  Operands and checkpoint of the NEXT chunk are requested before the current chunk's arithmetic.
-constexpr int GDR_CH = 4;
+// q/k head).
+constexpr int GDR_CH = 8;   // spacing of the HBM checkpoints the forward leaves (measured, B = 8, S = 708, fwd + bwd per layer: 4 -> 2.29 ms, 8 -> 2.22 ms, 16 -> 2.37 ms)
+constexpr int GDR_SUB = 4;  // steps whose S_{t-1} are parked in LDS at a time
+constexpr int GDR_NSUB = GDR_CH / GDR_SUB;
 template <int CPL>
 struct GdrOps {
     RawVec<CPL> k, q;
@@ -670,7 +668,35 @@ __device__ __forceinline__ void gdr_load_ops(GdrOps<CPL>& s, const bf16_t* kp, c
         s.g[r] = gp[r];
     }
 }
+// one forward step on a lane's 4 x CPL state slice (rows x columns), row dots over the 16 column lanes
+template <int CPL>
+__device__ __forceinline__ void gdr_replay_step(float (&st)[4 * CPL], const GdrOps<CPL>& op) {
+    float kf[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) kf[j] = raw_get<CPL>(op.k, j);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float u = 0.f;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            st[r * CPL + j] *= op.a;
+            u = fmaf(st[r * CPL + j], kf[j], u);
+        }
+        u = lanes_sum<16>(u);
+        const float c = op.b * (bf2f(op.v[r]) - u);
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) st[r * CPL + j] = fmaf(c, kf[j], st[r * CPL + j]);
+    }
+}
 
+// Two-level recomputation.  The reverse step t needs S_{t-1}.  Version 1 parked every S_{t-1} in HBM (2 x 5.9 GB per layer at
+// B = 8: purely bandwidth-bound, 3.1 ms); version 2 took 4-step checkpoints from the forward (1.45 GB per layer each way) and
+// parked 4 states in LDS; now the forward leaves a checkpoint every 16 steps (0.37 GB per layer) and, per 16-step chunk (last
+// first), this kernel (1) replays steps 0..11 keeping S_4, S_8, S_12 in registers (the accumulator file takes them), then for
+// the 4-step groups 3, 2, 1, 0: (2) phase A replays the group from its sub-checkpoint parking S_{t-1} in LDS -- each lane's own
+// 16-byte slots [step][vector][lane]: conflict-free, no barrier, nobody else reads them -- and (3) phase B walks the group
+// backwards.  The operands of the NEXT group in this order (and the next chunk's checkpoint) are requested before the current
+// group's arithmetic.
 template <int CPL>
 __global__ __launch_bounds__(256) void gdr_bwd_kernel(int B, int S, int Hqk, int Hv, int Dv, const bf16_t* __restrict__ q,
                                                       const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t ldv,
@@ -678,8 +704,8 @@ __global__ __launch_bounds__(256) void gdr_bwd_kernel(int B, int S, int Hqk, int
                                                       const float* __restrict__ ckpt, int nchunk, const bf16_t* __restrict__ d_o,
                                                       bf16_t* __restrict__ dv, int64_t lddv, float* __restrict__ pdq,
                                                       float* __restrict__ pdk, float* __restrict__ pdb, float* __restrict__ pda, float qscale) {
-    constexpr int DK = 16 * CPL;
-    __shared__ f32x4 park[4][GDR_CH][CPL][64];  // [wave][step][vector of the lane's 4*CPL state floats][lane]
+    constexpr int DK = 16 * CPL, NS = 4 * CPL;
+    __shared__ f32x4 park[4][GDR_SUB][CPL][64];  // [wave][step][vector of the lane's 4*CPL state floats][lane]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.z, h = blockIdx.y;
     const int rg = blockIdx.x * 4 + wave, RG = Dv / 16;
@@ -700,142 +726,154 @@ __global__ __launch_bounds__(256) void gdr_bwd_kernel(int B, int S, int Hqk, int
     const int64_t slot = ((int64_t)b * Hv + h) * RG + rg;
     float* wq = pdq + slot * (int64_t)S * DK + col;
     float* wk = pdk + slot * (int64_t)S * DK + col;
-    float dS[4 * CPL];
+    float dS[NS];
 #pragma unroll
-    for (int e = 0; e < 4 * CPL; ++e) dS[e] = 0.f;
+    for (int e = 0; e < NS; ++e) dS[e] = 0.f;
 
-    GdrOps<CPL> cur[GDR_CH], nxt[GDR_CH];
-    float ck[4 * CPL], ckN[4 * CPL];
-    auto load_chunk = [&](GdrOps<CPL>(&ops)[GDR_CH], float(&c)[4 * CPL], int chunk) {
-        const int t0 = chunk * GDR_CH;
+    GdrOps<CPL> cur[GDR_SUB], nxt[GDR_SUB];
+    float sub[GDR_NSUB][NS], ckN[NS];
+    auto load_group = [&](GdrOps<CPL>(&ops)[GDR_SUB], int tb) {
 #pragma unroll
-        for (int i = 0; i < GDR_CH; ++i) {
-            const int t = t0 + i < S ? t0 + i : S - 1;  // a ragged last chunk re-reads the last step; the copies are not used
+        for (int i = 0; i < GDR_SUB; ++i) {
+            const int t = tb + i < S ? tb + i : S - 1;  // a ragged last group re-reads the last step; the copies are not used
             gdr_load_ops<CPL>(ops[i], kp + t * ldqk, qp + t * ldqk, vp + t * ldv, gp + (int64_t)t * Hv * Dv, ap + (int64_t)t * Hv, bp + (int64_t)t * Hv);
         }
+    };
+    auto load_ckpt = [&](float(&c)[NS], int chunk) {
         const float* cp = ckp + (int64_t)chunk * Dv * DK;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int j = 0; j < CPL; ++j) c[r * CPL + j] = cp[r * DK + j];
     };
-    load_chunk(cur, ck, nchunk - 1);
+    load_group(cur, (nchunk - 1) * GDR_CH);
+    load_ckpt(sub[0], nchunk - 1);
 
     for (int chunk = nchunk - 1; chunk >= 0; --chunk) {
-        const int t0 = chunk * GDR_CH;
-        const int n = S - t0 < GDR_CH ? S - t0 : GDR_CH;
-        if (chunk > 0) load_chunk(nxt, ckN, chunk - 1);
-        // ---- phase A: replay forward from the checkpoint, park S_{t-1} of each step
+        const int c0 = chunk * GDR_CH;
+        const int n = S - c0 < GDR_CH ? S - c0 : GDR_CH;
+        const int nsub = (n + GDR_SUB - 1) / GDR_SUB;
+        if (chunk > 0) load_ckpt(ckN, chunk - 1);
+        // ---- (1) sub-checkpoints S_4, S_8, S_12: groups 0 .. nsub-2 are complete groups
 #pragma unroll
-        for (int i = 0; i < GDR_CH; ++i) {
-            if (i < n) {
+        for (int s_ = 0; s_ + 1 < GDR_NSUB; ++s_) {
+            if (s_ + 1 < nsub) {
+                load_group(nxt, c0 + (s_ + 1) * GDR_SUB);
 #pragma unroll
-                for (int vi = 0; vi < CPL; ++vi) park[wave][i][vi][lane] = f32x4{ck[4 * vi], ck[4 * vi + 1], ck[4 * vi + 2], ck[4 * vi + 3]};
-                float kf[CPL];
+                for (int e = 0; e < NS; ++e) sub[s_ + 1][e] = sub[s_][e];
 #pragma unroll
-                for (int j = 0; j < CPL; ++j) kf[j] = raw_get<CPL>(cur[i].k, j);
+                for (int i = 0; i < GDR_SUB; ++i) gdr_replay_step<CPL>(sub[s_ + 1], cur[i]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float u = 0.f;
-#pragma unroll
-                    for (int j = 0; j < CPL; ++j) {
-                        ck[r * CPL + j] *= cur[i].a;
-                        u = fmaf(ck[r * CPL + j], kf[j], u);
-                    }
-                    u = lanes_sum<16>(u);
-                    const float c = cur[i].b * (bf2f(cur[i].v[r]) - u);
-#pragma unroll
-                    for (int j = 0; j < CPL; ++j) ck[r * CPL + j] = fmaf(c, kf[j], ck[r * CPL + j]);
-                }
+                for (int i = 0; i < GDR_SUB; ++i) cur[i] = nxt[i];
             }
         }
-        // ---- phase B: reverse walk
+        // ---- groups nsub-1 .. 0: (2) park, (3) reverse
 #pragma unroll
-        for (int i = GDR_CH - 1; i >= 0; --i) {
-            if (i < n) {
-                const int t = t0 + i;
-                float Sp[4 * CPL];
+        for (int s_ = GDR_NSUB - 1; s_ >= 0; --s_) {
+            if (s_ < nsub) {
+                const int t0 = c0 + s_ * GDR_SUB;
+                const int ng = S - t0 < GDR_SUB ? S - t0 : GDR_SUB;
+                if (s_ > 0) load_group(nxt, t0 - GDR_SUB);
+                else if (chunk > 0) load_group(nxt, c0 - GDR_CH);
+                float work[NS];
 #pragma unroll
-                for (int vi = 0; vi < CPL; ++vi) {
-                    const f32x4 x = park[wave][i][vi][lane];
-                    Sp[4 * vi] = x[0];
-                    Sp[4 * vi + 1] = x[1];
-                    Sp[4 * vi + 2] = x[2];
-                    Sp[4 * vi + 3] = x[3];
-                }
-                const GdrOps<CPL>& op = cur[i];
-                float kf[CPL], qf[CPL], pq[CPL], pk[CPL];
+                for (int e = 0; e < NS; ++e) work[e] = sub[s_][e];
 #pragma unroll
-                for (int j = 0; j < CPL; ++j) {
-                    kf[j] = raw_get<CPL>(op.k, j);
-                    qf[j] = raw_get<CPL>(op.q, j);
-                    pq[j] = pk[j] = 0.f;
-                }
-                float dbp = 0.f, dap = 0.f;
-                float dvr[4];
+                for (int i = 0; i < GDR_SUB; ++i) {
+                    if (i < ng) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float G[CPL];
-                    const float gr = bf2f(op.g[r]) * qscale;  // d(o_i)/d(S_ij) = q_j / sqrt(dk)
-                    float u = 0.f;
-#pragma unroll
-                    for (int j = 0; j < CPL; ++j) {
-                        G[j] = Sp[r * CPL + j] * op.a;
-                        u = fmaf(G[j], kf[j], u);
-                    }
-                    u = lanes_sum<16>(u);
-                    const float resid = bf2f(op.v[r]) - u;
-                    const float c = op.b * resid;
-                    float dc = 0.f;
-#pragma unroll
-                    for (int j = 0; j < CPL; ++j) {
-                        const float Sn = fmaf(c, kf[j], G[j]);                      // S_t
-                        dS[r * CPL + j] = fmaf(gr, qf[j], dS[r * CPL + j]);         // dS += do q~^T
-                        pq[j] = fmaf(gr, Sn, pq[j]);                                // dq = S^T do / sqrt(dk)
-                        dc = fmaf(dS[r * CPL + j], kf[j], dc);
-                    }
-                    dc = lanes_sum<16>(dc);
-                    const float du = -op.b * dc;
-                    dbp += dc * resid;
-                    dvr[r] = op.b * dc;
-#pragma unroll
-                    for (int j = 0; j < CPL; ++j) {
-                        pk[j] = fmaf(c, dS[r * CPL + j], fmaf(du, G[j], pk[j]));
-                        const float dG = fmaf(du, kf[j], dS[r * CPL + j]);
-                        dap = fmaf(dG, Sp[r * CPL + j], dap);
-                        dS[r * CPL + j] = op.a * dG;
+                        for (int vi = 0; vi < CPL; ++vi) park[wave][i][vi][lane] = f32x4{work[4 * vi], work[4 * vi + 1], work[4 * vi + 2], work[4 * vi + 3]};
+                        if (i + 1 < ng) gdr_replay_step<CPL>(work, cur[i]);
                     }
                 }
-                // sums over this wave's 16 rows: across the 4 row quads; dap also across the 16 column lanes
-                dap = lanes_sum<16>(dap);
 #pragma unroll
-                for (int j = 0; j < CPL; ++j) {
-                    pq[j] = rows_sum(pq[j]);
-                    pk[j] = rows_sum(pk[j]);
-                }
-                dbp = rows_sum(dbp);
-                dap = rows_sum(dap);
-                if (rq == 0) {
+                for (int i = GDR_SUB - 1; i >= 0; --i) {
+                    if (i < ng) {
+                        const int t = t0 + i;
+                        float Sp[NS];
 #pragma unroll
-                    for (int j = 0; j < CPL; ++j) {
-                        wq[(int64_t)t * DK + j] = pq[j];
-                        wk[(int64_t)t * DK + j] = pk[j];
+                        for (int vi = 0; vi < CPL; ++vi) {
+                            const f32x4 x = park[wave][i][vi][lane];
+                            Sp[4 * vi] = x[0];
+                            Sp[4 * vi + 1] = x[1];
+                            Sp[4 * vi + 2] = x[2];
+                            Sp[4 * vi + 3] = x[3];
+                        }
+                        const GdrOps<CPL>& op = cur[i];
+                        float kf[CPL], qf[CPL], pq[CPL], pk[CPL];
+#pragma unroll
+                        for (int j = 0; j < CPL; ++j) {
+                            kf[j] = raw_get<CPL>(op.k, j);
+                            qf[j] = raw_get<CPL>(op.q, j);
+                            pq[j] = pk[j] = 0.f;
+                        }
+                        float dbp = 0.f, dap = 0.f;
+                        float dvr[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float G[CPL];
+                            const float gr = bf2f(op.g[r]) * qscale;  // d(o_i)/d(S_ij) = q_j / sqrt(dk)
+                            float u = 0.f;
+#pragma unroll
+                            for (int j = 0; j < CPL; ++j) {
+                                G[j] = Sp[r * CPL + j] * op.a;
+                                u = fmaf(G[j], kf[j], u);
+                            }
+                            u = lanes_sum<16>(u);
+                            const float resid = bf2f(op.v[r]) - u;
+                            const float c = op.b * resid;
+                            float dc = 0.f;
+#pragma unroll
+                            for (int j = 0; j < CPL; ++j) {
+                                const float Sn = fmaf(c, kf[j], G[j]);                      // S_t
+                                dS[r * CPL + j] = fmaf(gr, qf[j], dS[r * CPL + j]);         // dS += do q~^T
+                                pq[j] = fmaf(gr, Sn, pq[j]);                                // dq = S^T do / sqrt(dk)
+                                dc = fmaf(dS[r * CPL + j], kf[j], dc);
+                            }
+                            dc = lanes_sum<16>(dc);
+                            const float du = -op.b * dc;
+                            dbp += dc * resid;
+                            dvr[r] = op.b * dc;
+#pragma unroll
+                            for (int j = 0; j < CPL; ++j) {
+                                pk[j] = fmaf(c, dS[r * CPL + j], fmaf(du, G[j], pk[j]));
+                                const float dG = fmaf(du, kf[j], dS[r * CPL + j]);
+                                dap = fmaf(dG, Sp[r * CPL + j], dap);
+                                dS[r * CPL + j] = op.a * dG;
+                            }
+                        }
+                        // sums over this wave's 16 rows: across the 4 row quads; dap also across the 16 column lanes
+                        dap = lanes_sum<16>(dap);
+#pragma unroll
+                        for (int j = 0; j < CPL; ++j) {
+                            pq[j] = rows_sum(pq[j]);
+                            pk[j] = rows_sum(pk[j]);
+                        }
+                        dbp = rows_sum(dbp);
+                        dap = rows_sum(dap);
+                        if (rq == 0) {
+#pragma unroll
+                            for (int j = 0; j < CPL; ++j) {
+                                wq[(int64_t)t * DK + j] = pq[j];
+                                wk[(int64_t)t * DK + j] = pk[j];
+                            }
+                        }
+                        if (lane == 0) {
+                            pdb[slot * S + t] = dbp;
+                            pda[slot * S + t] = dap;
+                        }
+                        if (cl == 0) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) dv[(tok0 + t) * lddv + (int64_t)h * Dv + row + r] = f2bf(dvr[r]);
+                        }
                     }
                 }
-                if (lane == 0) {
-                    pdb[slot * S + t] = dbp;
-                    pda[slot * S + t] = dap;
-                }
-                if (cl == 0) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dv[(tok0 + t) * lddv + (int64_t)h * Dv + row + r] = f2bf(dvr[r]);
-                }
+                for (int i = 0; i < GDR_SUB; ++i) cur[i] = nxt[i];
             }
         }
 #pragma unroll
-        for (int i = 0; i < GDR_CH; ++i) cur[i] = nxt[i];
-#pragma unroll
-        for (int e = 0; e < 4 * CPL; ++e) ck[e] = ckN[e];
+        for (int e = 0; e < NS; ++e) sub[0][e] = ckN[e];
     }
 }
 
