@@ -584,61 +584,79 @@ __global__ __launch_bounds__(256) void gdr_fwd_kernel(int B, int S, int Hqk, int
     const float* ap = alpha + tok0 * Hv + h;
     const float* bp = beta + tok0 * Hv + h;
     bf16_t* op = o + tok0 * Hv * Dv + (int64_t)h * Dv + row;
-    float st[CPL];
+    static_assert(CPL % 2 == 0, "forward: an even number of columns per lane (packed f32 math)");
+    constexpr int CP2 = CPL / 2;
+    f32x2 st[CP2];
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) st[j] = 0.f;
+    for (int j = 0; j < CP2; ++j) st[j] = f32x2{0.f, 0.f};
     if (initial_state) {  // decode / continued prefill: the recurrent state of Qwen3_5Cache (may alias final_state: each lane reads, then writes, its own slice)
         const float* c = initial_state + (((int64_t)b * Hv + h) * Dv + row) * DK + cg * CPL;
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) st[j] = c[j];
+        for (int j = 0; j < CP2; ++j) st[j] = f32x2{c[2 * j], c[2 * j + 1]};
     }
-    RawVec<CPL> kc, qc, kn, qn;
-    float a_c, b_c, a_n = 0.f, b_n = 0.f;
-    bf16_t v_c, v_n = 0;
-    raw_load<CPL>(kc, kp);
-    raw_load<CPL>(qc, qp);
-    a_c = ap[0];
-    b_c = bp[0];
-    v_c = vp[0];
-    for (int t = 0; t < S; ++t) {
-        if (t + 1 < S) {
-            raw_load<CPL>(kn, kp + (t + 1) * ldqk);
-            raw_load<CPL>(qn, qp + (t + 1) * ldqk);
-            a_n = ap[(int64_t)(t + 1) * Hv];
-            b_n = bp[(int64_t)(t + 1) * Hv];
-            v_n = vp[(t + 1) * ldv];
-        }
+    struct In {
+        RawVec<CPL> k, q;
+        float a, b;
+        bf16_t v;
+    };
+    auto load_in = [&](In& in, int t) {
+        raw_load<CPL>(in.k, kp + t * ldqk);
+        raw_load<CPL>(in.q, qp + t * ldqk);
+        in.a = ap[(int64_t)t * Hv];
+        in.b = bp[(int64_t)t * Hv];
+        in.v = vp[t * ldv];
+    };
+    // one time step on packed pairs (v_pk_mul / v_pk_fma): both dot products run on two partial sums, one per half of a bf16 pair
+    auto step = [&](const In& in, int t) {
         if (ckpt && t % CH == 0) {
             float* c = ckpt + ((((int64_t)b * Hv + h) * nchunk + t / CH) * Dv + row) * DK + cg * CPL;
 #pragma unroll
-            for (int j = 0; j < CPL; ++j) c[j] = st[j];
+            for (int j = 0; j < CP2; ++j) {
+                c[2 * j] = st[j][0];
+                c[2 * j + 1] = st[j][1];
+            }
         }
-        float u = 0.f;
+        const f32x2 a2 = {in.a, in.a};
+        f32x2 u2 = {0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-            st[j] *= a_c;
-            u = fmaf(st[j], raw_get<CPL>(kc, j), u);
+        for (int j = 0; j < CP2; ++j) {
+            const f32x2 k2 = {__uint_as_float(in.k.w[j] << 16), __uint_as_float(in.k.w[j] & 0xffff0000u)};
+            st[j] = st[j] * a2;
+            u2 = __builtin_elementwise_fma(st[j], k2, u2);
         }
-        u = lanes_sum<LPR>(u);
-        const float c = b_c * (bf2f(v_c) - u);
-        float oo = 0.f;
+        const float u = lanes_sum<LPR>(u2[0] + u2[1]);
+        const float c = in.b * (bf2f(in.v) - u);
+        const f32x2 c2 = {c, c};
+        f32x2 o2 = {0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-            st[j] = fmaf(c, raw_get<CPL>(kc, j), st[j]);
-            oo = fmaf(st[j], raw_get<CPL>(qc, j), oo);
+        for (int j = 0; j < CP2; ++j) {
+            const f32x2 k2 = {__uint_as_float(in.k.w[j] << 16), __uint_as_float(in.k.w[j] & 0xffff0000u)};
+            const f32x2 q2 = {__uint_as_float(in.q.w[j] << 16), __uint_as_float(in.q.w[j] & 0xffff0000u)};
+            st[j] = __builtin_elementwise_fma(c2, k2, st[j]);
+            o2 = __builtin_elementwise_fma(st[j], q2, o2);
         }
-        oo = lanes_sum<LPR>(oo);
+        const float oo = lanes_sum<LPR>(o2[0] + o2[1]);
         if (cg == 0) op[(int64_t)t * Hv * Dv] = f2bf(oo * qscale);
-        kc = kn;
-        qc = qn;
-        a_c = a_n;
-        b_c = b_n;
-        v_c = v_n;
+    };
+    // two operand sets in ping-pong (the loop is unrolled by two, so no set is ever copied): the operands of step t+1 are requested
+    // as RAW bf16 words before step t's arithmetic and unpacked only when used
+    In inA, inB;
+    load_in(inA, 0);
+    for (int t = 0; t < S; t += 2) {
+        if (t + 1 < S) load_in(inB, t + 1);
+        step(inA, t);
+        if (t + 1 < S) {
+            if (t + 2 < S) load_in(inA, t + 2);
+            step(inB, t + 1);
+        }
     }
     if (final_state) {
         float* c = final_state + (((int64_t)b * Hv + h) * Dv + row) * DK + cg * CPL;
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) c[j] = st[j];
+        for (int j = 0; j < CP2; ++j) {
+            c[2 * j] = st[j][0];
+            c[2 * j + 1] = st[j][1];
+        }
     }
 }
 
