@@ -66,6 +66,33 @@ __device__ __forceinline__ float rows_sum(float v) {
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// Reduce-scatter over the wave's four 16-lane rows: ONE swap + ONE add folds TWO values across a row pair (v_permlane16_swap
+// exchanges the odd rows of its first operand with the even rows of its second): afterwards even rows hold sum(a), odd rows sum(b)
+// of their pair.  rows_fold32 does the same across the lower / upper half of the wave.
+__device__ __forceinline__ float rows_fold16(float a, float b) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float rows_fold32(float a, float b) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// dot product of two register vectors on two partial sums (packed f32 FMAs instead of one serial chain)
+template <int N>
+__device__ __forceinline__ float dot_pk(const float* __restrict__ x, const float (&y)[N]) {
+    if constexpr (N % 2 == 0) {
+        f32x2 acc = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < N; j += 2) acc = __builtin_elementwise_fma(f32x2{x[j], x[j + 1]}, f32x2{y[j], y[j + 1]}, acc);
+        return acc[0] + acc[1];
+    } else {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc = fmaf(x[j], y[j], acc);
+        return acc;
+    }
+}
+
 // ------------------------------------------------------------------------------------------- small helpers
 __global__ void zc_weight_kernel(int64_t n, const bf16_t* __restrict__ s, bf16_t* __restrict__ w) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -694,13 +721,9 @@ __device__ __forceinline__ void gdr_replay_step(float (&st)[4 * CPL], const GdrO
     for (int j = 0; j < CPL; ++j) kf[j] = raw_get<CPL>(op.k, j);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        float u = 0.f;
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-            st[r * CPL + j] *= op.a;
-            u = fmaf(st[r * CPL + j], kf[j], u);
-        }
-        u = lanes_sum<16>(u);
+        for (int j = 0; j < CPL; ++j) st[r * CPL + j] *= op.a;
+        const float u = lanes_sum<16>(dot_pk<CPL>(&st[r * CPL], kf));
         const float c = op.b * (bf2f(op.v[r]) - u);
 #pragma unroll
         for (int j = 0; j < CPL; ++j) st[r * CPL + j] = fmaf(c, kf[j], st[r * CPL + j]);
@@ -829,56 +852,55 @@ __global__ __launch_bounds__(256) void gdr_bwd_kernel(int B, int S, int Hqk, int
                         float dvr[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            float G[CPL];
+                            float G[CPL], dGv[CPL];
                             const float gr = bf2f(op.g[r]) * qscale;  // d(o_i)/d(S_ij) = q_j / sqrt(dk)
-                            float u = 0.f;
 #pragma unroll
-                            for (int j = 0; j < CPL; ++j) {
-                                G[j] = Sp[r * CPL + j] * op.a;
-                                u = fmaf(G[j], kf[j], u);
-                            }
-                            u = lanes_sum<16>(u);
+                            for (int j = 0; j < CPL; ++j) G[j] = Sp[r * CPL + j] * op.a;
+                            const float u = lanes_sum<16>(dot_pk<CPL>(G, kf));
                             const float resid = bf2f(op.v[r]) - u;
                             const float c = op.b * resid;
-                            float dc = 0.f;
 #pragma unroll
                             for (int j = 0; j < CPL; ++j) {
                                 const float Sn = fmaf(c, kf[j], G[j]);                      // S_t
                                 dS[r * CPL + j] = fmaf(gr, qf[j], dS[r * CPL + j]);         // dS += do q~^T
                                 pq[j] = fmaf(gr, Sn, pq[j]);                                // dq = S^T do / sqrt(dk)
-                                dc = fmaf(dS[r * CPL + j], kf[j], dc);
                             }
-                            dc = lanes_sum<16>(dc);
+                            const float dc = lanes_sum<16>(dot_pk<CPL>(&dS[r * CPL], kf));
                             const float du = -op.b * dc;
                             dbp += dc * resid;
                             dvr[r] = op.b * dc;
 #pragma unroll
                             for (int j = 0; j < CPL; ++j) {
                                 pk[j] = fmaf(c, dS[r * CPL + j], fmaf(du, G[j], pk[j]));
-                                const float dG = fmaf(du, kf[j], dS[r * CPL + j]);
-                                dap = fmaf(dG, Sp[r * CPL + j], dap);
-                                dS[r * CPL + j] = op.a * dG;
+                                dGv[j] = fmaf(du, kf[j], dS[r * CPL + j]);
+                                dS[r * CPL + j] = op.a * dGv[j];
                             }
+                            dap += dot_pk<CPL>(&Sp[r * CPL], dGv);
                         }
-                        // sums over this wave's 16 rows: across the 4 row quads; dap also across the 16 column lanes
+                        // sums over this wave's 16 rows (4 row quads) as a reduce-scatter: pq_j pairs with pk_j across the row pairs, then the
+                        // halves pair up: quad 0 ends with the totals of pq[0 .. CPL/2), quad 1 pk[0 .. CPL/2), quad 2 pq[CPL/2 ..), quad 3 pk[CPL/2 ..)
                         dap = lanes_sum<16>(dap);
+                        {
+                            float z[CPL];
 #pragma unroll
-                        for (int j = 0; j < CPL; ++j) {
-                            pq[j] = rows_sum(pq[j]);
-                            pk[j] = rows_sum(pk[j]);
-                        }
-                        dbp = rows_sum(dbp);
-                        dap = rows_sum(dap);
-                        if (rq == 0) {
+                            for (int j = 0; j < CPL; ++j) z[j] = rows_fold16(pq[j], pk[j]);
+                            float* dst = (rq & 1) ? wk : wq;
+                            if constexpr (CPL >= 2) {
+                                constexpr int H = CPL / 2;
+                                float w_[H];
 #pragma unroll
-                            for (int j = 0; j < CPL; ++j) {
-                                wq[(int64_t)t * DK + j] = pq[j];
-                                wk[(int64_t)t * DK + j] = pk[j];
+                                for (int j = 0; j < H; ++j) w_[j] = rows_fold32(z[j], z[j + H]);
+                                const int off = (rq >> 1) * H;
+#pragma unroll
+                                for (int j = 0; j < H; ++j) dst[(int64_t)t * DK + off + j] = w_[j];
+                            } else {
+                                const float w_ = rows_fold32(z[0], z[0]);
+                                if (rq < 2) dst[(int64_t)t * DK] = w_;
                             }
-                        }
-                        if (lane == 0) {
-                            pdb[slot * S + t] = dbp;
-                            pda[slot * S + t] = dap;
+                            const float sc = rows_fold16(dbp, dap);   // even quads: dbp of the pair, odd quads: dap
+                            const float tot = rows_fold32(sc, sc);
+                            if (lane == 0) pdb[slot * S + t] = tot;
+                            if (lane == 16) pda[slot * S + t] = tot;
                         }
                         if (cl == 0) {
 #pragma unroll
