@@ -850,32 +850,93 @@ __global__ __launch_bounds__(256) void gdr_bwd_kernel(int B, int S, int Hqk, int
                         }
                         float dbp = 0.f, dap = 0.f;
                         float dvr[4];
+                        if constexpr (CPL % 2 == 0) {  // packed pairs over the columns (v_pk_mul / v_pk_fma), explicit: the SLP vectoriser packs only part of it
+                            constexpr int P = CPL / 2;
+                            f32x2 k2[P], q2[P], pq2[P], pk2[P];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float G[CPL], dGv[CPL];
-                            const float gr = bf2f(op.g[r]) * qscale;  // d(o_i)/d(S_ij) = q_j / sqrt(dk)
-#pragma unroll
-                            for (int j = 0; j < CPL; ++j) G[j] = Sp[r * CPL + j] * op.a;
-                            const float u = lanes_sum<16>(dot_pk<CPL>(G, kf));
-                            const float resid = bf2f(op.v[r]) - u;
-                            const float c = op.b * resid;
-#pragma unroll
-                            for (int j = 0; j < CPL; ++j) {
-                                const float Sn = fmaf(c, kf[j], G[j]);                      // S_t
-                                dS[r * CPL + j] = fmaf(gr, qf[j], dS[r * CPL + j]);         // dS += do q~^T
-                                pq[j] = fmaf(gr, Sn, pq[j]);                                // dq = S^T do / sqrt(dk)
+                            for (int j = 0; j < P; ++j) {
+                                k2[j] = f32x2{kf[2 * j], kf[2 * j + 1]};
+                                q2[j] = f32x2{qf[2 * j], qf[2 * j + 1]};
+                                pq2[j] = pk2[j] = f32x2{0.f, 0.f};
                             }
-                            const float dc = lanes_sum<16>(dot_pk<CPL>(&dS[r * CPL], kf));
-                            const float du = -op.b * dc;
-                            dbp += dc * resid;
-                            dvr[r] = op.b * dc;
+                            const f32x2 a2 = {op.a, op.a};
+                            f32x2 dap2 = {0.f, 0.f};
 #pragma unroll
-                            for (int j = 0; j < CPL; ++j) {
-                                pk[j] = fmaf(c, dS[r * CPL + j], fmaf(du, G[j], pk[j]));
-                                dGv[j] = fmaf(du, kf[j], dS[r * CPL + j]);
-                                dS[r * CPL + j] = op.a * dGv[j];
+                            for (int r = 0; r < 4; ++r) {
+                                f32x2 G2[P], Sp2[P], d2[P];
+                                const float gr = bf2f(op.g[r]) * qscale;  // d(o_i)/d(S_ij) = q_j / sqrt(dk)
+                                const f32x2 gr2 = {gr, gr};
+                                f32x2 acc = {0.f, 0.f};
+#pragma unroll
+                                for (int j = 0; j < P; ++j) {
+                                    Sp2[j] = f32x2{Sp[r * CPL + 2 * j], Sp[r * CPL + 2 * j + 1]};
+                                    d2[j] = f32x2{dS[r * CPL + 2 * j], dS[r * CPL + 2 * j + 1]};
+                                    G2[j] = Sp2[j] * a2;
+                                    acc = __builtin_elementwise_fma(G2[j], k2[j], acc);
+                                }
+                                const float u = lanes_sum<16>(acc[0] + acc[1]);
+                                const float resid = bf2f(op.v[r]) - u;
+                                const float c = op.b * resid;
+                                const f32x2 c2 = {c, c};
+                                acc = f32x2{0.f, 0.f};
+#pragma unroll
+                                for (int j = 0; j < P; ++j) {
+                                    const f32x2 Sn = __builtin_elementwise_fma(c2, k2[j], G2[j]);   // S_t
+                                    d2[j] = __builtin_elementwise_fma(gr2, q2[j], d2[j]);           // dS += do q~^T
+                                    pq2[j] = __builtin_elementwise_fma(gr2, Sn, pq2[j]);            // dq = S^T do / sqrt(dk)
+                                    acc = __builtin_elementwise_fma(d2[j], k2[j], acc);
+                                }
+                                const float dc = lanes_sum<16>(acc[0] + acc[1]);
+                                const float du = -op.b * dc;
+                                const f32x2 du2 = {du, du};
+                                dbp += dc * resid;
+                                dvr[r] = op.b * dc;
+#pragma unroll
+                                for (int j = 0; j < P; ++j) {
+                                    pk2[j] = __builtin_elementwise_fma(c2, d2[j], __builtin_elementwise_fma(du2, G2[j], pk2[j]));
+                                    const f32x2 dG = __builtin_elementwise_fma(du2, k2[j], d2[j]);
+                                    dap2 = __builtin_elementwise_fma(dG, Sp2[j], dap2);
+                                    const f32x2 nd = a2 * dG;
+                                    dS[r * CPL + 2 * j] = nd[0];
+                                    dS[r * CPL + 2 * j + 1] = nd[1];
+                                }
                             }
-                            dap += dot_pk<CPL>(&Sp[r * CPL], dGv);
+                            dap = dap2[0] + dap2[1];
+#pragma unroll
+                            for (int j = 0; j < P; ++j) {
+                                pq[2 * j] = pq2[j][0];
+                                pq[2 * j + 1] = pq2[j][1];
+                                pk[2 * j] = pk2[j][0];
+                                pk[2 * j + 1] = pk2[j][1];
+                            }
+                        } else {
+    #pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float G[CPL], dGv[CPL];
+                                const float gr = bf2f(op.g[r]) * qscale;  // d(o_i)/d(S_ij) = q_j / sqrt(dk)
+    #pragma unroll
+                                for (int j = 0; j < CPL; ++j) G[j] = Sp[r * CPL + j] * op.a;
+                                const float u = lanes_sum<16>(dot_pk<CPL>(G, kf));
+                                const float resid = bf2f(op.v[r]) - u;
+                                const float c = op.b * resid;
+    #pragma unroll
+                                for (int j = 0; j < CPL; ++j) {
+                                    const float Sn = fmaf(c, kf[j], G[j]);                      // S_t
+                                    dS[r * CPL + j] = fmaf(gr, qf[j], dS[r * CPL + j]);         // dS += do q~^T
+                                    pq[j] = fmaf(gr, Sn, pq[j]);                                // dq = S^T do / sqrt(dk)
+                                }
+                                const float dc = lanes_sum<16>(dot_pk<CPL>(&dS[r * CPL], kf));
+                                const float du = -op.b * dc;
+                                dbp += dc * resid;
+                                dvr[r] = op.b * dc;
+    #pragma unroll
+                                for (int j = 0; j < CPL; ++j) {
+                                    pk[j] = fmaf(c, dS[r * CPL + j], fmaf(du, G[j], pk[j]));
+                                    dGv[j] = fmaf(du, kf[j], dS[r * CPL + j]);
+                                    dS[r * CPL + j] = op.a * dGv[j];
+                                }
+                                dap += dot_pk<CPL>(&Sp[r * CPL], dGv);
+                            }
                         }
                         // sums over this wave's 16 rows (4 row quads) as a reduce-scatter: pq_j pairs with pk_j across the row pairs, then the
                         // halves pair up: quad 0 ends with the totals of pq[0 .. CPL/2), quad 1 pk[0 .. CPL/2), quad 2 pq[CPL/2 ..), quad 3 pk[CPL/2 ..)
