@@ -139,6 +139,16 @@ def pmc_traffic():
         return None
 
 
+def pmc_step_traffic():
+    """Whole-step TCC counters (profiles/r01_pmc_tcc_step.json), collected with rocprofv3 --pmc over this script."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_tcc_step.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
 def dominant_kernel_rate(batch, device):
     """HIP-event timing of the step's dominant kernel class (gemm_bf16_kernel) on its largest shapes, on the stream the
     kernels are launched on (torch's current stream)."""
@@ -253,12 +263,14 @@ def main():
         if world == 1:
             line["roofline"]["dominant_kernel"] = {"name": "gemm_bf16_kernel", "hip_event_timing": dominant_kernel_rate(args.batch, device)}
             pmc = pmc_traffic()
+            step_pmc = pmc_step_traffic()
             if pmc is not None and args.batch == 64:  # the PMC passes were taken at this batch's shapes
-                line["roofline"]["traffic"] = pmc["NT"]["hbm_bytes"]
+                line["roofline"]["traffic"] = step_pmc["per_step"]["total_bytes"] if step_pmc else pmc["NT"]["hbm_bytes"]
                 line["roofline"]["traffic_note"] = (
-                    "bytes per launch of the dominant kernel (gemm_bf16_kernel, NT gate-up forward at this batch): 2 x FETCH_SIZE (gfx950 correction) "
-                    f"+ WRITE_SIZE from separate rocprofv3 --pmc passes (profiles/r01_pmc_tcc_gemm.json), {pmc['NT']['over_algorithmic']}x its algorithmic "
-                    "bytes; Infinity-Cache hits are counted in FETCH_SIZE, the kernel is MFMA-bound")
+                    "memory-side bytes PER STEP (like `achieved`): 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE summed over every kernel of one step, separate "
+                    "rocprofv3 --pmc passes over this bench (profiles/r01_pmc_tcc_step.json, per-kernel table inside); Infinity-Cache hits are counted in "
+                    "FETCH_SIZE; the dominant kernel alone (gemm_bf16_kernel NT gate-up forward) moves "
+                    f"{pmc['NT']['hbm_bytes']} bytes per launch = {pmc['NT']['over_algorithmic']}x its algorithmic bytes (profiles/r01_pmc_tcc_gemm.json) and is MFMA-bound")
                 line["roofline"]["dominant_kernel"]["pmc_bytes_per_launch"] = {f: pmc[f]["hbm_bytes"] for f in ("NT", "NN", "TN")}
                 line["roofline"]["dominant_kernel"]["algorithmic_bytes_per_launch"] = {
                     f: pmc[f]["algorithmic_read_bytes"] + pmc[f]["algorithmic_write_bytes"] for f in ("NT", "NN", "TN")}

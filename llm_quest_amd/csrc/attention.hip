@@ -279,6 +279,14 @@ __device__ __forceinline__ float owned_read() {
 __device__ __forceinline__ int acc_row(int e, int lane) { return (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); }
 
 // ================================================================================================ forward
+// position b of a round-robin-over-XCDs numbering -> position in a numbering where each XCD owns one contiguous chunk: workgroups
+// with adjacent VIRTUAL ids (the query blocks of one head, the two query heads of one kv head) then share an XCD and its L2, so
+// that K / V of a (batch, kv head) come over the fabric once per XCD instead of once per workgroup (FETCH_SIZE, profiles/).
+__device__ __forceinline__ int xcd_chunked(int b, int n) {
+    const int xcd = b & 7, q = n >> 3, r = n & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
 template <int D>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int B, int S, int Hq, int Hkv, const bf16_t* __restrict__ q, int64_t ldq,
                                                           const bf16_t* __restrict__ k, int64_t ldk, const bf16_t* __restrict__ v,
@@ -292,8 +300,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int B, int S, int Hq, 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nqb = (S + 127) / 128;
     // heaviest (latest) query blocks first under the causal mask
-    const int qb = nqb - 1 - (int)(blockIdx.x % nqb);
-    const int bh = blockIdx.x / nqb;
+    const int vid = (abl >> 8) & 1 ? (int)blockIdx.x : xcd_chunked((int)blockIdx.x, (int)gridDim.x);  // ablation bit 8: plain order
+    const int qb = nqb - 1 - (vid % nqb);
+    const int bh = vid / nqb;
     const int hq = bh % Hq, b = bh / Hq;
     const int hkv = hq / (Hq / Hkv);
     const int q0 = qb * 128;
@@ -497,9 +506,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(int B, int S, int H
     unsigned long long* kmw = reinterpret_cast<unsigned long long*>(smem + NST * STAGE);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // one workgroup = `bpw` consecutive 128-query blocks of one (batch, head), heaviest (latest) first
+    // one workgroup = `bpw` consecutive 128-query blocks of one (batch, head), heaviest (latest) first; adjacent virtual ids (the
+    // chunks of a head, the two query heads of a kv head) share an XCD
     const int nqb = (S + 127) / 128, nchunk = (nqb + bpw - 1) / bpw;
-    const int chunk = blockIdx.x % nchunk, bh = blockIdx.x / nchunk;
+    const int vid = (abl >> 8) & 1 ? (int)blockIdx.x : xcd_chunked((int)blockIdx.x, (int)gridDim.x);
+    const int chunk = vid % nchunk, bh = vid / nchunk;
     const int hq = bh % Hq, b = bh / Hq;
     const int hkv = hq / (Hq / Hkv);
     const int qb_hi = nqb - chunk * bpw, qb_lo = max(0, qb_hi - bpw);
