@@ -753,7 +753,11 @@ extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const 
         // per form, 246.2 ms/step with tile 3 everywhere vs +0.9 (NT) / +4.3 (NN) / +0.5 (TN) ms with tile 4.  The step decides.
         // The same A/B puts the forward projections (NT) on tile 2 (BK 64, two stages, fragments prefetched one phase ahead):
         // 239.3 vs 243.8-246 ms/step with NT on tile 3, although tile 3 is 10-20 % faster on every isolated NT shape.
+        // 256x256 tiles need at least half of the 256 CUs' worth of tiles; below that (small token counts: config 5 at B = 8 has 92 tiles for
+        // its N = 1024 outputs) four times as many 128x128 tiles, two workgroups per CU, fill the chip instead
+        const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
         if (M < 256 || N < 256) cfg = 1;
+        else if (form != MI355_GEMM_TN && tiles256 < 128) cfg = 1;  // measured: 92 tiles -> 128x128 wins (+2.8 % on the config-5 step), 180 tiles -> 256x256 wins
         else if (form == MI355_GEMM_TN) cfg = (M * N > 5 * 1024 * 1024) ? 3 : 1;
         else if (form == MI355_GEMM_NT) cfg = 2;
         else cfg = 3;
