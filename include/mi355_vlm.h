@@ -38,6 +38,10 @@ extern "C" {
 /* epilogue flags */
 #define MI355_EPI_NONE 0
 #define MI355_EPI_GELU_ERF 1 /* out = gelu(acc + bias) (applied before the residual add) */
+/* SwiGLU backward fused into the dgrad of lin2 (qwen3_transformer_block.py:48-53): acc = d(act) [M, N]; `residual` = the forward's
+ * gate-up output [u | g] [M, 2N] (ldr >= 2N); C = d(gate-up) [M, 2N] (ldc >= 2N) = [acc g sig(g) | acc u sig(g) (1 + g (1 - sig(g)))].
+ * Replaces mi355_swiglu_bwd and the d(act) round trip through HBM; bit-identical to the two-kernel form. */
+#define MI355_EPI_SWIGLU_BWD 2
 
 const char* mi355_last_error(void);
 int mi355_abi_version(void);

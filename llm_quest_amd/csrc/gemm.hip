@@ -506,6 +506,35 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
                     if constexpr (OUT_DT == MI355_DT_BF16) {
                         bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + gm * p.ldc + gn;
                         const bf16_t* r = p.R ? reinterpret_cast<const bf16_t*>(p.R) + gm * p.ldr + gn : nullptr;
+                        if (p.epilogue == MI355_EPI_SWIGLU_BWD) {
+                            // acc = d(act) for hidden units gn..gn+7; R = the forward's gate-up output [u | g] (ldr = 2N): write
+                            // d(gate-up) = [acc * g*sig(g) | acc * u * sig(g) (1 + g (1 - sig(g)))] into C (ldc = 2N).  acc is rounded to
+                            // bf16 first, so the result equals mi355_swiglu_bwd on the stored bf16 d(act) bit for bit.
+                            const u32x4 uv = *reinterpret_cast<const u32x4*>(r);
+                            const u32x4 gv = *reinterpret_cast<const u32x4*>(r + p.N);
+                            float du[8], dg[8];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                                for (int hlf = 0; hlf < 2; ++hlf) {
+                                    const float u_ = hlf ? __uint_as_float(uv[e] & 0xffff0000u) : __uint_as_float(uv[e] << 16);
+                                    const float g_ = hlf ? __uint_as_float(gv[e] & 0xffff0000u) : __uint_as_float(gv[e] << 16);
+                                    const float d_ = bf2f(f2bf(v[2 * e + hlf]));
+                                    const float sg = 1.0f / (1.0f + __expf(-g_));
+                                    du[2 * e + hlf] = d_ * g_ * sg;
+                                    dg[2 * e + hlf] = d_ * u_ * sg * (1.0f + g_ * (1.0f - sg));
+                                }
+                            }
+                            u32x4 o0, o1;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                o0[e] = pack_bf2(du[2 * e], du[2 * e + 1]);
+                                o1[e] = pack_bf2(dg[2 * e], dg[2 * e + 1]);
+                            }
+                            *reinterpret_cast<u32x4*>(c) = o0;
+                            *reinterpret_cast<u32x4*>(c + p.N) = o1;
+                            continue;
+                        }
                         if (vec_ok) {
                             if (r) {
                                 const u32x4 rv = *reinterpret_cast<const u32x4*>(r);
@@ -735,6 +764,11 @@ extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const 
     MI355_REQUIRE(out_dtype == MI355_DT_BF16 || out_dtype == MI355_DT_F32, "mi355_gemm_bf16: bad out_dtype");
     if (int rc = check_operands("mi355_gemm_bf16", form, M, N, K, A, lda, B, ldb, C)) return rc;
     MI355_REQUIRE(workspace == nullptr || ((uintptr_t)workspace & 15) == 0, "mi355_gemm_bf16: workspace must be 16-byte aligned");
+    MI355_REQUIRE(epilogue == MI355_EPI_NONE || epilogue == MI355_EPI_GELU_ERF || epilogue == MI355_EPI_SWIGLU_BWD, "mi355_gemm_bf16: unknown epilogue %d", epilogue);
+    if (epilogue == MI355_EPI_SWIGLU_BWD)
+        MI355_REQUIRE(out_dtype == MI355_DT_BF16 && residual && !bias && (N & 7) == 0 && ldc >= 2 * N && ldr >= 2 * N && (ldc & 7) == 0 && (ldr & 7) == 0 &&
+                          (((uintptr_t)residual | (uintptr_t)C) & 15) == 0,
+                      "mi355_gemm_bf16(SwiGLU backward epilogue): bf16 output [M, 2N] (ldc >= 2N), residual = the forward gate-up output [M, 2N], N %% 8 == 0, no bias");
     const int ablate = tile_hint >> 8;
     tile_hint &= 0xff;
     MI355_REQUIRE(tile_hint >= 0 && tile_hint <= 4, "mi355_gemm_bf16: tile_hint must be 0 (auto), 1 (128x128), 2 (256x256), 3 (256x256, alternating wave groups) or 4 (3 with one barrier per phase)");

@@ -112,6 +112,22 @@ def gemm_grouped(form, problems, tile=0):
     L.call("mi355_gemm_bf16_grouped", form, len(problems), _c.cast(table, _c.c_void_p), L.dt_code(odt), tile or _TILE_BY_FORM[form] or (_TILE_OVERRIDE if _TILE_OVERRIDE in (1, 3, 4) else 0))
 
 
+def gemm_dgrad_swiglu_bwd(dy, w, gu, tile=0):
+    """d(gate-up) [M, 2F] of a SwiGLU FFN in ONE launch: d(act) = dy @ w (NN, w = lin2.weight [N_out, F]) stays in the accumulators and the
+    activation's backward runs in the epilogue against ``gu`` = the forward's [lin1 | lin_gate] output (replaces gemm + swiglu_bwd)."""
+    L.require_gpu(dy, w, gu)
+    _rowmajor(dy, "dY")
+    _rowmajor(w, "W")
+    M, Kd = dy.shape
+    F = w.shape[1]
+    if dy.dtype != BF16 or w.dtype != BF16 or gu.dtype != BF16 or w.shape[0] != Kd or not gu.is_contiguous() or tuple(gu.shape) != (M, 2 * F):
+        raise ValueError("gemm_dgrad_swiglu_bwd: dY [M, N_out], W [N_out, F], gate-up output contiguous [M, 2F], all bf16")
+    out = torch.empty_like(gu)
+    L.call("mi355_gemm_bf16", L.GEMM_NN, M, F, Kd, L.ptr(dy), dy.stride(0), L.ptr(w), w.stride(0), L.ptr(out), out.stride(0), L.DT_BF16, None,
+           L.ptr(gu), gu.stride(0), L.EPI_SWIGLU_BWD, None, 0, tile or _TILE_BY_FORM[L.GEMM_NN] or _TILE_OVERRIDE)
+    return out
+
+
 def colsum(x, out=None, accumulate=False):
     """out[n] (+)= sum_m x[m, n]; x bf16 or fp32 (row-strided views allowed), out fp32."""
     L.require_gpu(x, out)

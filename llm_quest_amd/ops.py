@@ -35,6 +35,7 @@ def arena_for(module):
     return ar
 
 
+FUSE_SWIGLU_BWD = os.environ.get("MI355_FUSE_SWIGLU_BWD", "1") != "0"  # 0: separate dgrad GEMM + swiglu_bwd kernels (A/B measurements)
 GROUP_WGRADS = os.environ.get("MI355_GROUP_WGRADS", "1") != "0"  # 0: one launch per weight gradient (A/B measurements)
 
 
@@ -154,10 +155,11 @@ def block_backward(blk, saved, dx3, rt):
     x, h1, rstd1, ctx, att_saved, x2, h2, rstd2, gu, a = saved
     wg = []  # the four weight-gradient GEMMs run as one grouped launch at the end (their operands stay alive until then)
     # ---- FFN half
-    da = K.gemm(L.GEMM_NN, dx3, ffn.lin2.weight)
+    if FUSE_SWIGLU_BWD:  # d(act) never leaves the accumulators: the activation's backward is the dgrad GEMM's epilogue
+        dgu = K.gemm_dgrad_swiglu_bwd(dx3, ffn.lin2.weight, gu)
+    else:
+        dgu = K.swiglu_bwd(gu, K.gemm(L.GEMM_NN, dx3, ffn.lin2.weight), F_)
     _wgrad(arena, ffn.lin2.weight, None, dx3, a, wg)
-    dgu = K.swiglu_bwd(gu, da, F_)
-    del da
     wgu = arena.fused(ffn.lin1.weight, ffn.lin_gate.weight)
     dh2 = K.gemm(L.GEMM_NN, dgu, wgu)
     _wgrad(arena, ffn.lin1.weight, ffn.lin_gate.weight, dgu, h2, wg)

@@ -21,7 +21,7 @@ from . import _lib as L
 from . import kernels as K
 from . import kernels_q35 as Q
 from .arena import ParamArena
-from .ops import _flush_wgrads, _vecgrad, _wgrad
+from .ops import FUSE_SWIGLU_BWD, _flush_wgrads, _vecgrad, _wgrad
 
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -203,10 +203,11 @@ def block_backward(blk, saved, dx3, rt):
     x, w1, h1, rstd1, mix, att_saved, x2, w2, h2, rstd2, gu, a = saved
     wg = []
     # ---- FFN half
-    da = K.gemm(L.GEMM_NN, dx3, ffn.lin2.weight)
+    if FUSE_SWIGLU_BWD:  # d(act) never leaves the accumulators: the activation's backward is the dgrad GEMM's epilogue
+        dgu = K.gemm_dgrad_swiglu_bwd(dx3, ffn.lin2.weight, gu)
+    else:
+        dgu = K.swiglu_bwd(gu, K.gemm(L.GEMM_NN, dx3, ffn.lin2.weight), F_)
     _wgrad(arena, ffn.lin2.weight, None, dx3, a, wg)
-    dgu = K.swiglu_bwd(gu, da, F_)
-    del da
     dh2 = K.gemm(L.GEMM_NN, dgu, arena.fused(ffn.lin1.weight, ffn.lin_gate.weight))
     _wgrad(arena, ffn.lin1.weight, ffn.lin_gate.weight, dgu, h2, wg)
     gview, gacc = _vecgrad(arena, blk.norm2.scale)

@@ -510,3 +510,19 @@ def test_cast_clip_helpers(K):
     K.clip_scale_(y, ss, 1.0)
     coef = 1.0 / (math.sqrt(float(x.pow(2).sum())) + 1e-6)
     assert rel_l2(y, x * coef) < 1e-6
+
+
+def test_gemm_swiglu_backward_epilogue_equals_two_kernels_bit_for_bit():
+    """d(gate-up) from ONE dgrad GEMM with the SwiGLU-backward epilogue == dgrad GEMM -> bf16 d(act) -> mi355_swiglu_bwd, at the step's
+    shape (ragged M) and at a small one."""
+    from llm_quest_amd import _lib as L
+    from llm_quest_amd import kernels as K
+
+    torch.manual_seed(21)
+    for M, F, Nout in ((709 * 3 + 5, 3072, 1024), (300, 256, 64)):
+        dy = torch.randn(M, Nout, device="cuda").to(torch.bfloat16)
+        w = (torch.randn(Nout, F, device="cuda") / Nout**0.5).to(torch.bfloat16)
+        gu = torch.randn(M, 2 * F, device="cuda").to(torch.bfloat16)
+        want = K.swiglu_bwd(gu, K.gemm(L.GEMM_NN, dy, w, allow_split_k=False), F)
+        got = K.gemm_dgrad_swiglu_bwd(dy, w, gu)
+        assert torch.equal(got, want)
