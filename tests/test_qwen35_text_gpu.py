@@ -520,3 +520,50 @@ def test_qwen35_vlm_composes_vision_scatter_mrope_and_text_stack():
         if name.endswith("out_head.weight"):
             continue
         assert p.grad is not None and torch.isfinite(p.grad.float()).all(), name
+
+
+def test_rccl_gradsync_qwen35_single_rank():
+    """The RCCL path of config 5 on one GPU (1-rank 'nccl' group, GradSync forced on): block arenas during backward, the embedding arena
+    and the coalesced bucket of stand-alone parameters (fp32 GDN parameters, the fp32 vision tower) in finish_step.  Gradients unchanged."""
+    import os
+
+    import torch.distributed as dist
+
+    from oracle.gen_golden import TINY_Q35_VISION
+    from llm_quest_amd import ddp
+    from llm_quest_amd.qwen.qwen3_5.qwen3_5_vlm_model import Qwen3_5VLM
+
+    torch.manual_seed(14)
+    cfg = {**TINY_Q35_TEXT, **TINY_Q35_VISION, "dtype": BF16, "emb_dim": 128, "llm_d_in": 128, "image_token_id": 255, "n_heads": 2, "head_dim": 32}
+    vlm = Qwen3_5VLM(cfg).cuda().train()
+    ids = torch.randint(0, 250, (2, 30))
+    ids[:, 5:13] = 255
+    pix = torch.randn(2, 3, 4, 32, 32).cuda()
+    tgt = torch.randint(0, 256, (60,)).cuda()
+
+    def loss_fn():
+        vlm.zero_grad(set_to_none=True)
+        return F.cross_entropy(vlm(ids.cuda(), image_pixels=pix).float().flatten(0, 1), tgt)
+
+    loss_fn().backward()
+    ref = {n: p.grad.float().clone() for n, p in vlm.named_parameters() if p.grad is not None}
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        sync = ddp.sync_for_qwen35(vlm)
+        assert len(sync.tail_params) > 0 and any(p.dtype == F32 for p in sync.tail_params)
+        sync.enabled = True
+        sync.broadcast_parameters([vlm])
+        loss = loss_fn()
+        sync.begin_step()
+        loss.backward()
+        sync.finish_step()
+        torch.cuda.synchronize()
+        assert len(sync._done) == len(vlm.language_model.trf_blocks) + 1
+        for n, p in vlm.named_parameters():
+            if n in ref:  # two backward passes: fp32 atomics (bias column sums, embedding scatter) may order differently; a broken sync is O(1)
+                assert rel_l2(p.grad, ref[n]) < 1e-3, n
+    finally:
+        dist.destroy_process_group()
+        for m in vlm.language_model.trf_blocks:
+            object.__setattr__(m, "_grad_ready", None)
