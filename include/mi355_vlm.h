@@ -42,6 +42,11 @@ extern "C" {
  * gate-up output [u | g] [M, 2N] (ldr >= 2N); C = d(gate-up) [M, 2N] (ldc >= 2N) = [acc g sig(g) | acc u sig(g) (1 + g (1 - sig(g)))].
  * Replaces mi355_swiglu_bwd and the d(act) round trip through HBM; bit-identical to the two-kernel form. */
 #define MI355_EPI_SWIGLU_BWD 2
+/* SwiGLU forward fused into the gate-up projection (NT form; B = the fused weight [lin1 | lin_gate], N = 2F rows): C = the gate-up
+ * output [M, 2F] exactly as without the epilogue (the backward needs it), and `residual` is an OUTPUT here: a = lin1(x) * silu(lin_gate(x))
+ * [M, F] (ldr >= F).  The kernel fetches the weight rows of a tile as [32 lin1 | 32 lin_gate] groups so u and g of a hidden unit meet
+ * in one wave's epilogue; replaces mi355_swiglu_fwd, bit-identical. */
+#define MI355_EPI_SWIGLU_FWD 3
 
 const char* mi355_last_error(void);
 int mi355_abi_version(void);

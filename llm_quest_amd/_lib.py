@@ -16,7 +16,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 DT_BF16, DT_F32 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
-EPI_NONE, EPI_GELU, EPI_SWIGLU_BWD = 0, 1, 2
+EPI_NONE, EPI_GELU, EPI_SWIGLU_BWD, EPI_SWIGLU_FWD = 0, 1, 2, 3
 
 _c = ctypes
 _P, _I, _L, _F = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float

@@ -180,6 +180,25 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
     piece_offsets<B_TR, T::BN, BK, T::B_PPW>(wave, lane, p.ldb, p.N - n0, voffB, kneedB);
     const bf16_t* baseA = A_TR ? p.A + m0 : p.A + m0 * p.lda;
     const bf16_t* baseB = B_TR ? p.B + n0 : p.B + n0 * p.ldb;
+    if constexpr (!B_TR) {
+        if (p.epilogue == MI355_EPI_SWIGLU_FWD) {
+            // gate-up projection with the activation in the epilogue: every 64 output columns of the tile are [32 lin1 rows | the 32
+            // lin_gate rows of the SAME hidden units] of the fused weight [lin1 (N/2 rows) | lin_gate (N/2 rows)], so a wave's 64x64
+            // staging block holds u and g side by side.  Only the row each DMA lane fetches changes.
+            constexpr int CH = BK * 2 / 16, RPP = 64 / CH;
+            const int64_t nh = p.N >> 1;
+#pragma unroll
+            for (int j = 0; j < T::B_PPW; ++j) {
+                const int r = (wave * T::B_PPW + j) * RPP + lane / CH;
+                const int c = swz_rowk<BK>(lane % CH, r);
+                const int64_t hid = (n0 >> 1) + (r >> 6) * 32 + (r & 31);
+                const int64_t grow = ((r >> 5) & 1) * nh + hid;
+                voffB[j] = hid < nh ? (unsigned)(grow * p.ldb * 2 + c * 16) : OOB;
+                kneedB[j] = c * 8;
+            }
+            baseB = p.B;
+        }
+    }
     const int64_t stepA = A_TR ? (int64_t)BK * p.lda : BK;
     const int64_t stepB = B_TR ? (int64_t)BK * p.ldb : BK;
 
@@ -506,6 +525,39 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
                     if constexpr (OUT_DT == MI355_DT_BF16) {
                         bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + gm * p.ldc + gn;
                         const bf16_t* r = p.R ? reinterpret_cast<const bf16_t*>(p.R) + gm * p.ldr + gn : nullptr;
+                        if (p.epilogue == MI355_EPI_SWIGLU_FWD) {
+                            // this wave's 64 staging columns = [u (32) | g (32)] of hidden units hid0..hid0+31 (see the DMA plan): lanes 0-3 of each
+                            // row group write u into C[:, hid] and a = u * silu(g) into R[:, hid], lanes 4-7 write g into C[:, N/2 + hid];
+                            // u, g are rounded to bf16 first, so a equals mi355_swiglu_fwd on the stored gate-up output bit for bit.
+                            const int l8 = lane & 7;
+                            const int64_t nh = p.N >> 1;
+                            const int64_t hid = (n0 >> 1) + ((wc0 + sn * 64) >> 6) * 32 + (l8 & 3) * 8;
+                            if (hid >= nh) continue;
+                            bf16_t* gu_row = reinterpret_cast<bf16_t*>(p.C) + gm * p.ldc;
+                            u32x4 own;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) own[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+                            if (l8 >= 4) {
+                                *reinterpret_cast<u32x4*>(gu_row + nh + hid) = own;
+                                continue;
+                            }
+                            *reinterpret_cast<u32x4*>(gu_row + hid) = own;
+                            const float* gp_ = stg + row * EPI_LD + 32 + l8 * 8;
+                            u32x4 av;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float a2[2];
+#pragma unroll
+                                for (int hlf = 0; hlf < 2; ++hlf) {
+                                    const float u_ = hlf ? __uint_as_float(own[e] & 0xffff0000u) : __uint_as_float(own[e] << 16);
+                                    const float g_ = bf2f(f2bf(gp_[2 * e + hlf]));
+                                    a2[hlf] = u_ * bf2f(f2bf(g_ / (1.0f + __expf(-g_))));
+                                }
+                                av[e] = pack_bf2(a2[0], a2[1]);
+                            }
+                            *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(const_cast<void*>(p.R)) + gm * p.ldr + hid) = av;
+                            continue;
+                        }
                         if (p.epilogue == MI355_EPI_SWIGLU_BWD) {
                             // acc = d(act) for hidden units gn..gn+7; R = the forward's gate-up output [u | g] (ldr = 2N): write
                             // d(gate-up) = [acc * g*sig(g) | acc * u * sig(g) (1 + g (1 - sig(g)))] into C (ldc = 2N).  acc is rounded to
@@ -764,7 +816,11 @@ extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const 
     MI355_REQUIRE(out_dtype == MI355_DT_BF16 || out_dtype == MI355_DT_F32, "mi355_gemm_bf16: bad out_dtype");
     if (int rc = check_operands("mi355_gemm_bf16", form, M, N, K, A, lda, B, ldb, C)) return rc;
     MI355_REQUIRE(workspace == nullptr || ((uintptr_t)workspace & 15) == 0, "mi355_gemm_bf16: workspace must be 16-byte aligned");
-    MI355_REQUIRE(epilogue == MI355_EPI_NONE || epilogue == MI355_EPI_GELU_ERF || epilogue == MI355_EPI_SWIGLU_BWD, "mi355_gemm_bf16: unknown epilogue %d", epilogue);
+    MI355_REQUIRE(epilogue == MI355_EPI_NONE || epilogue == MI355_EPI_GELU_ERF || epilogue == MI355_EPI_SWIGLU_BWD || epilogue == MI355_EPI_SWIGLU_FWD, "mi355_gemm_bf16: unknown epilogue %d", epilogue);
+    if (epilogue == MI355_EPI_SWIGLU_FWD)
+        MI355_REQUIRE(form == MI355_GEMM_NT && out_dtype == MI355_DT_BF16 && residual && !bias && (N & 63) == 0 && ldc >= N && ldr >= N / 2 && (ldc & 7) == 0 &&
+                          (ldr & 7) == 0 && (((uintptr_t)residual | (uintptr_t)C) & 15) == 0,
+                      "mi355_gemm_bf16(SwiGLU forward epilogue): NT form, bf16 gate-up output [M, N] with N = 2F, F %% 32 == 0, `residual` = the activation output [M, F], no bias");
     if (epilogue == MI355_EPI_SWIGLU_BWD)
         MI355_REQUIRE(out_dtype == MI355_DT_BF16 && residual && !bias && (N & 7) == 0 && ldc >= 2 * N && ldr >= 2 * N && (ldc & 7) == 0 && (ldr & 7) == 0 &&
                           (((uintptr_t)residual | (uintptr_t)C) & 15) == 0,

@@ -112,6 +112,23 @@ def gemm_grouped(form, problems, tile=0):
     L.call("mi355_gemm_bf16_grouped", form, len(problems), _c.cast(table, _c.c_void_p), L.dt_code(odt), tile or _TILE_BY_FORM[form] or (_TILE_OVERRIDE if _TILE_OVERRIDE in (1, 3, 4) else 0))
 
 
+def gemm_gateup_swiglu(x, w_fused, tile=0):
+    """(gu [M, 2F], a [M, F]) of a SwiGLU FFN in ONE launch: gu = x @ [lin1 | lin_gate]^T as usual, a = u * silu(g) from the epilogue
+    (replaces gemm + swiglu_fwd)."""
+    L.require_gpu(x, w_fused)
+    _rowmajor(x, "X")
+    _rowmajor(w_fused, "W")
+    M, Kd = x.shape
+    N = w_fused.shape[0]
+    if x.dtype != BF16 or w_fused.dtype != BF16 or w_fused.shape[1] != Kd or N % 64:
+        raise ValueError("gemm_gateup_swiglu: bf16 X [M, K], fused weight [2F, K] with F % 32 == 0")
+    gu = torch.empty((M, N), dtype=BF16, device=x.device)
+    a = torch.empty((M, N // 2), dtype=BF16, device=x.device)
+    L.call("mi355_gemm_bf16", L.GEMM_NT, M, N, Kd, L.ptr(x), x.stride(0), L.ptr(w_fused), w_fused.stride(0), L.ptr(gu), gu.stride(0), L.DT_BF16, None,
+           L.ptr(a), a.stride(0), L.EPI_SWIGLU_FWD, None, 0, tile or _TILE_BY_FORM[L.GEMM_NT] or _TILE_OVERRIDE)
+    return gu, a
+
+
 def gemm_dgrad_swiglu_bwd(dy, w, gu, tile=0):
     """d(gate-up) [M, 2F] of a SwiGLU FFN in ONE launch: d(act) = dy @ w (NN, w = lin2.weight [N_out, F]) stays in the accumulators and the
     activation's backward runs in the epilogue against ``gu`` = the forward's [lin1 | lin_gate] output (replaces gemm + swiglu_bwd)."""

@@ -35,6 +35,7 @@ def arena_for(module):
     return ar
 
 
+FUSE_SWIGLU_FWD = os.environ.get("MI355_FUSE_SWIGLU_FWD", "1") != "0"  # 0: separate projection GEMM + swiglu_fwd kernel (A/B measurements)
 FUSE_SWIGLU_BWD = os.environ.get("MI355_FUSE_SWIGLU_BWD", "1") != "0"  # 0: separate dgrad GEMM + swiglu_bwd kernels (A/B measurements)
 GROUP_WGRADS = os.environ.get("MI355_GROUP_WGRADS", "1") != "0"  # 0: one launch per weight gradient (A/B measurements)
 
@@ -141,8 +142,11 @@ def block_forward(blk, x, rt, keep):
     ctx, att_saved = attention_forward(att, arena, h1, rt)
     x2 = K.gemm(L.GEMM_NT, ctx, att.out_proj.weight, residual=x)
     h2, rstd2 = K.rmsnorm_fwd(x2, blk.norm2.weight)
-    gu = K.gemm(L.GEMM_NT, h2, arena.fused(ffn.lin1.weight, ffn.lin_gate.weight))
-    a = K.swiglu_fwd(gu, F_)
+    if FUSE_SWIGLU_FWD and F_ % 32 == 0:  # the activation is the projection's epilogue (gu is still written: the backward needs it)
+        gu, a = K.gemm_gateup_swiglu(h2, arena.fused(ffn.lin1.weight, ffn.lin_gate.weight))
+    else:
+        gu = K.gemm(L.GEMM_NT, h2, arena.fused(ffn.lin1.weight, ffn.lin_gate.weight))
+        a = K.swiglu_fwd(gu, F_)
     x3 = K.gemm(L.GEMM_NT, a, ffn.lin2.weight, residual=x2)
     saved = (x, h1, rstd1, ctx, att_saved, x2, h2, rstd2, gu, a) if keep else None
     return x3, saved

@@ -21,7 +21,7 @@ from . import _lib as L
 from . import kernels as K
 from . import kernels_q35 as Q
 from .arena import ParamArena
-from .ops import FUSE_SWIGLU_BWD, _flush_wgrads, _vecgrad, _wgrad
+from .ops import FUSE_SWIGLU_BWD, FUSE_SWIGLU_FWD, _flush_wgrads, _vecgrad, _wgrad
 
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -189,8 +189,11 @@ def block_forward(blk, x, rt, keep):
     x2 = K.gemm(L.GEMM_NT, mix, att.out_proj.weight, residual=x)
     w2 = Q.zc_weight(blk.norm2.scale)
     h2, rstd2 = K.rmsnorm_fwd(x2, w2, eps=blk.norm2.eps)
-    gu = K.gemm(L.GEMM_NT, h2, arena.fused(ffn.lin1.weight, ffn.lin_gate.weight))
-    a = K.swiglu_fwd(gu, F_)
+    if FUSE_SWIGLU_FWD and F_ % 32 == 0:  # the activation is the projection's epilogue (gu is still written: the backward needs it)
+        gu, a = K.gemm_gateup_swiglu(h2, arena.fused(ffn.lin1.weight, ffn.lin_gate.weight))
+    else:
+        gu = K.gemm(L.GEMM_NT, h2, arena.fused(ffn.lin1.weight, ffn.lin_gate.weight))
+        a = K.swiglu_fwd(gu, F_)
     x3 = K.gemm(L.GEMM_NT, a, ffn.lin2.weight, residual=x2)
     saved = (x, w1, None if blk.is_linear else h1, rstd1, mix, att_saved, x2, w2, h2, rstd2, gu, a) if keep else None  # the GDN half keeps its own (masked) h1
     return x3, saved

@@ -526,3 +526,21 @@ def test_gemm_swiglu_backward_epilogue_equals_two_kernels_bit_for_bit():
         want = K.swiglu_bwd(gu, K.gemm(L.GEMM_NN, dy, w, allow_split_k=False), F)
         got = K.gemm_dgrad_swiglu_bwd(dy, w, gu)
         assert torch.equal(got, want)
+
+
+def test_gemm_swiglu_forward_epilogue_equals_two_kernels_bit_for_bit():
+    """(gate-up output, activation) from ONE projection GEMM with the SwiGLU epilogue (weight rows fetched as [32 lin1 | 32 lin_gate] groups)
+    == projection GEMM -> mi355_swiglu_fwd, for every tile configuration that serves NT, ragged M, F not a multiple of the tile."""
+    from llm_quest_amd import _lib as L
+    from llm_quest_amd import kernels as K
+
+    torch.manual_seed(22)
+    for M, F, Kd in ((709 * 2 + 3, 3072, 1024), (300, 3584, 256), (130, 96, 64)):
+        x = torch.randn(M, Kd, device="cuda").to(torch.bfloat16)
+        w = (torch.randn(2 * F, Kd, device="cuda") / Kd**0.5).to(torch.bfloat16)
+        gu_ref = K.gemm(L.GEMM_NT, x, w, allow_split_k=False)
+        a_ref = K.swiglu_fwd(gu_ref, F)
+        for tile in (0, 1, 2, 3):
+            gu, a = K.gemm_gateup_swiglu(x, w, tile=tile)
+            assert torch.equal(gu, gu_ref), (M, F, tile)
+            assert torch.equal(a, a_ref), (M, F, tile)
