@@ -113,17 +113,15 @@ def qwen3_forward_cached(model, x, kv_cache, attn_mask=None, position_ids=None, 
         qkv = lin(h1, arena.fused(att.w_queries.weight, att.w_values.weight))
         q, k, _ = K.qknorm_rope_fwd(qkv, att.q_norm.weight, att.k_norm.weight, model.cos, model.sin, pos, Hq, Hkv, D)
         v = qkv[:, (Hq + Hkv) * D :]
-        if dev_state is not None:
+        if dev_state is not None:  # graph replay: position and length are read on the device, the cache object is advanced by the caller
             kc, vc = kv_cache.keys_cache[att.layer_idx], kv_cache.values_cache[att.layer_idx]
             kv_append_dev(k, v, kc, vc, write_pos)
             ctx = attn_decode(q, kc, vc, kc.shape[1], Hq, Hkv, D, key_mask=km, scale=att.att_scaling, len_dev=len_dev)
-        else:
-            kc, vc, end = kv_cache.append_rows(k, v, att.layer_idx, B, S)
-        if dev_state is not None:
-            pass
         elif decode:
+            kc, vc, end = kv_cache.append_rows(k, v, att.layer_idx, B, S)
             ctx = attn_decode(q, kc, vc, end, Hq, Hkv, D, key_mask=km, scale=att.att_scaling)
         else:
+            kv_cache.append_rows(k, v, att.layer_idx, B, S)
             ctx, _ = K.attn_fwd(q, k, v, B, S, Hq, Hkv, D, key_mask=None if km is None else km[:, :S].contiguous(), causal=True, scale=att.att_scaling)
         h = lin(ctx, att.out_proj.weight, residual=h)
         h2, _ = K.rmsnorm_fwd(h, blk.norm2.weight, want_rstd=False)

@@ -21,4 +21,4 @@ def t(fn):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / a.reps * 1e3
 o, ck, _ = Q.gated_delta_rule_fwd(q, k, v, beta, alpha, B, S, Hqk, Hv, Dk, Dv)
-print(f"B={B} S={S}: fwd {t(lambda: Q.gated_delta_rule_fwd(q, k, v, beta, alpha, B, S, Hqk, Hv, Dk, Dv)):8.1f} us   bwd(+reduce) {t(lambda: Q.gated_delta_rule_bwd(q, k, v, beta, alpha, ck, do, dv, B, S, Hqk, Hv, Dk, Dv)):8.1f} us   ablate={os.environ.get('MI355_GDR_ABLATE', '0')} chunk={Q.gdr_chunk()}")
+print(f"B={B} S={S}: fwd {t(lambda: Q.gated_delta_rule_fwd(q, k, v, beta, alpha, B, S, Hqk, Hv, Dk, Dv)):8.1f} us   bwd(+reduce) {t(lambda: Q.gated_delta_rule_bwd(q, k, v, beta, alpha, ck, do, dv, B, S, Hqk, Hv, Dk, Dv)):8.1f} us   checkpoint spacing {Q.gdr_chunk()}")
