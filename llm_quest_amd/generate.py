@@ -118,3 +118,56 @@ def _generate_greedy_graph(input_tensor, model, max_gen, context_length, eos_ids
             if dec is not None:
                 dec.close()
     return torch.cat([input_tensor] + token_ids, dim=-1)
+
+
+def _batched_kv_loop(input_tensor, model, max_gen, context_length, top_k, top_p, min_p, temp, eos_ids, pad_id, device, attention_mask,
+                     first_position_ids, next_pos_ids, pick_first_logits):
+    """Shared body of the two padded, batched KV-cache loops: prefill, then one token per unfinished sequence; finished sequences keep
+    receiving ``pad_id`` and are masked out of later attention (reference: generate.py:252-365, 368-469)."""
+    input_tensor = input_tensor.to(device)
+    attention_mask = attention_mask.bool().to(device)
+    eos = torch.tensor(eos_ids if isinstance(eos_ids, list) else [eos_ids], device=device, dtype=torch.long)
+    pad = torch.tensor(pad_id, device=device, dtype=torch.long)
+    finished = torch.zeros(input_tensor.shape[0], dtype=torch.bool, device=device)
+    kv_cache = KVCache(num_layers=len(model.trf_blocks), prompt_len=input_tensor.shape[-1], context_len=context_length)
+    generated = []
+    with torch.inference_mode():
+        logits = pick_first_logits(model(input_tensor, attn_mask=attention_mask, kv_cache=kv_cache, position_ids=first_position_ids))
+        for i in range(max_gen):
+            next_token = torch.where(finished.unsqueeze(-1), pad, sampling(logits, top_k, top_p, min_p, temp))
+            generated.append(next_token)
+            finished |= torch.isin(next_token.squeeze(1), eos)
+            attention_mask = torch.cat([attention_mask, (~finished).unsqueeze(-1)], dim=-1)
+            if finished.all():
+                break
+            if i < max_gen - 1:
+                logits = model(next_token, attn_mask=attention_mask, kv_cache=kv_cache, position_ids=next_pos_ids).squeeze(1)
+            next_pos_ids = next_pos_ids + 1
+    return torch.cat([input_tensor] + generated, dim=1)
+
+
+def generate_batched_loop_kv_cache(input_tensor, model, max_gen, context_length, top_k=None, top_p=None, min_p=None, temp=0.0, eos_ids=50256,
+                                   pad_id=50256, device=torch.device("cuda"), last_real=None, *, attention_mask):
+    """RIGHT-padded prompts: the first logits come from each sequence's last real token, rotary positions continue from its real
+    length (reference: generate.py:252-365)."""
+    attention_mask = attention_mask.bool().to(device)
+    if last_real is not None:
+        last_real = last_real.to(device)
+        next_pos = last_real.unsqueeze(-1) + 1
+    else:
+        next_pos = attention_mask.sum(dim=-1, keepdim=True)
+        last_real = next_pos.squeeze(-1) - 1
+    rows = torch.arange(input_tensor.shape[0], device=device)
+    return _batched_kv_loop(input_tensor, model, max_gen, context_length, top_k, top_p, min_p, temp, eos_ids, pad_id, device, attention_mask,
+                            None, next_pos, lambda lg: lg[rows, last_real, :])
+
+
+def generate_batched_loop_kv_cache_left_pad(input_tensor, model, max_gen, context_length, top_k=None, top_p=None, min_p=None, temp=0.0,
+                                            eos_ids=50256, pad_id=50256, device=torch.device("cuda"), *, attention_mask):
+    """LEFT-padded prompts: positions count real tokens only (pads sit at position 0), every sequence ends in the last column
+    (reference: generate.py:368-469)."""
+    attention_mask = attention_mask.bool().to(device)
+    position_ids = (attention_mask.cumsum(dim=-1) - 1).masked_fill(~attention_mask, 0)
+    next_pos = attention_mask.sum(dim=-1, keepdim=True)
+    return _batched_kv_loop(input_tensor, model, max_gen, context_length, top_k, top_p, min_p, temp, eos_ids, pad_id, device, attention_mask,
+                            position_ids, next_pos, lambda lg: lg[:, -1, :])
