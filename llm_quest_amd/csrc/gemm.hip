@@ -18,7 +18,7 @@
 //     configurations give every wave 128x64 outputs: 25 % fewer fragment bytes and half the DMA bytes per MFMA.
 //   * Epilogue: accumulators -> LDS (fp32, 64x64 at a time per wave) -> row-contiguous 16-B global stores with
 //     bias/GELU/residual fused, or raw fp32 slabs when K is split (few output tiles + long K: weight gradients).
-//   * Workgroup -> tile map: XCD-aware (blocks b and b+8 share an L2) then 8-row super-groups.
+//   * Workgroup -> tile map: XCD-aware (blocks b and b+8 share an L2) then 3-row super-groups.
 #include <type_traits>
 
 #include "common.h"
@@ -163,8 +163,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    // ---- tile index -> (tm, tn): 8-row super-groups ----------------------------------------------------
-    const int GROUP_M = 8;
+    // ---- tile index -> (tm, tn): row super-groups ----------------------------------------------------
+    // super-group height by in-step A/B on the VLM step (ms/step, two runs each): 2: 245.9 / 246.2, 3: 243.8 / 243.8, 4: 245.3 / 245.3, 6: 243.8 / 244.3,
+    // 8: 245.2 / 245.6, 16: 249.7 / 248.0.  Profiling bits 5-7 of the tile hint select another height.
+    const int gsel = (p.ablate >> 5) & 7;
+    const int GROUP_M = gsel == 1 ? 4 : gsel == 2 ? 16 : gsel == 3 ? 2 : gsel == 4 ? 6 : gsel == 5 ? 8 : 3;
     const int in_group = GROUP_M * p.tiles_n;
     const int first_m = (pid / in_group) * GROUP_M;
     const int gsz = min(p.tiles_m - first_m, GROUP_M);
