@@ -47,6 +47,14 @@ extern "C" {
  * [M, F] (ldr >= F).  The kernel fetches the weight rows of a tile as [32 lin1 | 32 lin_gate] groups so u and g of a hidden unit meet
  * in one wave's epilogue; replaces mi355_swiglu_fwd, bit-identical. */
 #define MI355_EPI_SWIGLU_FWD 3
+/* Linear -> GELU of a training FFN in one launch (vit_transformer_block.py:59-67, vit_engine.py:43-53, qwen3_5_vision_model.py:112-125):
+ * C = acc + bias (the pre-activation, kept for the backward), `residual` is an OUTPUT: gelu(C) (erf: nn.GELU(); tanh: approximate="tanh"). */
+#define MI355_EPI_GELU_DUAL_ERF 4
+#define MI355_EPI_GELU_DUAL_TANH 5
+/* GELU backward fused into the dgrad of the following Linear: acc = d(act), `residual` = the forward's pre-activation, C = acc * gelu'(residual).
+ * Both pairs are bit-identical to GEMM + mi355_gelu_fwd / mi355_gelu_bwd. */
+#define MI355_EPI_GELU_BWD_ERF 6
+#define MI355_EPI_GELU_BWD_TANH 7
 
 const char* mi355_last_error(void);
 int mi355_abi_version(void);

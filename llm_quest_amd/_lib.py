@@ -17,6 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 DT_BF16, DT_F32 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_SWIGLU_BWD, EPI_SWIGLU_FWD = 0, 1, 2, 3
+EPI_GELU_DUAL_ERF, EPI_GELU_DUAL_TANH, EPI_GELU_BWD_ERF, EPI_GELU_BWD_TANH = 4, 5, 6, 7
 
 _c = ctypes
 _P, _I, _L, _F = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float

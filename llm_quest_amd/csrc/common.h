@@ -43,6 +43,24 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- GELU: KIND 0 exact erf (nn.GELU()), KIND 1 tanh approximation; one definition for the elementwise kernels and the GEMM epilogues
+template <int KIND>
+__device__ __forceinline__ float gelu_val(float x) {
+    if (KIND == 0) return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(u));
+}
+template <int KIND>
+__device__ __forceinline__ float gelu_grad(float x) {
+    if (KIND == 0) {
+        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+        return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+    }
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    const float th = tanhf(u);
+    return 0.5f * (1.0f + th) + 0.5f * x * (1.0f - th * th) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
+}
+
 // ---- host side error plumbing -------------------------------------------------------------
 void mi355_set_error(const char* fmt, ...);
 #define MI355_REQUIRE(cond, ...)          \

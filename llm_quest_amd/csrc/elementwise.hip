@@ -80,22 +80,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(int64_t tokens, int F, 
 // ------------------------------------------------------------------------------------------------ GELU (erf)
 // nn.GELU() on a bf16 tensor (ViTAdapter, vit_engine.py:50): a = bf16(gelu(x));  backward dx = da * gelu'(x)
 // KIND 0: exact erf GELU (nn.GELU());  KIND 1: tanh approximation (nn.GELU(approximate="tanh"), qwen3_5_vision_model.py:122)
-template <int KIND>
-__device__ __forceinline__ float gelu_val(float x) {
-    if (KIND == 0) return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    return 0.5f * x * (1.0f + tanhf(u));
-}
-template <int KIND>
-__device__ __forceinline__ float gelu_grad(float x) {
-    if (KIND == 0) {
-        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-        return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
-    }
-    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    const float th = tanhf(u);
-    return 0.5f * (1.0f + th) + 0.5f * x * (1.0f - th * th) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
-}
+// gelu_val<KIND> / gelu_grad<KIND> live in common.h (shared with the GEMM epilogues, so fused == separate bit for bit)
 template <int KIND>
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(int64_t n, const bf16_t* __restrict__ x, bf16_t* __restrict__ y) {
     const int64_t nv = n >> 3;

@@ -528,6 +528,33 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
                     if constexpr (OUT_DT == MI355_DT_BF16) {
                         bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + gm * p.ldc + gn;
                         const bf16_t* r = p.R ? reinterpret_cast<const bf16_t*>(p.R) + gm * p.ldr + gn : nullptr;
+                        if (p.epilogue == MI355_EPI_GELU_DUAL_ERF || p.epilogue == MI355_EPI_GELU_DUAL_TANH) {
+                            // v = acc + bias = the pre-activation: C gets it (the backward needs it), R (an OUTPUT here) gets gelu of its bf16 value
+                            u32x4 y1, act;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                y1[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+                                const float lo = __uint_as_float(y1[e] << 16), hi = __uint_as_float(y1[e] & 0xffff0000u);
+                                act[e] = p.epilogue == MI355_EPI_GELU_DUAL_ERF ? pack_bf2(gelu_val<0>(lo), gelu_val<0>(hi)) : pack_bf2(gelu_val<1>(lo), gelu_val<1>(hi));
+                            }
+                            *reinterpret_cast<u32x4*>(c) = y1;
+                            *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(const_cast<void*>(p.R)) + gm * p.ldr + gn) = act;
+                            continue;
+                        }
+                        if (p.epilogue == MI355_EPI_GELU_BWD_ERF || p.epilogue == MI355_EPI_GELU_BWD_TANH) {
+                            // acc = d(act); R = the forward's pre-activation: C = bf16(acc) * gelu'(R)  (== dgrad GEMM -> mi355_gelu_bwd)
+                            const u32x4 xv = *reinterpret_cast<const u32x4*>(r);
+                            u32x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float x0 = __uint_as_float(xv[e] << 16), x1 = __uint_as_float(xv[e] & 0xffff0000u);
+                                const float d0 = bf2f(f2bf(v[2 * e])), d1 = bf2f(f2bf(v[2 * e + 1]));
+                                o[e] = p.epilogue == MI355_EPI_GELU_BWD_ERF ? pack_bf2(d0 * gelu_grad<0>(x0), d1 * gelu_grad<0>(x1))
+                                                                             : pack_bf2(d0 * gelu_grad<1>(x0), d1 * gelu_grad<1>(x1));
+                            }
+                            *reinterpret_cast<u32x4*>(c) = o;
+                            continue;
+                        }
                         if (p.epilogue == MI355_EPI_SWIGLU_FWD) {
                             // this wave's 64 staging columns = [u (32) | g (32)] of hidden units hid0..hid0+31 (see the DMA plan): lanes 0-3 of each
                             // row group write u into C[:, hid] and a = u * silu(g) into R[:, hid], lanes 4-7 write g into C[:, N/2 + hid];
@@ -819,7 +846,12 @@ extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const 
     MI355_REQUIRE(out_dtype == MI355_DT_BF16 || out_dtype == MI355_DT_F32, "mi355_gemm_bf16: bad out_dtype");
     if (int rc = check_operands("mi355_gemm_bf16", form, M, N, K, A, lda, B, ldb, C)) return rc;
     MI355_REQUIRE(workspace == nullptr || ((uintptr_t)workspace & 15) == 0, "mi355_gemm_bf16: workspace must be 16-byte aligned");
-    MI355_REQUIRE(epilogue == MI355_EPI_NONE || epilogue == MI355_EPI_GELU_ERF || epilogue == MI355_EPI_SWIGLU_BWD || epilogue == MI355_EPI_SWIGLU_FWD, "mi355_gemm_bf16: unknown epilogue %d", epilogue);
+    MI355_REQUIRE(epilogue == MI355_EPI_NONE || epilogue == MI355_EPI_GELU_ERF || epilogue == MI355_EPI_SWIGLU_BWD || epilogue == MI355_EPI_SWIGLU_FWD || (epilogue >= MI355_EPI_GELU_DUAL_ERF && epilogue <= MI355_EPI_GELU_BWD_TANH), "mi355_gemm_bf16: unknown epilogue %d", epilogue);
+    if (epilogue >= MI355_EPI_GELU_DUAL_ERF && epilogue <= MI355_EPI_GELU_BWD_TANH)
+        MI355_REQUIRE(out_dtype == MI355_DT_BF16 && residual && (N & 7) == 0 && (ldc & 7) == 0 && (ldr & 7) == 0 && ldr >= N &&
+                          (((uintptr_t)residual | (uintptr_t)C) & 15) == 0 && (epilogue <= MI355_EPI_GELU_DUAL_TANH || !bias),
+                      "mi355_gemm_bf16(GELU dual / backward epilogue): bf16 output, N %% 8 == 0, `residual` = the second [M, N] operand (activation output, resp. "
+                      "the forward's pre-activation), no bias in the backward form");
     if (epilogue == MI355_EPI_SWIGLU_FWD)
         MI355_REQUIRE(form == MI355_GEMM_NT && out_dtype == MI355_DT_BF16 && residual && !bias && (N & 63) == 0 && ldc >= N && ldr >= N / 2 && (ldc & 7) == 0 &&
                           (ldr & 7) == 0 && (((uintptr_t)residual | (uintptr_t)C) & 15) == 0,

@@ -24,8 +24,7 @@ class _AdapterFn(torch.autograd.Function):
             y = K.gemm(L.GEMM_NT, x2, lins[0].weight, bias=bias[0])
             saved = (x2,)
         else:
-            y1 = K.gemm(L.GEMM_NT, x2, lins[0].weight, bias=bias[0])
-            a = K.gelu_fwd(y1)
+            y1, a = K.gemm_gelu_dual(x2, lins[0].weight, bias=bias[0])  # Linear + GELU in one launch
             y = K.gemm(L.GEMM_NT, a, lins[1].weight, bias=bias[1])
             saved = (x2, y1, a)
         ctx.mod, ctx.saved, ctx.shp, ctx.need_dx = mod, saved if keep else None, shp, x.requires_grad
@@ -54,8 +53,7 @@ class _AdapterFn(torch.autograd.Function):
             x2, y1, a = ctx.saved
             ops._wgrad(arena, lins[1].weight, None, dy2, a)
             bias_grad(lins[1], dy2)
-            da = K.gemm(L.GEMM_NN, dy2, lins[1].weight)
-            dy1 = K.gelu_bwd(y1, da)
+            dy1 = K.gemm_dgrad_gelu_bwd(dy2, lins[1].weight, y1)  # GELU backward in the dgrad epilogue
             ops._wgrad(arena, lins[0].weight, None, dy1, x2)
             bias_grad(lins[0], dy1)
             if ctx.need_dx:

@@ -85,8 +85,7 @@ def vit_forward_train(m, img, output_hidden_states):
         x2 = K.gemm(L.GEMM_NT, ctx, wo, bias=att.out_proj.bias.detach(), residual=x, out_dtype=F32)
         h2, mean2, rsig2 = K.layernorm_fwd(x2, blk.ln_2.scale.detach(), blk.ln_2.shift.detach(), out_dtype=BF16, eps=blk.ln_2.eps, want_stats=True)
         w1 = bf16_cached(ffn, "w1", [ffn.layers[0].weight])
-        y1 = K.gemm(L.GEMM_NT, h2, w1, bias=ffn.layers[0].bias.detach())
-        f = K.gelu_fwd(y1)
+        y1, f = K.gemm_gelu_dual(h2, w1, bias=ffn.layers[0].bias.detach())  # Linear + GELU in one launch (pre-activation kept for the backward)
         w2 = bf16_cached(ffn, "w2", [ffn.layers[2].weight])
         x3 = K.gemm(L.GEMM_NT, f, w2, bias=ffn.layers[2].bias.detach(), residual=x2, out_dtype=F32)
         saved_blocks.append((x, mean1, rsig1, h1, qkv, ctx, lse, x2, mean2, rsig2, h2, y1, f))
@@ -145,10 +144,9 @@ def vit_backward(m, saved, dout):
         wg = []  # this block's six weight gradients, one grouped launch
         # ---- FFN half
         dx3b = K.cast(dx, BF16)
-        df = K.gemm(L.GEMM_NN, dx3b, bf16_cached(ffn, "w2", [ffn.layers[2].weight]))
+        dy1 = K.gemm_dgrad_gelu_bwd(dx3b, bf16_cached(ffn, "w2", [ffn.layers[2].weight]), y1)  # GELU backward in the dgrad epilogue
         _wgrad(ffn.layers[2].weight, dx3b, f, wg)
         _bgrad(ffn.layers[2].bias, dx3b)
-        dy1 = K.gelu_bwd(y1, df)
         dh2 = K.gemm(L.GEMM_NN, dy1, bf16_cached(ffn, "w1", [ffn.layers[0].weight]))
         _wgrad(ffn.layers[0].weight, dy1, h2, wg)
         _bgrad(ffn.layers[0].bias, dy1)

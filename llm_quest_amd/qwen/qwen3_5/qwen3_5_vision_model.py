@@ -127,16 +127,14 @@ def _forward(m, pixels):
         wo = bf16_cached(blk.att, "wo", [blk.att.proj.weight])
         x2 = K.gemm(L.GEMM_NT, ctx, wo, bias=blk.att.proj.bias.detach(), residual=x, out_dtype=F32)
         h2, mean2, rsig2 = _ln(blk.norm2, x2, BF16)
-        y1 = K.gemm(L.GEMM_NT, h2, bf16_cached(blk.ffn, "w1", [blk.ffn.lin1.weight]), bias=blk.ffn.lin1.bias.detach())
-        f = K.gelu_fwd(y1, tanh=True)
+        y1, f = K.gemm_gelu_dual(h2, bf16_cached(blk.ffn, "w1", [blk.ffn.lin1.weight]), bias=blk.ffn.lin1.bias.detach(), tanh=True)
         x3 = K.gemm(L.GEMM_NT, f, bf16_cached(blk.ffn, "w2", [blk.ffn.lin2.weight]), bias=blk.ffn.lin2.bias.detach(), residual=x2, out_dtype=F32)
         saved.append((x, mean1, rsig1, h1, qkv, q, k, ctx, lse, x2, mean2, rsig2, h2, y1, f))
         x = x3
     ma = m.merge_adapter
     hn, meanm, rsigm = _ln(ma.norm, x, BF16)
     merged = K.merge_patches(hn, B * frames, ma.n_h_patches, ma.n_w_patches, ma.m)
-    z1 = K.gemm(L.GEMM_NT, merged, bf16_cached(ma, "w1", [ma.lin1.weight]), bias=ma.lin1.bias.detach())
-    a = K.gelu_fwd(z1)
+    z1, a = K.gemm_gelu_dual(merged, bf16_cached(ma, "w1", [ma.lin1.weight]), bias=ma.lin1.bias.detach())
     out = K.gemm(L.GEMM_NT, a, bf16_cached(ma, "w2", [ma.lin2.weight]), bias=ma.lin2.bias.detach(), out_dtype=F32)
     n_merged = frames * (ma.n_h_patches // ma.m) * (ma.n_w_patches // ma.m)
     return out.view(B, n_merged, -1), (rows, tok_pos, saved, (x, meanm, rsigm, merged, z1, a), (B, frames, S, d))
@@ -148,10 +146,9 @@ def _backward(m, saved_all, dout):
     ma = m.merge_adapter
     g = dout.reshape(-1, dout.shape[-1]).contiguous()
     gb = g if g.dtype == BF16 else K.cast(g, BF16)
-    da = K.gemm(L.GEMM_NN, gb, bf16_cached(ma, "w2", [ma.lin2.weight]))
+    dz1 = K.gemm_dgrad_gelu_bwd(gb, bf16_cached(ma, "w2", [ma.lin2.weight]), z1)
     _wgrad(ma.lin2.weight, gb, a)
     _bgrad(ma.lin2.bias, gb)
-    dz1 = K.gelu_bwd(z1, da)
     dmerged = K.gemm(L.GEMM_NN, dz1, bf16_cached(ma, "w1", [ma.lin1.weight]))
     _wgrad(ma.lin1.weight, dz1, merged)
     _bgrad(ma.lin1.bias, dz1)
@@ -161,10 +158,9 @@ def _backward(m, saved_all, dout):
         x, mean1, rsig1, h1, qkv, q, k, ctx, lse, x2, mean2, rsig2, h2, y1, f = sv
         wg = []  # this block's four weight gradients, one grouped launch
         dx3b = K.cast(dx, BF16)
-        df = K.gemm(L.GEMM_NN, dx3b, bf16_cached(blk.ffn, "w2", [blk.ffn.lin2.weight]))
+        dy1 = K.gemm_dgrad_gelu_bwd(dx3b, bf16_cached(blk.ffn, "w2", [blk.ffn.lin2.weight]), y1, tanh=True)
         _wgrad(blk.ffn.lin2.weight, dx3b, f, wg)
         _bgrad(blk.ffn.lin2.bias, dx3b)
-        dy1 = K.gelu_bwd(y1, df, tanh=True)
         dh2 = K.gemm(L.GEMM_NN, dy1, bf16_cached(blk.ffn, "w1", [blk.ffn.lin1.weight]))
         _wgrad(blk.ffn.lin1.weight, dy1, h2, wg)
         _bgrad(blk.ffn.lin1.bias, dy1)

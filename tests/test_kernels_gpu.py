@@ -544,3 +544,27 @@ def test_gemm_swiglu_forward_epilogue_equals_two_kernels_bit_for_bit():
             gu, a = K.gemm_gateup_swiglu(x, w, tile=tile)
             assert torch.equal(gu, gu_ref), (M, F, tile)
             assert torch.equal(a, a_ref), (M, F, tile)
+
+
+@pytest.mark.parametrize("tanh", [False, True])
+def test_gemm_gelu_epilogues_equal_two_kernels_bit_for_bit(tanh):
+    """Linear -> GELU (pre-activation + activation from one launch) and the GELU backward in the next Linear's dgrad epilogue == the
+    GEMM + elementwise-kernel forms, erf and tanh."""
+    from llm_quest_amd import _lib as L
+    from llm_quest_amd import kernels as K
+
+    K._FUSE_GELU = True  # the fused forms are an option (the separate kernels are faster on the ViT step and stay the default)
+    torch.manual_seed(23)
+    for M, Kd, F in ((197 * 5 + 3, 768, 3072), (260, 64, 264)):
+        x = torch.randn(M, Kd, device="cuda").to(torch.bfloat16)
+        w1 = (torch.randn(F, Kd, device="cuda") / Kd**0.5).to(torch.bfloat16)
+        b1 = torch.randn(F, device="cuda")
+        y_ref = K.gemm(L.GEMM_NT, x, w1, bias=b1, allow_split_k=False)
+        f_ref = K.gelu_fwd(y_ref, tanh=tanh)
+        y1, f = K.gemm_gelu_dual(x, w1, bias=b1, tanh=tanh)
+        assert torch.equal(y1, y_ref) and torch.equal(f, f_ref)
+        dy = torch.randn(M, Kd, device="cuda").to(torch.bfloat16)
+        w2 = (torch.randn(Kd, F, device="cuda") / F**0.5).to(torch.bfloat16)
+        want = K.gelu_bwd(y_ref, K.gemm(L.GEMM_NN, dy, w2, allow_split_k=False), tanh=tanh)
+        assert torch.equal(K.gemm_dgrad_gelu_bwd(dy, w2, y_ref, tanh=tanh), want)
+    K._FUSE_GELU = False
