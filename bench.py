@@ -48,11 +48,15 @@ def build_models(device, seed=123):
     return vit, vit_cfg, ad, llm, llm_cfg
 
 
-def synthetic_batch(batch, device, seed):
+def synthetic_batch(batch, device, seed, ragged=False):
+    """SURVEY 8d, config 4 inputs: randn images, uniform token ids, all-ones text mask; ``ragged``: real lengths ~ U[256, 512], right-padded."""
     g = torch.Generator().manual_seed(seed)
     img = torch.randn(batch, 3, 224, 224, generator=g)
     ids = torch.randint(0, VOCAB, (batch, N_TEXT), generator=g)
     mask = torch.ones(batch, N_TEXT, dtype=torch.bool)
+    if ragged:
+        lengths = torch.randint(256, N_TEXT + 1, (batch,), generator=g)
+        mask = torch.arange(N_TEXT).unsqueeze(0) < lengths.unsqueeze(1)
     return img.to(device), ids.to(device), mask.to(device)
 
 
@@ -185,6 +189,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU micro-batch (samples); 64 x 709 tokens keeps ~70 GB of the 288 GB HBM live")
     ap.add_argument("--cpu-baseline", choices=["auto", "off"], default="auto")
+    ap.add_argument("--ragged", action="store_true", help="text lengths ~ U[256, 512] (padding mask active in attention and loss) instead of all-ones masks")
     ap.add_argument("--optimizer", choices=["on", "off"], default="on", help="also time the same steps with clip + AdamW (reported beside the fwd+bwd metric)")
     args = ap.parse_args()
 
@@ -203,7 +208,7 @@ def main():
     vit, vit_cfg, ad, llm, llm_cfg = build_models(device)
     sync = ddp.sync_for_vlm(llm, ad)
     sync.broadcast_parameters([llm, ad, vit])
-    img, ids, mask = synthetic_batch(args.batch, device, seed=123 + rank)
+    img, ids, mask = synthetic_batch(args.batch, device, seed=123 + rank, ragged=args.ragged)
 
     def step():
         loss = vlm_step_loss(vit, llm, ad, img, ids, mask, hf_vit_model=False)
@@ -283,7 +288,7 @@ def main():
             "config": {
                 "workload": "BASELINE configs[3]: VLM early fusion, ViT-B/16 (frozen, fwd) + ffn adapter 768->3072->1024 + Qwen3-0.6B, "
                             "224x224 image + 512 text tokens (S=709), fwd+loss+bwd, no optimizer step",
-                "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}", "text_mask": "ragged U[256,512]" if args.ragged else "all ones",
                 "units_per_sample": UNITS_PER_SAMPLE,
             },
             "roofline": {
