@@ -168,3 +168,91 @@ def test_hf_qwen3_checkpoint_import_round_trip(tmp_path, capsys):
     assert all(torch.equal(a, b) for a, b in zip(src.parameters(), third.parameters()))
     with pytest.raises(ValueError):
         load_qwen3_weights(Qwen3Model(cfg), cfg)
+
+
+def _to_hf_names(state_dict, rules, skip=()):
+    """Inverse of the loader's rename: our names -> HF names, last rule first so that nested substrings unwind correctly."""
+    out = {}
+    for name, w in state_dict.items():
+        if name in skip:
+            continue
+        hf_name = name
+        for hf, ours in reversed(rules):
+            if ours in hf_name and (ours.startswith(".") or hf_name.startswith(ours)):
+                hf_name = hf_name.replace(ours, hf, 1)
+        out[hf_name] = w.detach().clone()
+    return out
+
+
+def test_hf_qwen3_5_checkpoint_import_round_trip(tmp_path, capsys):
+    """Row f2 for BASELINE config 5: an HF-named Qwen3.5 checkpoint (text stack + vision tower + an ``mtp.`` head that must be
+    ignored) loads bit for bit into the text-only model and into the VLM; fp32 stragglers keep their dtype."""
+    from safetensors.torch import save_file
+
+    from llm_quest_amd.qwen.qwen3_5.qwen3_5_text_model import Qwen3_5TextModel
+    from llm_quest_amd.qwen.qwen3_5.qwen3_5_vlm_model import Qwen3_5VLM
+    from llm_quest_amd.qwen.qwen3_5.qwen3_5_weight_loading import (
+        get_remapping_rules,
+        get_vision_remapping_rules,
+        load_qwen3_5_text_weights,
+        load_qwen3_5_vlm_weights,
+    )
+
+    cfg = dict(
+        vocab_size=256, emb_dim=128, hidden_dim=128, n_layers=4, linear_sdpa_ratio=2, n_heads=2, num_kv_groups=1, head_dim=32,
+        rope_base=10_000_000, partial_rope_factor=0.5, context_length=64, linear_num_qk_heads=2, linear_num_value_heads=4,
+        linear_qk_head_dim=16, linear_value_head_dim=16, linear_conv_kernel_size=4, tie_embeddings=True, p_dropout=0.0,
+        training=False, mrope_section=[3, 3, 2], dtype=torch.bfloat16,
+        vision_n_layers=2, vision_emb_dim=128, vision_hidden_dim=256, vision_num_heads=2, llm_d_in=128, in_channels=3, patch_size=8,
+        spatial_merge_size=2, temporal_patch_size=2, num_position_embeddings=64, img_width=32, img_height=32,
+        vision_rope_base=10_000, image_token_id=250,
+    )
+    torch.manual_seed(1)
+    src = Qwen3_5VLM(cfg)
+    with torch.no_grad():  # the zero / one initialised tensors would make the comparison vacuous
+        for p in src.parameters():
+            if p.dim() == 1:
+                p.copy_(torch.randn(p.shape))
+    hf = _to_hf_names(src.language_model.state_dict(), get_remapping_rules(),
+                      skip=("out_head.weight", "mask", "cos", "sin"))  # tied head; buffers are rebuilt locally
+    hf.update(_to_hf_names(src.vision_model.state_dict(), get_vision_remapping_rules()))
+    assert {"model.language_model.embed_tokens.weight", "model.language_model.norm.weight",
+            "model.language_model.layers.0.linear_attn.A_log", "model.language_model.layers.0.linear_attn.in_proj_qkv.weight",
+            "model.language_model.layers.1.self_attn.q_proj.weight", "model.language_model.layers.3.self_attn.k_norm.weight",
+            "model.language_model.layers.2.linear_attn.norm.weight", "model.language_model.layers.2.mlp.down_proj.weight",
+            "model.visual.patch_embed.proj.bias", "model.visual.pos_embed.weight", "model.visual.blocks.1.attn.qkv.weight",
+            "model.visual.blocks.0.mlp.linear_fc2.bias", "model.visual.blocks.0.norm2.weight",
+            "model.visual.merger.linear_fc1.weight", "model.visual.merger.norm.bias"} <= set(hf)
+    assert not [k for k in hf if not k.startswith(("model.language_model.", "model.visual."))]
+    hf["mtp.fc.weight"] = torch.zeros(4, 4)
+
+    # text-only model: vision + mtp tensors are skipped silently, everything else lands
+    text = load_qwen3_5_text_weights(Qwen3_5TextModel(cfg), cfg, source=hf)
+    out = capsys.readouterr().out
+    assert "WARNING" not in out and f"Skipped {1 + len(src.vision_model.state_dict())} weights" in out
+    for (n1, p1), (n2, p2) in zip(src.language_model.named_parameters(), text.named_parameters()):
+        assert n1 == n2 and p1.dtype == p2.dtype and torch.equal(p1, p2), n1
+    assert text.out_head.weight is text.emb_dict.weight
+    assert text.trf_blocks[0].att.log_A.dtype == torch.float32
+
+    # VLM, through a file
+    path = tmp_path / "model.safetensors"
+    save_file({k: v.contiguous() for k, v in hf.items()}, str(path))
+    dst = load_qwen3_5_vlm_weights(Qwen3_5VLM(cfg), cfg, source=str(path))
+    out = capsys.readouterr().out
+    assert "WARNING" not in out and "Unexpected" not in out
+    assert f"Loaded {len(hf) - 1}/{len(dst.state_dict())} weights" in out  # everything in the file but the mtp head
+    for (n1, p1), (n2, p2) in zip(src.named_parameters(), dst.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2), n1
+    assert dst.language_model.out_head.weight is dst.language_model.emb_dict.weight
+
+    # a mis-shaped tensor is reported and left alone; no source is an error, not a download
+    bad = dict(hf)
+    bad["model.language_model.layers.0.linear_attn.dt_bias"] = torch.zeros(7)
+    keep = Qwen3_5TextModel(cfg)
+    before = keep.trf_blocks[0].att.dt_bias.detach().clone()
+    load_qwen3_5_text_weights(keep, cfg, source=bad, verbose=False)
+    assert "Shape mismatch: trf_blocks.0.att.dt_bias" in capsys.readouterr().out
+    assert torch.equal(keep.trf_blocks[0].att.dt_bias, before)
+    with pytest.raises(ValueError):
+        load_qwen3_5_vlm_weights(Qwen3_5VLM(cfg), cfg)
