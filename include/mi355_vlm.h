@@ -68,7 +68,8 @@ int mi355_abi_version(void);
  *   bias         fp32 [N] or NULL;  residual  [M,N] with ldr, or NULL (may alias C: accumulate)
  *   workspace    optional fp32 scratch (16-byte aligned) of workspace_bytes: lets problems with few output tiles
  *                and a long K (weight gradients) split K over several workgroups (slabs + reduce); NULL = never split.
- *   tile_hint    0 = choose by shape; 1 = 128x128 tile (4 waves), 2 = 256x256 tile (8 waves), 3 = 256x256, alternating wave groups
+ *   tile_hint    0 = choose by shape; 1 = 128x128 tile (4 waves), 2 = 256x256 tile (8 waves), 3 = 256x256, alternating wave groups,
+ *                4 = 3 with one barrier per phase, 5 = 256x256 as four waves of 128x128 (one per SIMD, accumulators in AGPRs)
  * Requirements: K-contiguous dims multiple of 8 elements (16-byte rows); see DESIGN.md.            */
 int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                     int64_t ldb, void* C, int64_t ldc, int out_dtype, const float* bias, const void* residual,

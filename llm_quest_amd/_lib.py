@@ -98,7 +98,7 @@ _lib = None
 
 def build(verbose=False):
     """Compile libmi355vlm.so in-tree (hipcc --offload-arch=gfx950)."""
-    cmd = ["make", "-C", CSRC, "-j4"]
+    cmd = ["make", "-C", CSRC, "-j8"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("building libmi355vlm.so failed:\n" + res.stdout[-4000:] + res.stderr[-4000:])

@@ -52,6 +52,7 @@ using Cfg128 = TileCfg<128, 128, 2, 2, 64, 2>;      // 68 KiB LDS, 2 workgroups 
 using Cfg256 = TileCfg<256, 256, 2, 4, 64, 2>;      // 136 KiB LDS, 1 workgroup (8 waves) / CU
 using Cfg256a = TileCfg<256, 256, 2, 4, 32, 4>;     // 136 KiB LDS, 4-stage ring, alternating wave groups
 using Cfg256b = TileCfg<256, 256, 2, 4, 32, 5>;     // 160 KiB LDS (all of it), 5-stage ring, ONE barrier per phase (tile hint 4)
+using Cfg256w = TileCfg<256, 256, 2, 2, 32, 4>;     // 128 KiB LDS, FOUR waves of 128x128 (one per SIMD, 512 registers each), tile hint 5
 
 #ifndef GEMM_PROF
 #define GEMM_PROF 0  // profiling builds only: in-kernel cycle stamps of the alternating loop (tools/gemm_prof.py)
@@ -109,6 +110,15 @@ __device__ __forceinline__ void piece_offsets(int wave, int lane, int64_t ld, in
             kneed[j] = kr;
         }
     }
+}
+
+// A pointer every lane agrees on, moved to scalar registers.  The buffer resource of an LDS-DMA must be scalar; a base pointer that went
+// through a select (the SwiGLU-forward row remap picks another B base) otherwise reaches the DMA in vector registers and every piece
+// is wrapped in a readfirstlane waterfall loop.
+__device__ __forceinline__ const bf16_t* uniform_ptr(const bf16_t* ptr) {
+    const unsigned long long v = (unsigned long long)ptr;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const bf16_t*)(((unsigned long long)hi << 32) | lo);
 }
 
 __device__ __forceinline__ void dma_piece(const void* base, unsigned voff, char* lds_dst) {
@@ -202,6 +212,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
             baseB = p.B;
         }
     }
+    baseA = uniform_ptr(baseA);
+    baseB = uniform_ptr(baseB);
     const int64_t stepA = A_TR ? (int64_t)BK * p.lda : BK;
     const int64_t stepB = B_TR ? (int64_t)BK * p.ldb : BK;
 
@@ -304,6 +316,75 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
             }
         }
         extra_barrier = !late;  // the early group balances the late group's extra barrier
+    } else if constexpr (T::NW == 4 && T::BK == 32) {
+        // ---- one wave per SIMD, 128x128 outputs per wave (256 accumulator registers): a third fewer fragment bytes per MFMA than the
+        // 128x64 wave tiles, and nobody to alternate with, so the loads ride in the shadow of the wave's own MFMAs: per K-tile (64 MFMAs)
+        //   phase 0: 32 MFMAs (rows 0-63)   beside the 4 fragment reads of rows 64-127 and the wave's 8 DMA pieces of tile t+3
+        //   counted vmcnt (tile t+1 landed) ; s_barrier
+        //   phase 1: 32 MFMAs (rows 64-127) beside the 12 fragment reads of tile t+1 (its B fragments go to the other register set)
+        // The DMA is issued for every tile number, past the end of K with out-of-range offsets (zero fill into a stage nobody reads),
+        // so the body has no branches and the vmcnt immediate is one constant.
+        static_assert(T::KK == 1 && T::NS == 4 && T::FM == 8 && T::FN == 8 && T::A_PPW == 4 && T::B_PPW == 4, "4-wave loop: 128x128 per wave, 4+4 pieces");
+        constexpr int HM = 4;
+        auto issue_piece = [&](int tl, int stage, int g) {  // piece g (0-3: A, 4-7: B) of this wave's share of tile tl, any tile number
+            const int64_t krem = p.K - (int64_t)tl * BK;
+            if (g < T::A_PPW) {
+                dma_piece(baseA + tl * stepA, (tl < nt && kneedA[g] < krem) ? voffA[g] : OOB, smem + stage * T::STAGE + (wave * T::A_PPW + g) * 1024);
+            } else {
+                const int h = g - T::A_PPW;
+                dma_piece(baseB + tl * stepB, (tl < nt && kneedB[h] < krem) ? voffB[h] : OOB, smem + stage * T::STAGE + T::A_BYTES + (wave * T::B_PPW + h) * 1024);
+            }
+        };
+        // The accumulators are pinned to the accumulation registers by the operand constraint: with the builtin, hipcc keeps part of the
+        // 256 values in vector registers and moves four in and four out around every MFMA (measured: 594 TFLOP/s on the gate-up shape).
+        auto mma = [&](f32x4& c, const bf16x8& av, const bf16x8& bv) {
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(av), "v"(bv));
+        };
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int g = 0; g < 8; ++g) issue_piece(t0 + i, i, g);
+        wait_vmcnt<16>();
+        __builtin_amdgcn_s_barrier();  // tile t0 landed for every wave
+        bf16x8 a0[HM], a1[HM], b[2][T::FN];
+#pragma unroll
+        for (int j = 0; j < T::FN; ++j) b[0][j] = B_TR ? frag_tr<T::BN>(smem + T::A_BYTES, wc0 + j * 16, 0, lane) : frag_rowk<BK>(smem + T::A_BYTES, wc0 + j * 16, 0, lane);
+#pragma unroll
+        for (int i = 0; i < HM; ++i) a0[i] = A_TR ? frag_tr<T::BM>(smem, wr0 + i * 16, 0, lane) : frag_rowk<BK>(smem, wr0 + i * 16, 0, lane);
+        auto body = [&](auto par, int t) {
+            constexpr int CUR = decltype(par)::value;
+            const char* sA = smem + ((t - t0) & 3) * T::STAGE;
+            const char* nA = smem + ((t + 1 - t0) & 3) * T::STAGE;
+            const int nst = (t + 3 - t0) & 3;
+            // -------- phase 0: 8 groups of { 4 MFMAs, 1 DMA piece, (first four) 1 fragment of the lower rows }
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mma(acc[g >> 1][(g & 1) * 4 + q], a0[g >> 1], b[CUR][(g & 1) * 4 + q]);
+                issue_piece(t + 3, nst, g);
+                if (g < HM) a1[g] = A_TR ? frag_tr<T::BM>(sA, wr0 + (HM + g) * 16, 0, lane) : frag_rowk<BK>(sA, wr0 + (HM + g) * 16, 0, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            wait_vmcnt<16>();  // this wave's pieces of tile t+1 have landed (t+2, t+3 in flight)
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // -------- phase 1: 12 groups of { 2 MFMAs, 1 fragment of tile t+1 }, then the last 8 MFMAs
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) mma(acc[HM + (g >> 2)][(g & 3) * 2 + q], a1[g >> 2], b[CUR][(g & 3) * 2 + q]);
+                if (g < T::FN) b[CUR ^ 1][g] = B_TR ? frag_tr<T::BN>(nA + T::A_BYTES, wc0 + g * 16, 0, lane) : frag_rowk<BK>(nA + T::A_BYTES, wc0 + g * 16, 0, lane);
+                else if (g < T::FN + HM) a0[g - T::FN] = A_TR ? frag_tr<T::BM>(nA, wr0 + (g - T::FN) * 16, 0, lane) : frag_rowk<BK>(nA, wr0 + (g - T::FN) * 16, 0, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        int t = t0;
+        for (; t + 1 < nt; t += 2) {
+            body(std::integral_constant<int, 0>{}, t);
+            body(std::integral_constant<int, 1>{}, t + 1);
+        }
+        if (t < nt) body(std::integral_constant<int, 0>{}, t);
+        wait_vmcnt<0>();  // the zero-fill DMAs past the last tile must not land in the epilogue's staging
     } else if constexpr (T::BK == 32) {
         // ---- alternating-group loop (8 waves, BK = 32, NS-stage ring).  Waves 4-7 run ONE barrier behind waves 0-3, so on
         // every SIMD one wave is in its 16-MFMA cluster while its partner is in the load segment (fragment reads, two
@@ -477,182 +558,203 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
     // ---- epilogue: acc -> LDS (fp32, 64x64 per wave at a time) -> coalesced rows ---------------------------------
     __syncthreads();
     float* stg = reinterpret_cast<float*>(smem) + wave * 64 * EPI_LD;
+    // "No fused form" and "this 64x64 sub-block lies inside the matrix and is 16-byte addressable" are resolved once, outside the store
+    // passes: the plain epilogue (with or without bias / residual) gets a straight-line copy of them for interior sub-blocks.  With the kind
+    // tested inside every pass (all fused forms inlined behind run-time branches) the passes were instruction-issue-bound: 22 us per
+    // 256x256 tile with four waves, ~5 us with eight.  The fused forms keep the run-time dispatch (compile time: every extra copy of the
+    // passes costs about a minute over the 48 kernels of this file).
+    const bool aligned_io = ((p.ldc & 7) == 0) && ((p.ldr & 7) == 0 || p.R == nullptr);
+    auto run_epilogue = [&](auto kind_c) __attribute__((always_inline)) {
+        constexpr int KSEL = decltype(kind_c)::value;
+        const int KIND = KSEL >= 0 ? KSEL : p.epilogue;
 #pragma unroll
-    for (int sm = 0; sm < T::WTM / 64; ++sm) {
+        for (int sm = 0; sm < T::WTM / 64; ++sm) {
 #pragma unroll
-        for (int sn = 0; sn < T::WTN / 64; ++sn) {
+            for (int sn = 0; sn < T::WTN / 64; ++sn) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        stg[(i * 16 + (lane >> 4) * 4 + e) * EPI_LD + j * 16 + (lane & 15)] = acc[sm * 4 + i][sn * 4 + j][e];
-            __builtin_amdgcn_wave_barrier();
-            const int64_t gn = n0 + wc0 + sn * 64 + (lane & 7) * 8;
-            const int64_t gm0 = m0 + wr0 + sm * 64;
-            if (p.ksplit > 1) {  // raw fp32 partial sums; residual / conversion happen in splitk_reduce_kernel
-                if constexpr (OUT_DT == MI355_DT_F32) {
-                    float* slab = p.ws + (int64_t)split * p.M * p.N;
+                        for (int e = 0; e < 4; ++e)
+                            stg[(i * 16 + (lane >> 4) * 4 + e) * EPI_LD + j * 16 + (lane & 15)] = acc[sm * 4 + i][sn * 4 + j][e];
+                __builtin_amdgcn_wave_barrier();
+                const int64_t gn = n0 + wc0 + sn * 64 + (lane & 7) * 8;
+                const int64_t gm0 = m0 + wr0 + sm * 64;
+                auto passes = [&](auto full_c) __attribute__((always_inline)) {
+                    constexpr bool FULL = decltype(full_c)::value;
+                    if (p.ksplit > 1) {  // raw fp32 partial sums; residual / conversion happen in splitk_reduce_kernel
+                        if constexpr (OUT_DT == MI355_DT_F32) {
+                            float* slab = p.ws + (int64_t)split * p.M * p.N;
 #pragma unroll
-                    for (int tpass = 0; tpass < 8; ++tpass) {
-                        const int row = tpass * 8 + (lane >> 3);
-                        const int64_t gm = gm0 + row;
-                        if (gm >= p.M || gn >= p.N) continue;  // N % 8 == 0 is required for split-K
-                        *reinterpret_cast<f32x4*>(slab + gm * p.N + gn) = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + (lane & 7) * 8);
-                        *reinterpret_cast<f32x4*>(slab + gm * p.N + gn + 4) = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + (lane & 7) * 8 + 4);
-                    }
-                }
-            } else {
-                const bool vec_ok = (gn + 8 <= p.N) && ((p.ldc & 7) == 0) && ((p.ldr & 7) == 0 || p.R == nullptr);
-#pragma unroll
-                for (int tpass = 0; tpass < 8; ++tpass) {
-                    const int row = tpass * 8 + (lane >> 3);
-                    const int64_t gm = gm0 + row;
-                    if (gm >= p.M || gn >= p.N) continue;
-                    float v[8];
-                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + (lane & 7) * 8);
-                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + (lane & 7) * 8 + 4);
-                    v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3];
-                    v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
-                    const int nvalid = (int)min((int64_t)8, p.N - gn);
-                    if (p.bias) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            if (e < nvalid) v[e] += p.bias[gn + e];
-                    }
-                    if (p.epilogue == MI355_EPI_GELU_ERF) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-                    }
-                    if constexpr (OUT_DT == MI355_DT_BF16) {
-                        bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + gm * p.ldc + gn;
-                        const bf16_t* r = p.R ? reinterpret_cast<const bf16_t*>(p.R) + gm * p.ldr + gn : nullptr;
-                        if (p.epilogue == MI355_EPI_GELU_DUAL_ERF || p.epilogue == MI355_EPI_GELU_DUAL_TANH) {
-                            // v = acc + bias = the pre-activation: C gets it (the backward needs it), R (an OUTPUT here) gets gelu of its bf16 value
-                            u32x4 y1, act;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                y1[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
-                                const float lo = __uint_as_float(y1[e] << 16), hi = __uint_as_float(y1[e] & 0xffff0000u);
-                                act[e] = p.epilogue == MI355_EPI_GELU_DUAL_ERF ? pack_bf2(gelu_val<0>(lo), gelu_val<0>(hi)) : pack_bf2(gelu_val<1>(lo), gelu_val<1>(hi));
+                            for (int tpass = 0; tpass < 8; ++tpass) {
+                                const int row = tpass * 8 + (lane >> 3);
+                                const int64_t gm = gm0 + row;
+                                if (!FULL && (gm >= p.M || gn >= p.N)) continue;  // N % 8 == 0 is required for split-K
+                                *reinterpret_cast<f32x4*>(slab + gm * p.N + gn) = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + (lane & 7) * 8);
+                                *reinterpret_cast<f32x4*>(slab + gm * p.N + gn + 4) = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + (lane & 7) * 8 + 4);
                             }
-                            *reinterpret_cast<u32x4*>(c) = y1;
-                            *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(const_cast<void*>(p.R)) + gm * p.ldr + gn) = act;
-                            continue;
-                        }
-                        if (p.epilogue == MI355_EPI_GELU_BWD_ERF || p.epilogue == MI355_EPI_GELU_BWD_TANH) {
-                            // acc = d(act); R = the forward's pre-activation: C = bf16(acc) * gelu'(R)  (== dgrad GEMM -> mi355_gelu_bwd)
-                            const u32x4 xv = *reinterpret_cast<const u32x4*>(r);
-                            u32x4 o;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float x0 = __uint_as_float(xv[e] << 16), x1 = __uint_as_float(xv[e] & 0xffff0000u);
-                                const float d0 = bf2f(f2bf(v[2 * e])), d1 = bf2f(f2bf(v[2 * e + 1]));
-                                o[e] = p.epilogue == MI355_EPI_GELU_BWD_ERF ? pack_bf2(d0 * gelu_grad<0>(x0), d1 * gelu_grad<0>(x1))
-                                                                             : pack_bf2(d0 * gelu_grad<1>(x0), d1 * gelu_grad<1>(x1));
-                            }
-                            *reinterpret_cast<u32x4*>(c) = o;
-                            continue;
-                        }
-                        if (p.epilogue == MI355_EPI_SWIGLU_FWD) {
-                            // this wave's 64 staging columns = [u (32) | g (32)] of hidden units hid0..hid0+31 (see the DMA plan): lanes 0-3 of each
-                            // row group write u into C[:, hid] and a = u * silu(g) into R[:, hid], lanes 4-7 write g into C[:, N/2 + hid];
-                            // u, g are rounded to bf16 first, so a equals mi355_swiglu_fwd on the stored gate-up output bit for bit.
-                            const int l8 = lane & 7;
-                            const int64_t nh = p.N >> 1;
-                            const int64_t hid = (n0 >> 1) + ((wc0 + sn * 64) >> 6) * 32 + (l8 & 3) * 8;
-                            if (hid >= nh) continue;
-                            bf16_t* gu_row = reinterpret_cast<bf16_t*>(p.C) + gm * p.ldc;
-                            u32x4 own;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) own[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
-                            if (l8 >= 4) {
-                                *reinterpret_cast<u32x4*>(gu_row + nh + hid) = own;
-                                continue;
-                            }
-                            *reinterpret_cast<u32x4*>(gu_row + hid) = own;
-                            const float* gp_ = stg + row * EPI_LD + 32 + l8 * 8;
-                            u32x4 av;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                float a2[2];
-#pragma unroll
-                                for (int hlf = 0; hlf < 2; ++hlf) {
-                                    const float u_ = hlf ? __uint_as_float(own[e] & 0xffff0000u) : __uint_as_float(own[e] << 16);
-                                    const float g_ = bf2f(f2bf(gp_[2 * e + hlf]));
-                                    a2[hlf] = u_ * bf2f(f2bf(g_ / (1.0f + __expf(-g_))));
-                                }
-                                av[e] = pack_bf2(a2[0], a2[1]);
-                            }
-                            *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(const_cast<void*>(p.R)) + gm * p.ldr + hid) = av;
-                            continue;
-                        }
-                        if (p.epilogue == MI355_EPI_SWIGLU_BWD) {
-                            // acc = d(act) for hidden units gn..gn+7; R = the forward's gate-up output [u | g] (ldr = 2N): write
-                            // d(gate-up) = [acc * g*sig(g) | acc * u * sig(g) (1 + g (1 - sig(g)))] into C (ldc = 2N).  acc is rounded to
-                            // bf16 first, so the result equals mi355_swiglu_bwd on the stored bf16 d(act) bit for bit.
-                            const u32x4 uv = *reinterpret_cast<const u32x4*>(r);
-                            const u32x4 gv = *reinterpret_cast<const u32x4*>(r + p.N);
-                            float du[8], dg[8];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                                for (int hlf = 0; hlf < 2; ++hlf) {
-                                    const float u_ = hlf ? __uint_as_float(uv[e] & 0xffff0000u) : __uint_as_float(uv[e] << 16);
-                                    const float g_ = hlf ? __uint_as_float(gv[e] & 0xffff0000u) : __uint_as_float(gv[e] << 16);
-                                    const float d_ = bf2f(f2bf(v[2 * e + hlf]));
-                                    const float sg = 1.0f / (1.0f + __expf(-g_));
-                                    du[2 * e + hlf] = d_ * g_ * sg;
-                                    dg[2 * e + hlf] = d_ * u_ * sg * (1.0f + g_ * (1.0f - sg));
-                                }
-                            }
-                            u32x4 o0, o1;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                o0[e] = pack_bf2(du[2 * e], du[2 * e + 1]);
-                                o1[e] = pack_bf2(dg[2 * e], dg[2 * e + 1]);
-                            }
-                            *reinterpret_cast<u32x4*>(c) = o0;
-                            *reinterpret_cast<u32x4*>(c + p.N) = o1;
-                            continue;
-                        }
-                        if (vec_ok) {
-                            if (r) {
-                                const u32x4 rv = *reinterpret_cast<const u32x4*>(r);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    v[2 * e] += __uint_as_float(rv[e] << 16);
-                                    v[2 * e + 1] += __uint_as_float(rv[e] & 0xffff0000u);
-                                }
-                            }
-                            u32x4 o;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
-                            *reinterpret_cast<u32x4*>(c) = o;
-                        } else {
-                            for (int e = 0; e < nvalid; ++e) c[e] = f2bf(v[e] + (r ? bf2f(r[e]) : 0.f));
                         }
                     } else {
-                        float* c = reinterpret_cast<float*>(p.C) + gm * p.ldc + gn;
-                        const float* r = p.R ? reinterpret_cast<const float*>(p.R) + gm * p.ldr + gn : nullptr;
-                        if (vec_ok) {
-                            f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-                            if (r) {
-                                o0 += *reinterpret_cast<const f32x4*>(r);
-                                o1 += *reinterpret_cast<const f32x4*>(r + 4);
+                        const bool vec_ok = FULL || ((gn + 8 <= p.N) && aligned_io);
+#pragma unroll
+                        for (int tpass = 0; tpass < 8; ++tpass) {
+                            const int row = tpass * 8 + (lane >> 3);
+                            const int64_t gm = gm0 + row;
+                            if (!FULL && (gm >= p.M || gn >= p.N)) continue;
+                            float v[8];
+                            const f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + (lane & 7) * 8);
+                            const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + (lane & 7) * 8 + 4);
+                            v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3];
+                            v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
+                            const int nvalid = FULL ? 8 : (int)min((int64_t)8, p.N - gn);
+                            if (p.bias) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e)
+                                    if (e < nvalid) v[e] += p.bias[gn + e];
                             }
-                            *reinterpret_cast<f32x4*>(c) = o0;
-                            *reinterpret_cast<f32x4*>(c + 4) = o1;
-                        } else {
-                            for (int e = 0; e < nvalid; ++e) c[e] = v[e] + (r ? r[e] : 0.f);
+                            if (KIND == MI355_EPI_GELU_ERF) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+                            }
+                            if constexpr (OUT_DT == MI355_DT_BF16) {
+                                bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + gm * p.ldc + gn;
+                                const bf16_t* r = p.R ? reinterpret_cast<const bf16_t*>(p.R) + gm * p.ldr + gn : nullptr;
+                                if (KIND == MI355_EPI_GELU_DUAL_ERF || KIND == MI355_EPI_GELU_DUAL_TANH) {
+                                    // v = acc + bias = the pre-activation: C gets it (the backward needs it), R (an OUTPUT here) gets gelu of its bf16 value
+                                    u32x4 y1, act;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        y1[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+                                        const float lo = __uint_as_float(y1[e] << 16), hi = __uint_as_float(y1[e] & 0xffff0000u);
+                                        act[e] = KIND == MI355_EPI_GELU_DUAL_ERF ? pack_bf2(gelu_val<0>(lo), gelu_val<0>(hi)) : pack_bf2(gelu_val<1>(lo), gelu_val<1>(hi));
+                                    }
+                                    *reinterpret_cast<u32x4*>(c) = y1;
+                                    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(const_cast<void*>(p.R)) + gm * p.ldr + gn) = act;
+                                    continue;
+                                }
+                                if (KIND == MI355_EPI_GELU_BWD_ERF || KIND == MI355_EPI_GELU_BWD_TANH) {
+                                    // acc = d(act); R = the forward's pre-activation: C = bf16(acc) * gelu'(R)  (== dgrad GEMM -> mi355_gelu_bwd)
+                                    const u32x4 xv = *reinterpret_cast<const u32x4*>(r);
+                                    u32x4 o;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        const float x0 = __uint_as_float(xv[e] << 16), x1 = __uint_as_float(xv[e] & 0xffff0000u);
+                                        const float d0 = bf2f(f2bf(v[2 * e])), d1 = bf2f(f2bf(v[2 * e + 1]));
+                                        o[e] = KIND == MI355_EPI_GELU_BWD_ERF ? pack_bf2(d0 * gelu_grad<0>(x0), d1 * gelu_grad<0>(x1))
+                                                                                     : pack_bf2(d0 * gelu_grad<1>(x0), d1 * gelu_grad<1>(x1));
+                                    }
+                                    *reinterpret_cast<u32x4*>(c) = o;
+                                    continue;
+                                }
+                                if (KIND == MI355_EPI_SWIGLU_FWD) {
+                                    // this wave's 64 staging columns = [u (32) | g (32)] of hidden units hid0..hid0+31 (see the DMA plan): lanes 0-3 of each
+                                    // row group write u into C[:, hid] and a = u * silu(g) into R[:, hid], lanes 4-7 write g into C[:, N/2 + hid];
+                                    // u, g are rounded to bf16 first, so a equals mi355_swiglu_fwd on the stored gate-up output bit for bit.
+                                    const int l8 = lane & 7;
+                                    const int64_t nh = p.N >> 1;
+                                    const int64_t hid = (n0 >> 1) + ((wc0 + sn * 64) >> 6) * 32 + (l8 & 3) * 8;
+                                    if (hid >= nh) continue;
+                                    bf16_t* gu_row = reinterpret_cast<bf16_t*>(p.C) + gm * p.ldc;
+                                    u32x4 own;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) own[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+                                    if (l8 >= 4) {
+                                        *reinterpret_cast<u32x4*>(gu_row + nh + hid) = own;
+                                        continue;
+                                    }
+                                    *reinterpret_cast<u32x4*>(gu_row + hid) = own;
+                                    const float* gp_ = stg + row * EPI_LD + 32 + l8 * 8;
+                                    u32x4 av;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        float a2[2];
+#pragma unroll
+                                        for (int hlf = 0; hlf < 2; ++hlf) {
+                                            const float u_ = hlf ? __uint_as_float(own[e] & 0xffff0000u) : __uint_as_float(own[e] << 16);
+                                            const float g_ = bf2f(f2bf(gp_[2 * e + hlf]));
+                                            a2[hlf] = u_ * bf2f(f2bf(g_ / (1.0f + __expf(-g_))));
+                                        }
+                                        av[e] = pack_bf2(a2[0], a2[1]);
+                                    }
+                                    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(const_cast<void*>(p.R)) + gm * p.ldr + hid) = av;
+                                    continue;
+                                }
+                                if (KIND == MI355_EPI_SWIGLU_BWD) {
+                                    // acc = d(act) for hidden units gn..gn+7; R = the forward's gate-up output [u | g] (ldr = 2N): write
+                                    // d(gate-up) = [acc * g*sig(g) | acc * u * sig(g) (1 + g (1 - sig(g)))] into C (ldc = 2N).  acc is rounded to
+                                    // bf16 first, so the result equals mi355_swiglu_bwd on the stored bf16 d(act) bit for bit.
+                                    const u32x4 uv = *reinterpret_cast<const u32x4*>(r);
+                                    const u32x4 gv = *reinterpret_cast<const u32x4*>(r + p.N);
+                                    float du[8], dg[8];
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                                        for (int hlf = 0; hlf < 2; ++hlf) {
+                                            const float u_ = hlf ? __uint_as_float(uv[e] & 0xffff0000u) : __uint_as_float(uv[e] << 16);
+                                            const float g_ = hlf ? __uint_as_float(gv[e] & 0xffff0000u) : __uint_as_float(gv[e] << 16);
+                                            const float d_ = bf2f(f2bf(v[2 * e + hlf]));
+                                            const float sg = 1.0f / (1.0f + __expf(-g_));
+                                            du[2 * e + hlf] = d_ * g_ * sg;
+                                            dg[2 * e + hlf] = d_ * u_ * sg * (1.0f + g_ * (1.0f - sg));
+                                        }
+                                    }
+                                    u32x4 o0, o1;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        o0[e] = pack_bf2(du[2 * e], du[2 * e + 1]);
+                                        o1[e] = pack_bf2(dg[2 * e], dg[2 * e + 1]);
+                                    }
+                                    *reinterpret_cast<u32x4*>(c) = o0;
+                                    *reinterpret_cast<u32x4*>(c + p.N) = o1;
+                                    continue;
+                                }
+                                if (vec_ok) {
+                                    if (r) {
+                                        const u32x4 rv = *reinterpret_cast<const u32x4*>(r);
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) {
+                                            v[2 * e] += __uint_as_float(rv[e] << 16);
+                                            v[2 * e + 1] += __uint_as_float(rv[e] & 0xffff0000u);
+                                        }
+                                    }
+                                    u32x4 o;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) o[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+                                    *reinterpret_cast<u32x4*>(c) = o;
+                                } else {
+                                    for (int e = 0; e < nvalid; ++e) c[e] = f2bf(v[e] + (r ? bf2f(r[e]) : 0.f));
+                                }
+                            } else {
+                                float* c = reinterpret_cast<float*>(p.C) + gm * p.ldc + gn;
+                                const float* r = p.R ? reinterpret_cast<const float*>(p.R) + gm * p.ldr + gn : nullptr;
+                                if (vec_ok) {
+                                    f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                                    if (r) {
+                                        o0 += *reinterpret_cast<const f32x4*>(r);
+                                        o1 += *reinterpret_cast<const f32x4*>(r + 4);
+                                    }
+                                    *reinterpret_cast<f32x4*>(c) = o0;
+                                    *reinterpret_cast<f32x4*>(c + 4) = o1;
+                                } else {
+                                    for (int e = 0; e < nvalid; ++e) c[e] = v[e] + (r ? r[e] : 0.f);
+                                }
+                            }
                         }
                     }
+                };
+                if constexpr (KSEL >= 0) {
+                    if (aligned_io && gm0 + 64 <= p.M && n0 + wc0 + sn * 64 + 64 <= p.N) passes(std::true_type{});
+                    else passes(std::false_type{});
+                } else {
+                    passes(std::false_type{});
                 }
+                __builtin_amdgcn_wave_barrier();  // the staging area is rewritten by the next 64x64 sub-block
             }
-            __builtin_amdgcn_wave_barrier();  // the staging area is rewritten by the next 64x64 sub-block
         }
-    }
+    };
+    if (p.epilogue == MI355_EPI_NONE) run_epilogue(std::integral_constant<int, MI355_EPI_NONE>{});
+    else run_epilogue(std::integral_constant<int, -1>{});  // fused forms: kind read at run time, bounds checked per row
 }
 
 template <class T, bool A_TR, bool B_TR, int OUT_DT>
@@ -826,6 +928,41 @@ __global__ __launch_bounds__(256) void colsum_kernel(int64_t M, int64_t N, const
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------- translation-unit split
+// This file is compiled once per tile configuration (-DGEMM_PART=1..5: that configuration's kernels behind two bridge functions) and once
+// for the entry points (-DGEMM_PART=0), so the objects build in parallel; parameter blocks cross the bridge as untyped pointers (every part
+// is this same source, so the layouts agree).  Without -DGEMM_PART everything lands in one object.
+#ifndef GEMM_PART
+#define GEMM_PART -1
+#endif
+#define GEMM_BRIDGE_DECL(N)                                                                                                                       \
+    extern "C" __attribute__((visibility("hidden"))) int mi355_gemm_part##N(int form, const void* params, int out_dtype, void* ws, int64_t ws_bytes, void* stream); \
+    extern "C" __attribute__((visibility("hidden"))) int mi355_gemm_grouped_part##N(int form, void* table, int out_dtype, void* stream);
+#define GEMM_BRIDGE_DEF(N, CFG)                                                                                                                   \
+    extern "C" int mi355_gemm_part##N(int form, const void* params, int out_dtype, void* ws, int64_t ws_bytes, void* stream) {                     \
+        return launch_form<CFG>(form, *static_cast<const GemmParams*>(params), out_dtype, ws, ws_bytes, (hipStream_t)stream);                      \
+    }                                                                                                                                             \
+    extern "C" int mi355_gemm_grouped_part##N(int form, void* table, int out_dtype, void* stream) {                                                \
+        return launch_grouped_form<CFG>(form, *static_cast<GroupTable*>(table), out_dtype, (hipStream_t)stream);                                   \
+    }
+GEMM_BRIDGE_DECL(1) GEMM_BRIDGE_DECL(2) GEMM_BRIDGE_DECL(3) GEMM_BRIDGE_DECL(4) GEMM_BRIDGE_DECL(5)
+#if GEMM_PART == 1 || GEMM_PART == -1
+GEMM_BRIDGE_DEF(1, Cfg128)
+#endif
+#if GEMM_PART == 2 || GEMM_PART == -1
+GEMM_BRIDGE_DEF(2, Cfg256)
+#endif
+#if GEMM_PART == 3 || GEMM_PART == -1
+GEMM_BRIDGE_DEF(3, Cfg256a)
+#endif
+#if GEMM_PART == 4 || GEMM_PART == -1
+GEMM_BRIDGE_DEF(4, Cfg256b)
+#endif
+#if GEMM_PART == 5 || GEMM_PART == -1
+GEMM_BRIDGE_DEF(5, Cfg256w)
+#endif
+
+#if GEMM_PART <= 0
 #if GEMM_PROF
 extern "C" int mi355_debug_gemm_prof(unsigned long long* out, int reset) {
     if (hipDeviceSynchronize() != hipSuccess) return 1;
@@ -862,7 +999,7 @@ extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const 
                       "mi355_gemm_bf16(SwiGLU backward epilogue): bf16 output [M, 2N] (ldc >= 2N), residual = the forward gate-up output [M, 2N], N %% 8 == 0, no bias");
     const int ablate = tile_hint >> 8;
     tile_hint &= 0xff;
-    MI355_REQUIRE(tile_hint >= 0 && tile_hint <= 4, "mi355_gemm_bf16: tile_hint must be 0 (auto), 1 (128x128), 2 (256x256), 3 (256x256, alternating wave groups) or 4 (3 with one barrier per phase)");
+    MI355_REQUIRE(tile_hint >= 0 && tile_hint <= 5, "mi355_gemm_bf16: tile_hint must be 0 (auto), 1 (128x128), 2 (256x256), 3 (256x256, alternating wave groups), 4 (3 with one barrier per phase) or 5 (256x256, four waves of 128x128)");
     GemmParams p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.bias = bias; p.R = residual;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
@@ -888,10 +1025,11 @@ extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const 
         else cfg = 3;
     }
     switch (cfg) {
-        case 2: return launch_form<Cfg256>(form, p, out_dtype, workspace, workspace_bytes, s);
-        case 3: return launch_form<Cfg256a>(form, p, out_dtype, workspace, workspace_bytes, s);
-        case 4: return launch_form<Cfg256b>(form, p, out_dtype, workspace, workspace_bytes, s);
-        default: return launch_form<Cfg128>(form, p, out_dtype, workspace, workspace_bytes, s);
+        case 2: return mi355_gemm_part2(form, &p, out_dtype, workspace, workspace_bytes, s);
+        case 3: return mi355_gemm_part3(form, &p, out_dtype, workspace, workspace_bytes, s);
+        case 4: return mi355_gemm_part4(form, &p, out_dtype, workspace, workspace_bytes, s);
+        case 5: return mi355_gemm_part5(form, &p, out_dtype, workspace, workspace_bytes, s);
+        default: return mi355_gemm_part1(form, &p, out_dtype, workspace, workspace_bytes, s);
     }
 }
 
@@ -919,9 +1057,9 @@ extern "C" int mi355_gemm_bf16_grouped(int form, int count, const mi355_gemm_pro
     // 256x256 tiles (one workgroup per CU) once they cover most of the chip; otherwise 128x128 (two per CU, 4x the tiles)
     const int cfg = tile_hint ? tile_hint : ((small || tiles256 < 160) ? 1 : 3);
     hipStream_t s = (hipStream_t)stream;
-    if (cfg == 4) return launch_grouped_form<Cfg256b>(form, tbl, out_dtype, s);
-    if (cfg == 3) return launch_grouped_form<Cfg256a>(form, tbl, out_dtype, s);
-    return launch_grouped_form<Cfg128>(form, tbl, out_dtype, s);
+    if (cfg == 4) return mi355_gemm_grouped_part4(form, &tbl, out_dtype, s);
+    if (cfg == 3) return mi355_gemm_grouped_part3(form, &tbl, out_dtype, s);
+    return mi355_gemm_grouped_part1(form, &tbl, out_dtype, s);
 }
 
 extern "C" int mi355_colsum(int64_t M, int64_t N, const void* X, int x_dtype, int64_t ldx, float* out, int accumulate,
@@ -943,3 +1081,4 @@ extern "C" int mi355_colsum(int64_t M, int64_t N, const void* X, int x_dtype, in
     MI355_LAUNCH_CHECK("mi355_colsum");
     return 0;
 }
+#endif  // GEMM_PART <= 0
