@@ -571,7 +571,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
         // paid once per tile instead of in every store pass (measured: +7.6 us per 256x256 tile on eight waves, +17 us on four).  NT only:
         // that is where the step's residual adds are (out-projection, down-projection); in the NN / TN kernels the 38 extra registers of the
         // look-ahead changed the main loop's allocation and cost 1.2 ms/step each in the per-kernel profile, for a path they never take.
-        constexpr bool RES_AHEAD = KSEL >= 0 && OUT_DT == MI355_DT_BF16 && !A_TR && !B_TR;
+        constexpr bool RES_AHEAD = KSEL == MI355_EPI_NONE && OUT_DT == MI355_DT_BF16 && !A_TR && !B_TR;
         constexpr int SUBS_N = T::WTN / 64, SUBS = (T::WTM / 64) * SUBS_N;
         const bool res_ahead = RES_AHEAD && p.R != nullptr && aligned_io && p.ksplit == 1;
         [[maybe_unused]] u32x4 rnext[8];
@@ -779,8 +779,19 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
             }
         }
     };
-    if (p.epilogue == MI355_EPI_NONE) run_epilogue(std::integral_constant<int, MI355_EPI_NONE>{});
-    else run_epilogue(std::integral_constant<int, -1>{});  // fused forms: kind read at run time, bounds checked per row
+    // a third copy of the passes for the SwiGLU-forward form (231.9 vs 233.6 ms/step); not on the 4-wave tile, where a third copy of its four
+    // sub-blocks stops the unroller and the accumulators land in scratch
+    constexpr bool SWIGLU_FWD_COPY = !A_TR && !B_TR && OUT_DT == MI355_DT_BF16 && T::NW == 8;
+    constexpr bool SWIGLU_BWD_COPY = !A_TR && B_TR && OUT_DT == MI355_DT_BF16 && T::NW == 8;  // the down-projection's dgrad
+    if (p.epilogue == MI355_EPI_NONE) {
+        run_epilogue(std::integral_constant<int, MI355_EPI_NONE>{});
+    } else if (SWIGLU_FWD_COPY && p.epilogue == MI355_EPI_SWIGLU_FWD) {
+        if constexpr (SWIGLU_FWD_COPY) run_epilogue(std::integral_constant<int, MI355_EPI_SWIGLU_FWD>{});  // the step's largest forward GEMM
+    } else if (SWIGLU_BWD_COPY && p.epilogue == MI355_EPI_SWIGLU_BWD) {
+        if constexpr (SWIGLU_BWD_COPY) run_epilogue(std::integral_constant<int, MI355_EPI_SWIGLU_BWD>{});
+    } else {
+        run_epilogue(std::integral_constant<int, -1>{});  // other fused forms: kind read at run time, bounds checked per row
+    }
 }
 
 template <class T, bool A_TR, bool B_TR, int OUT_DT>
