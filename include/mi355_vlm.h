@@ -157,6 +157,11 @@ int mi355_embedding_fwd(int64_t tokens, int width, int64_t vocab, const int64_t*
 int mi355_embedding_bwd(int64_t tokens, int width, int64_t vocab, const int64_t* ids, const void* dout, int64_t ldd,
                         float* dtable_f32, void* stream);
 
+/* y[c][r] = x[r][c], bf16, pitches in elements.  rows, cols, ldx, ldy multiples of 8; pointers 16-byte aligned.  The backward of a Linear
+ * (reference: every nn.Linear on the path, e.g. llm_quest/qwen/qwen3/qwen3_transformer_block.py:7-53) uses it once per weight so that the
+ * dgrad GEMM dX = dY W reads W^T in the K-contiguous NT form.                                                                              */
+int mi355_transpose_bf16(int64_t rows, int64_t cols, const void* x, int64_t ldx, void* y, int64_t ldy, void* stream);
+
 /* Strided 2-D copy (early-fusion concat, vlm_engine.py:114; logits/hidden row slicing): bit-exact.
  * dst[r, 0:width] = src[r, 0:width] for r in [0, rows), element size elem_bytes. */
 int mi355_copy2d(int64_t rows, int64_t width_bytes, const void* src, int64_t src_pitch_bytes, void* dst,

@@ -296,6 +296,32 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(int64_t tokens, int 
 }
 
 // ------------------------------------------------------------------------------------------- strided copy
+// y[c][r] = x[r][c] for a bf16 matrix, 64x64 tiles through LDS: 16-byte loads along x's rows, 16-byte stores along y's rows.
+// Used once per weight and backward pass: dgrad GEMMs then read W^T with K contiguous (NT form) instead of the K-strided NN form.
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(int64_t rows, int64_t cols, const unsigned short* __restrict__ x, int64_t ldx,
+                                                             unsigned short* __restrict__ y, int64_t ldy) {
+    __shared__ unsigned short t[64][72];  // [c][r], row pitch 144 B: 16-byte aligned rows, bank-spread columns
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int r = (tid >> 3) + h * 32, ch = tid & 7;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (r0 + r < rows && c0 + ch * 8 < cols) v = *reinterpret_cast<const u32x4*>(x + (r0 + r) * ldx + c0 + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            t[ch * 8 + 2 * e][r] = (unsigned short)(v[e] & 0xffffu);
+            t[ch * 8 + 2 * e + 1][r] = (unsigned short)(v[e] >> 16);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int c = (tid >> 3) + h * 32, rh = tid & 7;
+        if (c0 + c < cols && r0 + rh * 8 < rows) *reinterpret_cast<u32x4*>(y + (c0 + c) * ldy + r0 + rh * 8) = *reinterpret_cast<const u32x4*>(&t[c][rh * 8]);
+    }
+}
+
 __global__ __launch_bounds__(256) void copy2d_kernel(int64_t rows, int64_t wvec, const char* __restrict__ src, int64_t sp,
                                                      char* __restrict__ dst, int64_t dp) {
     const int64_t total = rows * wvec;
@@ -529,6 +555,17 @@ extern "C" int mi355_embedding_bwd(int64_t tokens, int width, int64_t vocab, con
     MI355_REQUIRE(tokens > 0 && width > 0 && ids && dout && dtable_f32, "mi355_embedding_bwd: bad arguments");
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3(grid_for(tokens, 4)), dim3(256), 0, STREAM, tokens, width, vocab, ids, (const bf16_t*)dout, ldd, dtable_f32);
     MI355_LAUNCH_CHECK("mi355_embedding_bwd");
+    return 0;
+}
+
+extern "C" int mi355_transpose_bf16(int64_t rows, int64_t cols, const void* x, int64_t ldx, void* y, int64_t ldy, void* stream) {
+    MI355_REQUIRE(rows > 0 && cols > 0 && x && y, "mi355_transpose_bf16: bad arguments");
+    MI355_REQUIRE(((rows | cols | ldx | ldy) & 7) == 0 && ldx >= cols && ldy >= rows && (((uintptr_t)x | (uintptr_t)y) & 15) == 0,
+                  "mi355_transpose_bf16: rows, cols and both pitches must be multiples of 8 elements, pointers 16-byte aligned");
+    MI355_REQUIRE((rows + 63) / 64 <= 65535, "mi355_transpose_bf16: too many rows");
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64)), dim3(256), 0, STREAM, rows, cols,
+                       (const unsigned short*)x, ldx, (unsigned short*)y, ldy);
+    MI355_LAUNCH_CHECK("mi355_transpose_bf16");
     return 0;
 }
 

@@ -22,6 +22,8 @@ import os
 
 _TILE_OVERRIDE = int(os.environ.get("MI355_GEMM_TILE", "0"))  # profiling knob: force a GEMM tile configuration
 _TILE_BY_FORM = {f: int(os.environ.get("MI355_GEMM_TILE_" + n, "0")) for f, n in ((L.GEMM_NT, "NT"), (L.GEMM_NN, "NN"), (L.GEMM_TN, "TN"))}
+DGRAD_NT = os.environ.get("MI355_DGRAD_NT", "1") != "0"  # 0: dgrad GEMMs in the NN form on the weight as stored (A/B measurements)
+DGRAD_NT_MIN_ROWS = 4096  # below this the transpose pass is not paid back
 _WS = {}
 WS_BYTES = 512 << 20  # split-K scratch per device (fp32 slabs of the largest weight-gradient GEMM)
 
@@ -183,6 +185,11 @@ def gemm_dgrad_swiglu_bwd(dy, w, gu, tile=0):
     if dy.dtype != BF16 or w.dtype != BF16 or gu.dtype != BF16 or w.shape[0] != Kd or not gu.is_contiguous() or tuple(gu.shape) != (M, 2 * F):
         raise ValueError("gemm_dgrad_swiglu_bwd: dY [M, N_out], W [N_out, F], gate-up output contiguous [M, 2F], all bf16")
     out = torch.empty_like(gu)
+    if DGRAD_NT and M >= DGRAD_NT_MIN_ROWS:
+        wt = transpose(w)  # [F, N_out]: the same product in the K-contiguous form
+        L.call("mi355_gemm_bf16", L.GEMM_NT, M, F, Kd, L.ptr(dy), dy.stride(0), L.ptr(wt), wt.stride(0), L.ptr(out), out.stride(0), L.DT_BF16, None,
+               L.ptr(gu), gu.stride(0), L.EPI_SWIGLU_BWD, None, 0, tile or _TILE_BY_FORM[L.GEMM_NT] or _TILE_OVERRIDE)
+        return out
     L.call("mi355_gemm_bf16", L.GEMM_NN, M, F, Kd, L.ptr(dy), dy.stride(0), L.ptr(w), w.stride(0), L.ptr(out), out.stride(0), L.DT_BF16, None,
            L.ptr(gu), gu.stride(0), L.EPI_SWIGLU_BWD, None, 0, tile or _TILE_BY_FORM[L.GEMM_NN] or _TILE_OVERRIDE)
     return out
@@ -361,6 +368,32 @@ def embedding_bwd(ids, dout, dtable_f32):
     if dtable_f32.dtype != F32 or not dtable_f32.is_contiguous() or dout.shape[0] != flat.numel():
         raise ValueError("embedding_bwd: accumulator must be contiguous fp32 and dout must have one row per id")
     L.call("mi355_embedding_bwd", flat.numel(), dout.shape[1], dtable_f32.shape[0], L.ptr(flat), L.ptr(dout), dout.stride(0), L.ptr(dtable_f32))
+
+
+def transpose(x, out=None):
+    """out[c, r] = x[r, c] for a bf16 matrix (row-strided views allowed; rows, cols and pitches multiples of 8)."""
+    L.require_gpu(x, out)
+    _rowmajor(x, "x")
+    if x.dtype != BF16:
+        raise TypeError("transpose: bf16 only")
+    R, C = x.shape
+    if out is None:
+        out = torch.empty((C, R), dtype=BF16, device=x.device)
+    _rowmajor(out, "out")
+    if tuple(out.shape) != (C, R) or out.dtype != BF16:
+        raise ValueError("transpose: output must be bf16 [cols, rows]")
+    L.call("mi355_transpose_bf16", R, C, L.ptr(x), x.stride(0), L.ptr(out), out.stride(0))
+    return out
+
+
+def dgrad(dy, w, out=None):
+    """dX = dY W for a Linear with weight W [N_out, N_in].  Above ``DGRAD_NT_MIN_ROWS`` token rows W is transposed first (one pass over the
+    weight, 63 MB per transformer block) and the product runs in the K-contiguous NT form, whose main loop needs no transposing LDS reads;
+    same-box A/B in DESIGN.md.  The result is the same sum in the same order per K-tile, bit-identical to the NN form."""
+    M = dy.shape[0]
+    if DGRAD_NT and M >= DGRAD_NT_MIN_ROWS and (w.shape[0] & 7) == 0 and (w.shape[1] & 7) == 0:
+        return gemm(L.GEMM_NT, dy, transpose(w), out=out)
+    return gemm(L.GEMM_NN, dy, w, out=out)
 
 
 def copy2d(src, dst):

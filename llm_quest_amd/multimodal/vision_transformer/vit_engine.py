@@ -48,7 +48,7 @@ class _AdapterFn(torch.autograd.Function):
             ops._wgrad(arena, lins[0].weight, None, dy2, x2)
             bias_grad(lins[0], dy2)
             if ctx.need_dx:
-                dx = K.gemm(L.GEMM_NN, dy2, lins[0].weight)
+                dx = K.dgrad(dy2, lins[0].weight)
         else:
             x2, y1, a = ctx.saved
             ops._wgrad(arena, lins[1].weight, None, dy2, a)
@@ -57,7 +57,7 @@ class _AdapterFn(torch.autograd.Function):
             ops._wgrad(arena, lins[0].weight, None, dy1, x2)
             bias_grad(lins[0], dy1)
             if ctx.need_dx:
-                dx = K.gemm(L.GEMM_NN, dy1, lins[0].weight)
+                dx = K.dgrad(dy1, lins[0].weight)
         ctx.saved = None
         hook = getattr(mod, "_grad_ready", None)
         if hook is not None:

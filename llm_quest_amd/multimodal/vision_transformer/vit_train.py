@@ -129,7 +129,7 @@ def vit_backward(m, saved, dout):
             K.copy2d(wc, wc_p[:ncls])
         else:
             dl_p, wc_p = dlog, wc
-        dcls_n = K.gemm(L.GEMM_NN, dl_p, wc_p)
+        dcls_n = K.dgrad(dl_p, wc_p)
         if m.classifier.weight.requires_grad:
             gw = K.gemm(L.GEMM_TN, dl_p, cls_n, out_dtype=F32)  # [pad, d]
             _acc(m.classifier.weight, gw[:ncls].contiguous())
@@ -147,20 +147,20 @@ def vit_backward(m, saved, dout):
         dy1 = K.gemm_dgrad_gelu_bwd(dx3b, bf16_cached(ffn, "w2", [ffn.layers[2].weight]), y1)  # GELU backward in the dgrad epilogue
         _wgrad(ffn.layers[2].weight, dx3b, f, wg)
         _bgrad(ffn.layers[2].bias, dx3b)
-        dh2 = K.gemm(L.GEMM_NN, dy1, bf16_cached(ffn, "w1", [ffn.layers[0].weight]))
+        dh2 = K.dgrad(dy1, bf16_cached(ffn, "w1", [ffn.layers[0].weight]))
         _wgrad(ffn.layers[0].weight, dy1, h2, wg)
         _bgrad(ffn.layers[0].bias, dy1)
         dx2 = _ln_bwd(blk.ln_2, x2, mean2, rsig2, dh2, dx)
         # ---- attention half
         dx2b = K.cast(dx2, BF16)
-        dctx = K.gemm(L.GEMM_NN, dx2b, bf16_cached(att, "wo", [att.out_proj.weight]))
+        dctx = K.dgrad(dx2b, bf16_cached(att, "wo", [att.out_proj.weight]))
         _wgrad(att.out_proj.weight, dx2b, ctx, wg)
         _bgrad(att.out_proj.bias, dx2b)
         dqkv = torch.empty_like(qkv)
         K.attn_bwd(qkv[:, :d], qkv[:, d : 2 * d], qkv[:, 2 * d :], ctx, dctx, lse, B, S, H, H, Dh,
                    dqkv[:, :d], dqkv[:, d : 2 * d], dqkv[:, 2 * d :], key_mask=None, causal=False, scale=att.att_scaling)
         wqkv = bf16_cached(att, "wqkv", [att.w_queries.weight, att.w_keys.weight, att.w_values.weight])
-        dh1 = K.gemm(L.GEMM_NN, dqkv, wqkv)
+        dh1 = K.dgrad(dqkv, wqkv)
         for i, lin in enumerate((att.w_queries, att.w_keys, att.w_values)):
             _wgrad(lin.weight, dqkv[:, i * d : (i + 1) * d], h1, wg)
         if att.w_queries.bias is not None:

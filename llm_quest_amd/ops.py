@@ -128,7 +128,7 @@ def attention_backward(att, arena, h1, ctx, saved, dctx, rt, defer=None):
         if view is not None:
             K.add_f32_to_bf16(g.contiguous(), view if acc else None, view)
     wqkv = arena.fused(att.w_queries.weight, att.w_values.weight)
-    dh1 = K.gemm(L.GEMM_NN, dqkv, wqkv)
+    dh1 = K.dgrad(dqkv, wqkv)
     _wgrad(arena, att.w_queries.weight, att.w_values.weight, dqkv, h1, defer)
     return dh1
 
@@ -162,15 +162,15 @@ def block_backward(blk, saved, dx3, rt):
     if FUSE_SWIGLU_BWD:  # d(act) never leaves the accumulators: the activation's backward is the dgrad GEMM's epilogue
         dgu = K.gemm_dgrad_swiglu_bwd(dx3, ffn.lin2.weight, gu)
     else:
-        dgu = K.swiglu_bwd(gu, K.gemm(L.GEMM_NN, dx3, ffn.lin2.weight), F_)
+        dgu = K.swiglu_bwd(gu, K.dgrad(dx3, ffn.lin2.weight), F_)
     _wgrad(arena, ffn.lin2.weight, None, dx3, a, wg)
     wgu = arena.fused(ffn.lin1.weight, ffn.lin_gate.weight)
-    dh2 = K.gemm(L.GEMM_NN, dgu, wgu)
+    dh2 = K.dgrad(dgu, wgu)
     _wgrad(arena, ffn.lin1.weight, ffn.lin_gate.weight, dgu, h2, wg)
     gview, gacc = _vecgrad(arena, blk.norm2.weight)
     dx2, _ = K.rmsnorm_bwd(x2, blk.norm2.weight, rstd2, dh2, dres=dx3, dw_out=gview, dw_accumulate=gacc)
     # ---- attention half
-    dctx = K.gemm(L.GEMM_NN, dx2, att.out_proj.weight)
+    dctx = K.dgrad(dx2, att.out_proj.weight)
     _wgrad(arena, att.out_proj.weight, None, dx2, ctx, wg)
     dh1 = attention_backward(att, arena, h1, ctx, att_saved, dctx, rt, wg)
     gview, gacc = _vecgrad(arena, blk.norm1.weight)
@@ -257,7 +257,7 @@ class LinearFn(torch.autograd.Function):
         w = ctx.weight
         dy2 = dy.reshape(-1, w.shape[0])
         dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
-        dx = K.gemm(L.GEMM_NN, dy2, w)
+        dx = K.dgrad(dy2, w)
         _wgrad(arena_for(ctx.owner), w, None, dy2, ctx.x2)
         return dx.view(ctx.shp), None, None, None, None
 
@@ -331,7 +331,7 @@ class LMHeadLossFn(torch.autograd.Function):
             raise RuntimeError("LMHeadLossFn: backward through a forward that ran without grad mode")
         w = ctx.weight
         gs = g.to(F32).reshape(1)
-        dh = K.gemm(L.GEMM_NN, dl, w)
+        dh = K.dgrad(dl, w)
         dh = K.scale_bf16(dh, gs, out=dh)
         if w.requires_grad:
             view, acc = arena_for(ctx.owner).grad_target(w)

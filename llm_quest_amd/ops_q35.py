@@ -124,7 +124,7 @@ def gated_attention_backward(att, arena, h1, saved, dgated, rt, defer=None):
     _bf16_vec_grad(arena, att.q_norm.scale, dwq)
     _bf16_vec_grad(arena, att.k_norm.scale, dwk)
     w = arena.fused(att.w_queries_gate.weight, att.w_values.weight)
-    dh1 = K.gemm(L.GEMM_NN, dproj, w)
+    dh1 = K.dgrad(dproj, w)
     _wgrad(arena, att.w_queries_gate.weight, att.w_values.weight, dproj, h1, defer)
     return dh1
 
@@ -168,7 +168,7 @@ def gdn_backward(att, arena, saved, dgated, rt, defer=None):
     _f32_param_grad(att.log_A, dlog_A)
     _bf16_vec_grad(arena, att.dt_bias, ddtb)
     w = arena.fused(att.w_qkv.weight, att.w_alpha.weight)
-    dh1 = K.gemm(L.GEMM_NN, dproj, w)
+    dh1 = K.dgrad(dproj, w)
     _wgrad(arena, att.w_qkv.weight, att.w_alpha.weight, dproj, h1, defer)
     if rt.key_mask is not None:
         dh1 = Q.rowmask(dh1, rt.key_mask.view(-1))
@@ -209,14 +209,14 @@ def block_backward(blk, saved, dx3, rt):
     if FUSE_SWIGLU_BWD:  # d(act) never leaves the accumulators: the activation's backward is the dgrad GEMM's epilogue
         dgu = K.gemm_dgrad_swiglu_bwd(dx3, ffn.lin2.weight, gu)
     else:
-        dgu = K.swiglu_bwd(gu, K.gemm(L.GEMM_NN, dx3, ffn.lin2.weight), F_)
+        dgu = K.swiglu_bwd(gu, K.dgrad(dx3, ffn.lin2.weight), F_)
     _wgrad(arena, ffn.lin2.weight, None, dx3, a, wg)
-    dh2 = K.gemm(L.GEMM_NN, dgu, arena.fused(ffn.lin1.weight, ffn.lin_gate.weight))
+    dh2 = K.dgrad(dgu, arena.fused(ffn.lin1.weight, ffn.lin_gate.weight))
     _wgrad(arena, ffn.lin1.weight, ffn.lin_gate.weight, dgu, h2, wg)
     gview, gacc = _vecgrad(arena, blk.norm2.scale)
     dx2, _ = K.rmsnorm_bwd(x2, w2, rstd2, dh2, dres=dx3, dw_out=gview, dw_accumulate=gacc)
     # ---- token-mixer half
-    dmix = K.gemm(L.GEMM_NN, dx2, att.out_proj.weight)
+    dmix = K.dgrad(dx2, att.out_proj.weight)
     _wgrad(arena, att.out_proj.weight, None, dx2, mix, wg)
     if blk.is_linear:
         dh1 = gdn_backward(att, arena, att_saved, dmix, rt, wg)
@@ -287,7 +287,7 @@ class MixerFn(torch.autograd.Function):
         h1, mix, saved = ctx.saved
         dy2 = dy.reshape(B * S, -1)
         dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
-        dmix = K.gemm(L.GEMM_NN, dy2, att.out_proj.weight)
+        dmix = K.dgrad(dy2, att.out_proj.weight)
         _wgrad(arena, att.out_proj.weight, None, dy2, mix)
         dh1 = gdn_backward(att, arena, saved, dmix, ctx.rt) if att.is_linear else gated_attention_backward(att, arena, h1, saved, dmix, ctx.rt)
         ctx.saved = None

@@ -41,7 +41,7 @@ class _AttentionFn(torch.autograd.Function):
         arena = ops.arena_for(att)
         h1, c, saved = ctx.saved
         dy2 = dy.reshape(B * S, -1).contiguous()
-        dctx = K.gemm(L.GEMM_NN, dy2, att.out_proj.weight)
+        dctx = K.dgrad(dy2, att.out_proj.weight)
         ops._wgrad(arena, att.out_proj.weight, None, dy2, c)
         dh1 = ops.attention_backward(att, arena, h1, c, saved, dctx, ctx.rt)
         ctx.saved = None

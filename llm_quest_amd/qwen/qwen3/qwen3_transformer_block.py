@@ -29,10 +29,10 @@ class _FFNFn(torch.autograd.Function):
         x2, gu, a = ctx.saved
         F_ = ffn.lin1.weight.shape[0]
         dy2 = dy.reshape(x2.shape[0], -1).contiguous()
-        da = K.gemm(L.GEMM_NN, dy2, ffn.lin2.weight)
+        da = K.dgrad(dy2, ffn.lin2.weight)
         ops._wgrad(arena, ffn.lin2.weight, None, dy2, a)
         dgu = K.swiglu_bwd(gu, da, F_)
-        dx = K.gemm(L.GEMM_NN, dgu, arena.fused(ffn.lin1.weight, ffn.lin_gate.weight))
+        dx = K.dgrad(dgu, arena.fused(ffn.lin1.weight, ffn.lin_gate.weight))
         ops._wgrad(arena, ffn.lin1.weight, ffn.lin_gate.weight, dgu, x2)
         ctx.saved = None
         return (dx.view(ctx.shp), None, None) + (None,) * len(ffn._param_list)

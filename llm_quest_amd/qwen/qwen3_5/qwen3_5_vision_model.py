@@ -149,7 +149,7 @@ def _backward(m, saved_all, dout):
     dz1 = K.gemm_dgrad_gelu_bwd(gb, bf16_cached(ma, "w2", [ma.lin2.weight]), z1)
     _wgrad(ma.lin2.weight, gb, a)
     _bgrad(ma.lin2.bias, gb)
-    dmerged = K.gemm(L.GEMM_NN, dz1, bf16_cached(ma, "w1", [ma.lin1.weight]))
+    dmerged = K.dgrad(dz1, bf16_cached(ma, "w1", [ma.lin1.weight]))
     _wgrad(ma.lin1.weight, dz1, merged)
     _bgrad(ma.lin1.bias, dz1)
     dhn = K.merge_patches(dmerged, B * frames, ma.n_h_patches, ma.n_w_patches, ma.m, inverse=True)
@@ -161,19 +161,19 @@ def _backward(m, saved_all, dout):
         dy1 = K.gemm_dgrad_gelu_bwd(dx3b, bf16_cached(blk.ffn, "w2", [blk.ffn.lin2.weight]), y1, tanh=True)
         _wgrad(blk.ffn.lin2.weight, dx3b, f, wg)
         _bgrad(blk.ffn.lin2.bias, dx3b)
-        dh2 = K.gemm(L.GEMM_NN, dy1, bf16_cached(blk.ffn, "w1", [blk.ffn.lin1.weight]))
+        dh2 = K.dgrad(dy1, bf16_cached(blk.ffn, "w1", [blk.ffn.lin1.weight]))
         _wgrad(blk.ffn.lin1.weight, dy1, h2, wg)
         _bgrad(blk.ffn.lin1.bias, dy1)
         dx2 = _ln_bwd(blk.norm2, x2, mean2, rsig2, dh2, dx)
         dx2b = K.cast(dx2, BF16)
-        dctx = K.gemm(L.GEMM_NN, dx2b, bf16_cached(blk.att, "wo", [blk.att.proj.weight]))
+        dctx = K.dgrad(dx2b, bf16_cached(blk.att, "wo", [blk.att.proj.weight]))
         _wgrad(blk.att.proj.weight, dx2b, ctx, wg)
         _bgrad(blk.att.proj.bias, dx2b)
         dqkv = torch.empty_like(qkv)
         dq, dk = torch.empty_like(q), torch.empty_like(k)
         K.attn_bwd(q, k, qkv[:, 2 * d :], ctx, dctx, lse, B, S, H_, H_, Dh, dq, dk, dqkv[:, 2 * d :], key_mask=None, causal=False, scale=Dh**-0.5)
         K.qknorm_rope_bwd(qkv, None, None, m.cos, m.sin, tok_pos, None, dq, dk, dqkv, H_, H_, Dh)  # RoPE^T only
-        dh1 = K.gemm(L.GEMM_NN, dqkv, bf16_cached(blk.att, "wqkv", [blk.att.qkv.weight]))
+        dh1 = K.dgrad(dqkv, bf16_cached(blk.att, "wqkv", [blk.att.qkv.weight]))
         _wgrad(blk.att.qkv.weight, dqkv, h1, wg)
         _bgrad(blk.att.qkv.bias, dqkv)
         dx = _ln_bwd(blk.norm1, x, mean1, rsig1, dh1, dx2)

@@ -54,7 +54,7 @@ GEMM_SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("form", ["NT", "NN", "TN"])
 @pytest.mark.parametrize("M,N,K_", GEMM_SHAPES)
 def test_gemm_forms(K, form, M, N, K_, tile):
@@ -187,6 +187,34 @@ def test_gemm_grouped_matches_single_launches(K, tile):
     assert rel_l2(o3, a.float() @ b.float().t()) < 2e-6
     with pytest.raises(RuntimeError):
         K.gemm_grouped(L.GEMM_TN, [(dy_all, xs[0], torch.empty((904, 264), dtype=F32, device="cuda"), None)], tile=2)
+
+
+@pytest.mark.gpu
+def test_transpose_and_nt_dgrad_match_nn_form(K):
+    """mi355_transpose_bf16 is a bit-exact transpose (ragged tile edges, strided views), and the dgrad it enables -- dX = dY W as an NT GEMM on
+    W^T -- returns the NN form's bits, plain and with the SwiGLU backward in the epilogue."""
+    from llm_quest_amd import _lib as L
+
+    g = torch.Generator().manual_seed(11)
+    for R, C in [(64, 64), (1024, 3072), (200, 136), (8, 1032), (6144, 1024)]:
+        x = torch.randn(R, C + 8, generator=g).to(BF16)
+        xv = dev(x)[:, :C]  # row-strided view
+        y = K.transpose(xv)
+        assert y.shape == (C, R) and torch.equal(y.cpu(), x[:, :C].t().contiguous()), (R, C)
+    with pytest.raises(RuntimeError):
+        K.transpose(dev(torch.zeros(12, 64).to(BF16)))  # rows not a multiple of 8: refused, not mis-copied
+    M, d, F_ = 4352, 256, 640
+    dy = dev(torch.randn(M, d, generator=g).to(BF16))
+    w = dev((torch.randn(d, F_, generator=g) * 0.1).to(BF16))
+    nn = K.gemm(L.GEMM_NN, dy, w)
+    assert K.DGRAD_NT and M >= K.DGRAD_NT_MIN_ROWS
+    assert torch.equal(K.dgrad(dy, w), nn)
+    small = dy[:512]
+    assert torch.equal(K.dgrad(small, w), K.gemm(L.GEMM_NN, small, w))  # below the threshold: NN form, no transpose
+    gu = dev(torch.randn(M, 2 * F_, generator=g).to(BF16))
+    fused = K.gemm_dgrad_swiglu_bwd(dy, w, gu)
+    two_step = K.swiglu_bwd(gu, nn, F_)
+    assert torch.equal(fused, two_step)
 
 
 def test_colsum(K):
