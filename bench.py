@@ -166,7 +166,8 @@ def dominant_kernel_rate(batch, device):
     out = {}
     for name, fn, flops in (
         ("NT gate-up fwd", lambda: K.gemm(L.GEMM_NT, x, w), 2.0 * M * 6144 * 1024),
-        ("NN gate-up dgrad", lambda: K.gemm(L.GEMM_NN, dy, w), 2.0 * M * 6144 * 1024),
+        ("NT gate-up dgrad on W^T (the step's form, transpose included)", lambda: K.dgrad(dy, w), 2.0 * M * 6144 * 1024),
+        ("NN gate-up dgrad (form not used by the step)", lambda: K.gemm(L.GEMM_NN, dy, w), 2.0 * M * 6144 * 1024),
         ("TN gate-up wgrad", lambda: K.gemm(L.GEMM_TN, dy, x), 2.0 * M * 6144 * 1024),
     ):
         for _ in range(3):
