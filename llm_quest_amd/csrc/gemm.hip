@@ -588,6 +588,20 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
         for (int sm = 0; sm < T::WTM / 64; ++sm) {
 #pragma unroll
             for (int sn = 0; sn < T::WTN / 64; ++sn) {
+                // SwiGLU backward: the sub-block's 16 loads of the forward gate-up pair go out before its staging writes, all in flight at once,
+                // instead of two dependent loads inside each of the eight store passes
+                constexpr bool GU_EARLY = KSEL == MI355_EPI_SWIGLU_BWD && OUT_DT == MI355_DT_BF16;
+                [[maybe_unused]] u32x4 ucur[8], gcur[8];
+                if constexpr (GU_EARLY) {
+                    if (sub_inside(sm, sn)) {
+                        const bf16_t* r0 = reinterpret_cast<const bf16_t*>(p.R) + (m0 + wr0 + sm * 64 + (lane >> 3)) * p.ldr + n0 + wc0 + sn * 64 + (lane & 7) * 8;
+#pragma unroll
+                        for (int tpass = 0; tpass < 8; ++tpass) {
+                            ucur[tpass] = *reinterpret_cast<const u32x4*>(r0 + (int64_t)tpass * 8 * p.ldr);
+                            gcur[tpass] = *reinterpret_cast<const u32x4*>(r0 + (int64_t)tpass * 8 * p.ldr + p.N);
+                        }
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -708,8 +722,14 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
                                     // acc = d(act) for hidden units gn..gn+7; R = the forward's gate-up output [u | g] (ldr = 2N): write
                                     // d(gate-up) = [acc * g*sig(g) | acc * u * sig(g) (1 + g (1 - sig(g)))] into C (ldc = 2N).  acc is rounded to
                                     // bf16 first, so the result equals mi355_swiglu_bwd on the stored bf16 d(act) bit for bit.
-                                    const u32x4 uv = *reinterpret_cast<const u32x4*>(r);
-                                    const u32x4 gv = *reinterpret_cast<const u32x4*>(r + p.N);
+                                    u32x4 uv, gv;
+                                    if constexpr (FULL && GU_EARLY) {
+                                        uv = ucur[tpass];
+                                        gv = gcur[tpass];
+                                    } else {
+                                        uv = *reinterpret_cast<const u32x4*>(r);
+                                        gv = *reinterpret_cast<const u32x4*>(r + p.N);
+                                    }
                                     float du[8], dg[8];
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) {
@@ -782,7 +802,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
     // a third copy of the passes for the SwiGLU-forward form (231.9 vs 233.6 ms/step); not on the 4-wave tile, where a third copy of its four
     // sub-blocks stops the unroller and the accumulators land in scratch
     constexpr bool SWIGLU_FWD_COPY = !A_TR && !B_TR && OUT_DT == MI355_DT_BF16 && T::NW == 8;
-    constexpr bool SWIGLU_BWD_COPY = !A_TR && B_TR && OUT_DT == MI355_DT_BF16 && T::NW == 8;  // the down-projection's dgrad
+    constexpr bool SWIGLU_BWD_COPY = !A_TR && OUT_DT == MI355_DT_BF16 && T::NW == 8;  // the down-projection's dgrad (NT on W^T in the step, NN otherwise)
     if (p.epilogue == MI355_EPI_NONE) {
         run_epilogue(std::integral_constant<int, MI355_EPI_NONE>{});
     } else if (SWIGLU_FWD_COPY && p.epilogue == MI355_EPI_SWIGLU_FWD) {
