@@ -151,6 +151,27 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* tile, int c0, int kk, int 
     return r;
 }
 
+// The same fragment requested from an asm statement.  hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of every ds_read_tr16_b64 INTRINSIC
+// that follows an LDS-DMA (it cannot tell the read from the DMA's destination; plain ds_read_b128 loads are not affected), which drains the
+// whole prefetch ring in every phase of the K-strided forms.  An asm read is invisible to that logic -- and to the compiler's lgkmcnt
+// bookkeeping, so the two 64-bit halves stay separate values until `tr_join`, which runs after a wait that names them.
+struct TrHalves {
+    bf16x4 lo, hi;
+};
+template <int EXT>
+__device__ __forceinline__ void frag_tr_issue(TrHalves& f, const char* tile, int c0, int kk, int lane) {
+    constexpr int ROWB = EXT * 2;
+    static_assert(4 * ROWB < 65536, "ds offset field is 16 bits");
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int fq = q | ((g & 1) << 2);
+    const int chunk = ((c0 >> 3) + (p >> 1)) ^ (fq << 1);
+    const int row = kk * 32 + 8 * g + q;
+    const unsigned addr = (unsigned)(uintptr_t)LDS_PTR(tile + row * ROWB + (chunk << 4) + (p & 1) * 8);
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%c3" : "=&v"(f.lo), "=&v"(f.hi) : "v"(addr), "i"(4 * ROWB));
+}
+__device__ __forceinline__ bf16x8 tr_join(const TrHalves& f) { return __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7); }
+#define TRH(x) "+v"((x).lo), "+v"((x).hi)
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -406,6 +427,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
         __builtin_amdgcn_s_barrier();  // tile t0 landed for every wave
         if (late) __builtin_amdgcn_s_barrier();
         bf16x8 a[HM], b[T::FN];
+        constexpr bool TR_ASM = A_TR && B_TR;  // weight gradients: both operands K-strided
+        [[maybe_unused]] TrHalves ah[HM], bh[T::FN];
         [[maybe_unused]] unsigned long long gp[8] = {};
         [[maybe_unused]] const unsigned long long gp_start = GP_T();
         for (int t = t0; t < nt; ++t) {
@@ -417,7 +440,14 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
             for (int ph = 0; ph < 2; ++ph) {
                 [[maybe_unused]] unsigned long long gt = GP_T();
                 // -------- load segment
-                if (!(p.ablate & 2) || t == t0) {
+                if constexpr (TR_ASM) {
+                    if (ph == 0) {
+#pragma unroll
+                        for (int j = 0; j < T::FN; ++j) frag_tr_issue<T::BN>(bh[j], sB, wc0 + j * 16, 0, lane);
+                    }
+#pragma unroll
+                    for (int i = 0; i < HM; ++i) frag_tr_issue<T::BM>(ah[i], sA, wr0 + (ph * HM + i) * 16, 0, lane);
+                } else if (!(p.ablate & 2) || t == t0) {
                     if (ph == 0) {
 #pragma unroll
                         for (int j = 0; j < T::FN; ++j) b[j] = B_TR ? frag_tr<T::BN>(sB, wc0 + j * 16, 0, lane) : frag_rowk<BK>(sB, wc0 + j * 16, 0, lane);
@@ -449,8 +479,21 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
                     if (younger >= 2) wait_vmcnt<8>(); else if (younger >= 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
                 }
                 GP_ADD(2, gt);  // vmcnt wait
-                const bool wait_late = (p.ablate & 8) || ((p.ablate & 16) && ph == 0);
-                if (!wait_late) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const bool wait_late = !TR_ASM && ((p.ablate & 8) || ((p.ablate & 16) && ph == 0));
+                if constexpr (TR_ASM) {  // the wait names the halves it covers, so no use of them can be placed in front of it
+                    static_assert(HM == 4 && T::FN == 4, "operand lists below are written for 4 + 4 fragments");
+                    if (ph == 0) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" : TRH(bh[0]), TRH(bh[1]), TRH(bh[2]), TRH(bh[3]), TRH(ah[0]), TRH(ah[1]), TRH(ah[2]), TRH(ah[3])::"memory");
+#pragma unroll
+                        for (int j = 0; j < T::FN; ++j) b[j] = tr_join(bh[j]);
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" : TRH(ah[0]), TRH(ah[1]), TRH(ah[2]), TRH(ah[3])::"memory");
+                    }
+#pragma unroll
+                    for (int i = 0; i < HM; ++i) a[i] = tr_join(ah[i]);
+                } else if (!wait_late) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
                 GP_ADD(3, gt);  // lgkmcnt wait
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
