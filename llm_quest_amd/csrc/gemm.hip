@@ -285,6 +285,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
         __builtin_amdgcn_s_barrier();  // tile t0 landed for every wave
         if (late) __builtin_amdgcn_s_barrier();
         bf16x8 a[HM], b[T::FN];
+        constexpr bool TR_ASM = A_TR && B_TR;  // weight gradients: transposing reads from asm (see frag_tr_issue)
+        [[maybe_unused]] TrHalves ah[HM], bh[T::FN];
         for (int t = t0; t < nt; ++t) {
             const char* sA = smem + ((t - t0) % T::NS) * T::STAGE;
             const char* sB = sA + T::A_BYTES;
@@ -293,6 +295,15 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph) {
                 auto read_frags = [&]() {
+                    if constexpr (TR_ASM) {
+                        if (ph == 0) {
+#pragma unroll
+                            for (int j = 0; j < T::FN; ++j) frag_tr_issue<T::BN>(bh[j], sB, wc0 + j * 16, 0, lane);
+                        }
+#pragma unroll
+                        for (int i = 0; i < HM; ++i) frag_tr_issue<T::BM>(ah[i], sA, wr0 + (ph * HM + i) * 16, 0, lane);
+                        return;
+                    }
                     if (ph == 0) {
 #pragma unroll
                         for (int j = 0; j < T::FN; ++j) b[j] = B_TR ? frag_tr<T::BN>(sB, wc0 + j * 16, 0, lane) : frag_rowk<BK>(sB, wc0 + j * 16, 0, lane);
@@ -322,7 +333,20 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
                 if (ph == 0 && t + 1 < nt) {  // this wave's share of tile t+1 has landed; tile t+2 and the A pieces of t+3 may be in flight
                     if (nxt < nt) wait_vmcnt<6>(); else if (t + 2 < nt) wait_vmcnt<4>(); else wait_vmcnt<0>();
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if constexpr (TR_ASM) {
+                    static_assert(HM == 4 && T::FN == 4, "operand lists below are written for 4 + 4 fragments");
+                    if (ph == 0) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" : TRH(bh[0]), TRH(bh[1]), TRH(bh[2]), TRH(bh[3]), TRH(ah[0]), TRH(ah[1]), TRH(ah[2]), TRH(ah[3])::"memory");
+#pragma unroll
+                        for (int j = 0; j < T::FN; ++j) b[j] = tr_join(bh[j]);
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" : TRH(ah[0]), TRH(ah[1]), TRH(ah[2]), TRH(ah[3])::"memory");
+                    }
+#pragma unroll
+                    for (int i = 0; i < HM; ++i) a[i] = tr_join(ah[i]);
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
