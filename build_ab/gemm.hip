@@ -1,0 +1,1121 @@
+// bf16 MFMA GEMM for gfx950 with fused epilogue (bias / exact GELU / residual-or-accumulate) and split-K.
+//
+// One kernel template covers the three operand forms a Linear layer needs (include/mi355_vlm.h):
+//   NT  y  = x W^T      both operands K-contiguous            -> ds_read_b128 fragments
+//   NN  dx = dy W       B is K-strided ([K][N] row-major)     -> ds_read_b64_tr_b16 fragments for B
+//   TN  dW = dy^T x     A and B K-strided                     -> transposing reads for both
+// so no operand is ever transposed in HBM.
+//
+// Structure (tile BM x BN x 64, WM x WN waves, every wave owns (BM/WM) x (BN/WN) outputs as 16x16x32 MFMA tiles):
+//   * HBM -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction), two LDS stages, the
+//     next K-tile's DMA in flight while the current one feeds the MFMAs; one barrier per K-tile.
+//   * The DMA destination is lane-linear, so the bank-conflict swizzle is applied on the per-lane SOURCE
+//     address and again on the fragment read (both-sides rule): row-major-K tiles use 128-B rows with
+//     chunk' = chunk ^ ((row>>1)&7); K-strided tiles use (2*cols)-byte rows with chunk' = chunk ^ (f(k)<<1).
+//   * Out-of-range rows/cols/K are zero-filled by the buffer range check (offset 0x80000000 > num_records),
+//     so any M and any K,N multiple of 8 work without a tail path in the main loop.
+//   * The kernel is LDS-bandwidth-bound at 64x64 per wave (fragment reads + DMA writes ~ MFMA time), so the large
+//     configurations give every wave 128x64 outputs: 25 % fewer fragment bytes and half the DMA bytes per MFMA.
+//   * Epilogue: accumulators -> LDS (fp32, 64x64 at a time per wave) -> row-contiguous 16-B global stores with
+//     bias/GELU/residual fused, or raw fp32 slabs when K is split (few output tiles + long K: weight gradients).
+//   * Workgroup -> tile map: XCD-aware (blocks b and b+8 share an L2) then 3-row super-groups.
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+constexpr int EPI_LD = 68;             // fp32 row pitch of the epilogue staging (bank-spread, 16-B aligned)
+constexpr unsigned OOB = 0x80000000u;  // beyond num_records (0x7fffffff): load returns zeros
+
+// BK_ = K extent of one LDS stage, NS_ = stages of the ring: the DMA of K-tile t+NS-1 is issued while tile t is being
+// multiplied, and the wait in front of the per-tile barrier is a COUNTED vmcnt that leaves the NS-2 youngest tiles in
+// flight (a vmcnt(0) there -- what __syncthreads() emits -- is the ceiling of the simple structure).
+template <int BM_, int BN_, int WM_, int WN_, int BK_, int NS_>
+struct TileCfg {
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = BK_, NS = NS_, NW = WM_ * WN_, NTHREADS = NW * 64;
+    static constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
+    static constexpr int FM = WTM / 16, FN = WTN / 16;  // 16x16 accumulator tiles per wave
+    static constexpr int KK = BK / 32;                  // MFMA k-steps per stage
+    static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    static constexpr int A_PPW = A_BYTES / 1024 / NW, B_PPW = B_BYTES / 1024 / NW;  // DMA pieces per wave per K-tile
+    static constexpr int DMA_PER_TILE = A_PPW + B_PPW;
+    static constexpr int EPI_BYTES = NW * 64 * EPI_LD * 4;
+    static constexpr int SMEM = NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES;
+    static constexpr int MIN_WAVES = (NW == 8) ? 2 : (SMEM <= 80 * 1024 ? 2 : 1);
+    static_assert(BK == 32 || BK == 64, "BK must be 32 or 64");
+    static_assert(WTM % 64 == 0 && WTN % 64 == 0, "wave tile must be a multiple of 64x64");
+    static_assert(A_BYTES % (1024 * NW) == 0 && B_BYTES % (1024 * NW) == 0, "pieces must divide evenly over the waves");
+    static_assert((NS - 2) * DMA_PER_TILE <= 63, "vmcnt field is 6 bits");
+};
+using Cfg128 = TileCfg<128, 128, 2, 2, 64, 2>;      // 68 KiB LDS, 2 workgroups / CU, vmcnt(0) structure
+using Cfg256 = TileCfg<256, 256, 2, 4, 64, 2>;      // 136 KiB LDS, 1 workgroup (8 waves) / CU
+using Cfg256a = TileCfg<256, 256, 2, 4, 32, 4>;     // 136 KiB LDS, 4-stage ring, alternating wave groups
+using Cfg256b = TileCfg<256, 256, 2, 4, 32, 5>;     // 160 KiB LDS (all of it), 5-stage ring, ONE barrier per phase (tile hint 4)
+using Cfg256w = TileCfg<256, 256, 2, 2, 32, 4>;     // 128 KiB LDS, FOUR waves of 128x128 (one per SIMD, 512 registers each), tile hint 5
+
+#ifndef GEMM_PROF
+#define GEMM_PROF 0  // profiling builds only: in-kernel cycle stamps of the alternating loop (tools/gemm_prof.py)
+#endif
+#if GEMM_PROF
+__device__ unsigned long long g_gemm_prof[32];
+#define GP_T() __builtin_readcyclecounter()
+#define GP_ADD(i, t0) do { const unsigned long long now_ = __builtin_readcyclecounter(); gp[i] += now_ - (t0); (t0) = now_; } while (0)
+#else
+#define GP_T() 0ull
+#define GP_ADD(i, t0) do { } while (0)
+#endif
+
+struct GemmParams {
+    const bf16_t* A;
+    const bf16_t* B;
+    void* C;
+    const float* bias;
+    const void* R;
+    int64_t M, N, K, lda, ldb, ldc, ldr;
+    int tiles_m, tiles_n, epilogue;
+    int ksplit;  // > 1: K is split over ksplit workgroups per tile, each writes an fp32 slab into ws
+    float* ws;   // [ksplit][M][N] fp32
+    int ablate;  // profiling only (tile_hint >> 8): 1 = no DMA after the prologue, 2 = no fragment reads after the first, 4 = no barrier
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ int tr_f(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+// swizzle of a row-major-K image: 128-B rows (BK 64): chunk ^ ((row>>1)&7); 64-B rows (BK 32): chunk ^ ((-(row>>2))&3)
+template <int BKc>
+__device__ __forceinline__ int swz_rowk(int chunk, int row) {
+    return BKc == 64 ? chunk ^ ((row >> 1) & 7) : chunk ^ ((0 - (row >> 2)) & 3);
+}
+
+// Per-lane byte offsets (relative to the tile's corner) of this wave's DMA pieces of one operand tile, plus the
+// K-extent each piece needs for validity.  Non-TR: tile [EXT rows][BK k]; TR: tile [BK k][EXT cols] (2*EXT-byte rows).
+template <bool TR, int EXT, int BKc, int PPW>
+__device__ __forceinline__ void piece_offsets(int wave, int lane, int64_t ld, int64_t ext_left, unsigned (&voff)[PPW], int (&kneed)[PPW]) {
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int pi = wave * PPW + j;
+        if constexpr (!TR) {
+            constexpr int CH = BKc * 2 / 16, RPP = 64 / CH;  // chunks per row, rows per 1-KiB piece
+            const int r = pi * RPP + lane / CH;
+            const int c = swz_rowk<BKc>(lane % CH, r);
+            voff[j] = (r < ext_left) ? (unsigned)(r * ld * 2 + c * 16) : OOB;
+            kneed[j] = c * 8;  // valid iff kneed < K - k0
+        } else {
+            constexpr int CH = EXT * 2 / 16, RPP = 64 / CH;
+            const int kr = pi * RPP + lane / CH;
+            const int c = (lane % CH) ^ (tr_f(kr) << 1);
+            voff[j] = (c * 8 < ext_left) ? (unsigned)(kr * ld * 2 + c * 16) : OOB;
+            kneed[j] = kr;
+        }
+    }
+}
+
+// A pointer every lane agrees on, moved to scalar registers.  The buffer resource of an LDS-DMA must be scalar; a base pointer that went
+// through a select (the SwiGLU-forward row remap picks another B base) otherwise reaches the DMA in vector registers and every piece
+// is wrapped in a readfirstlane waterfall loop.
+__device__ __forceinline__ const bf16_t* uniform_ptr(const bf16_t* ptr) {
+    const unsigned long long v = (unsigned long long)ptr;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const bf16_t*)(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ void dma_piece(const void* base, unsigned voff, char* lds_dst) {
+    auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_dst), 16, voff, 0, 0, 0);
+}
+
+// fragment of a row-major-K tile: 16 rows starting at r0, k-step kk (32 wide)
+template <int BKc>
+__device__ __forceinline__ bf16x8 frag_rowk(const char* tile, int r0, int kk, int lane) {
+    const int r = r0 + (lane & 15);
+    const int c = kk * 4 + (lane >> 4);
+    return *reinterpret_cast<const bf16x8*>(tile + r * (BKc * 2) + (swz_rowk<BKc>(c, r) << 4));
+}
+
+// fragment of a K-strided tile [BK k][EXT cols]: 16 cols starting at c0, k-step kk, via two transposing reads
+template <int EXT>
+__device__ __forceinline__ bf16x8 frag_tr(const char* tile, int c0, int kk, int lane) {
+    constexpr int ROWB = EXT * 2;
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int f = q | ((g & 1) << 2);
+    const int chunk = ((c0 >> 3) + (p >> 1)) ^ (f << 1);
+    const int row = kk * 32 + 8 * g + q;
+    const char* a0 = tile + row * ROWB + (chunk << 4) + (p & 1) * 8;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a0));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a0 + 4 * ROWB));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else static_assert(N == 0, "add the immediate");
+}
+
+// position b of a round-robin-over-XCDs numbering -> position in a numbering where each XCD owns one contiguous chunk
+__device__ __forceinline__ int xcd_chunked(int b, int n) {
+    const int xcd = b & 7, q = n >> 3, r = n & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+// One output tile (and one K split) of one problem.  `pid` = tile index in XCD-chunked order, `split` = K-split index.
+template <class T, bool A_TR, bool B_TR, int OUT_DT>
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, const int split, char* smem) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // ---- tile index -> (tm, tn): row super-groups ----------------------------------------------------
+    // super-group height by in-step A/B on the VLM step (ms/step, two runs each): 2: 245.9 / 246.2, 3: 243.8 / 243.8, 4: 245.3 / 245.3, 6: 243.8 / 244.3,
+    // 8: 245.2 / 245.6, 16: 249.7 / 248.0.  Profiling bits 5-7 of the tile hint select another height.
+    const int gsel = (p.ablate >> 5) & 7;
+    const int GROUP_M = gsel == 1 ? 4 : gsel == 2 ? 16 : gsel == 3 ? 2 : gsel == 4 ? 6 : gsel == 5 ? 8 : 3;
+    const int in_group = GROUP_M * p.tiles_n;
+    const int first_m = (pid / in_group) * GROUP_M;
+    const int gsz = min(p.tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (pid % in_group) % gsz;
+    const int tn = (pid % in_group) / gsz;
+    const int64_t m0 = (int64_t)tm * T::BM, n0 = (int64_t)tn * T::BN;
+
+    // ---- DMA plan -------------------------------------------------------------------------------------
+    unsigned voffA[T::A_PPW], voffB[T::B_PPW];
+    int kneedA[T::A_PPW], kneedB[T::B_PPW];
+    constexpr int BK = T::BK;
+    piece_offsets<A_TR, T::BM, BK, T::A_PPW>(wave, lane, p.lda, p.M - m0, voffA, kneedA);
+    piece_offsets<B_TR, T::BN, BK, T::B_PPW>(wave, lane, p.ldb, p.N - n0, voffB, kneedB);
+    const bf16_t* baseA = A_TR ? p.A + m0 : p.A + m0 * p.lda;
+    const bf16_t* baseB = B_TR ? p.B + n0 : p.B + n0 * p.ldb;
+    if constexpr (!B_TR) {
+        if (p.epilogue == MI355_EPI_SWIGLU_FWD) {
+            // gate-up projection with the activation in the epilogue: every 64 output columns of the tile are [32 lin1 rows | the 32
+            // lin_gate rows of the SAME hidden units] of the fused weight [lin1 (N/2 rows) | lin_gate (N/2 rows)], so a wave's 64x64
+            // staging block holds u and g side by side.  Only the row each DMA lane fetches changes.
+            constexpr int CH = BK * 2 / 16, RPP = 64 / CH;
+            const int64_t nh = p.N >> 1;
+#pragma unroll
+            for (int j = 0; j < T::B_PPW; ++j) {
+                const int r = (wave * T::B_PPW + j) * RPP + lane / CH;
+                const int c = swz_rowk<BK>(lane % CH, r);
+                const int64_t hid = (n0 >> 1) + (r >> 6) * 32 + (r & 31);
+                const int64_t grow = ((r >> 5) & 1) * nh + hid;
+                voffB[j] = hid < nh ? (unsigned)(grow * p.ldb * 2 + c * 16) : OOB;
+                kneedB[j] = c * 8;
+            }
+            baseB = p.B;
+        }
+    }
+    baseA = uniform_ptr(baseA);
+    baseB = uniform_ptr(baseB);
+    const int64_t stepA = A_TR ? (int64_t)BK * p.lda : BK;
+    const int64_t stepB = B_TR ? (int64_t)BK * p.ldb : BK;
+
+    auto issue_tile = [&](int t, int stage) {
+        const int64_t krem = p.K - (int64_t)t * BK;
+        const bf16_t* pa = baseA + t * stepA;
+        const bf16_t* pb = baseB + t * stepB;
+        char* dA = smem + stage * T::STAGE + wave * T::A_PPW * 1024;
+        char* dB = smem + stage * T::STAGE + T::A_BYTES + wave * T::B_PPW * 1024;
+#pragma unroll
+        for (int j = 0; j < T::A_PPW; ++j) dma_piece(pa, kneedA[j] < krem ? voffA[j] : OOB, dA + j * 1024);
+#pragma unroll
+        for (int j = 0; j < T::B_PPW; ++j) dma_piece(pb, kneedB[j] < krem ? voffB[j] : OOB, dB + j * 1024);
+    };
+
+    f32x4 acc[T::FM][T::FN];
+#pragma unroll
+    for (int i = 0; i < T::FM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int wr0 = (wave / T::WN) * T::WTM, wc0 = (wave % T::WN) * T::WTN;
+    const int nt_all = (int)((p.K + BK - 1) / BK);
+    const int per = (nt_all + p.ksplit - 1) / p.ksplit;
+    const int t0 = split * per;
+    const int nt = min(nt_all, t0 + per);
+
+    bool extra_barrier = false;
+    if constexpr (std::is_same_v<T, Cfg256b>) {
+        // ---- alternating groups, ONE barrier per phase.  The two groups stay one barrier apart (waves 4-7 take an extra one
+        // up front), so at every barrier one group has just finished a load segment and the other a 16-MFMA cluster; a phase
+        // is { load segment ; lgkmcnt(0) ; s_barrier ; 16 MFMAs }.  With half the barriers the hazards are covered by distance:
+        //   WAR  the DMA of tile t+3 (issued during tile t) lands in the stage of tile t-2 (5 stages), which both groups left
+        //        at least one barrier before the issuing wave's current one;
+        //   RAW  a wave confirms its pieces of tile t+1 (counted vmcnt; they were requested 3-4 phases earlier) in phase 0
+        //        of tile t; the group that runs ahead reads tile t+1 two barriers later, after the group behind has passed
+        //        its own phase-0 wait.
+        static_assert(T::NW == 8 && T::KK == 1 && T::NS == 5 && T::A_PPW == 2 && T::B_PPW == 2, "single-barrier loop: 8 waves, 5 stages, 2+2 pieces");
+        constexpr int HM = T::FM / 2;
+        const bool late = wave >= 4;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (t0 + i < nt) issue_tile(t0 + i, i);
+        if (t0 < nt) {
+            const int younger = nt - 1 - t0;
+            if (younger >= 2) wait_vmcnt<8>(); else if (younger >= 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();  // tile t0 landed for every wave
+        if (late) __builtin_amdgcn_s_barrier();
+        bf16x8 a[HM], b[T::FN];
+        for (int t = t0; t < nt; ++t) {
+            const char* sA = smem + ((t - t0) % T::NS) * T::STAGE;
+            const char* sB = sA + T::A_BYTES;
+            const int nxt = t + 3;
+            const int nst = (nxt - t0) % T::NS;
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                auto read_frags = [&]() {
+                    if (ph == 0) {
+#pragma unroll
+                        for (int j = 0; j < T::FN; ++j) b[j] = B_TR ? frag_tr<T::BN>(sB, wc0 + j * 16, 0, lane) : frag_rowk<BK>(sB, wc0 + j * 16, 0, lane);
+                    }
+#pragma unroll
+                    for (int i = 0; i < HM; ++i) {
+                        const int r0 = wr0 + (ph * HM + i) * 16;
+                        a[i] = A_TR ? frag_tr<T::BM>(sA, r0, 0, lane) : frag_rowk<BK>(sA, r0, 0, lane);
+                    }
+                };
+                if (!(p.ablate & 2)) read_frags();
+                if (nxt < nt) {
+                    const int64_t krem = p.K - (int64_t)nxt * BK;
+                    if (ph == 0) {
+                        const bf16_t* pa = baseA + nxt * stepA;
+                        char* dA = smem + nst * T::STAGE + wave * T::A_PPW * 1024;
+#pragma unroll
+                        for (int j = 0; j < T::A_PPW; ++j) dma_piece(pa, kneedA[j] < krem ? voffA[j] : OOB, dA + j * 1024);
+                    } else {
+                        const bf16_t* pb = baseB + nxt * stepB;
+                        char* dB = smem + nst * T::STAGE + T::A_BYTES + wave * T::B_PPW * 1024;
+#pragma unroll
+                        for (int j = 0; j < T::B_PPW; ++j) dma_piece(pb, kneedB[j] < krem ? voffB[j] : OOB, dB + j * 1024);
+                    }
+                }
+                if (p.ablate & 2) read_frags();  // experiment: DMA issue in front of the fragment reads
+                if (ph == 0 && t + 1 < nt) {  // this wave's share of tile t+1 has landed; tile t+2 and the A pieces of t+3 may be in flight
+                    if (nxt < nt) wait_vmcnt<6>(); else if (t + 2 < nt) wait_vmcnt<4>(); else wait_vmcnt<0>();
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (p.ablate & 1) __builtin_amdgcn_s_setprio(1);  // measured: raising the cluster's priority costs 2-3 % in this loop
+#pragma unroll
+                for (int i = 0; i < HM; ++i)
+#pragma unroll
+                    for (int j = 0; j < T::FN; ++j)
+                        acc[ph * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[ph * HM + i][j], 0, 0, 0);
+                if (p.ablate & 1) __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        extra_barrier = !late;  // the early group balances the late group's extra barrier
+    } else if constexpr (T::NW == 4 && T::BK == 32) {
+        // ---- one wave per SIMD, 128x128 outputs per wave (256 accumulator registers): a third fewer fragment bytes per MFMA than the
+        // 128x64 wave tiles, and nobody to alternate with, so the loads ride in the shadow of the wave's own MFMAs: per K-tile (64 MFMAs)
+        //   phase 0: 32 MFMAs (rows 0-63)   beside the 4 fragment reads of rows 64-127 and the wave's 8 DMA pieces of tile t+3
+        //   counted vmcnt (tile t+1 landed) ; s_barrier
+        //   phase 1: 32 MFMAs (rows 64-127) beside the 12 fragment reads of tile t+1 (its B fragments go to the other register set)
+        // The DMA is issued for every tile number, past the end of K with out-of-range offsets (zero fill into a stage nobody reads),
+        // so the body has no branches and the vmcnt immediate is one constant.
+        static_assert(T::KK == 1 && T::NS == 4 && T::FM == 8 && T::FN == 8 && T::A_PPW == 4 && T::B_PPW == 4, "4-wave loop: 128x128 per wave, 4+4 pieces");
+        constexpr int HM = 4;
+        auto issue_piece = [&](int tl, int stage, int g) {  // piece g (0-3: A, 4-7: B) of this wave's share of tile tl, any tile number
+            const int64_t krem = p.K - (int64_t)tl * BK;
+            if (g < T::A_PPW) {
+                dma_piece(baseA + tl * stepA, (tl < nt && kneedA[g] < krem) ? voffA[g] : OOB, smem + stage * T::STAGE + (wave * T::A_PPW + g) * 1024);
+            } else {
+                const int h = g - T::A_PPW;
+                dma_piece(baseB + tl * stepB, (tl < nt && kneedB[h] < krem) ? voffB[h] : OOB, smem + stage * T::STAGE + T::A_BYTES + (wave * T::B_PPW + h) * 1024);
+            }
+        };
+        // The accumulators are pinned to the accumulation registers by the operand constraint: with the builtin, hipcc keeps part of the
+        // 256 values in vector registers and moves four in and four out around every MFMA (measured: 594 TFLOP/s on the gate-up shape).
+        auto mma = [&](f32x4& c, const bf16x8& av, const bf16x8& bv) {
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(av), "v"(bv));
+        };
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int g = 0; g < 8; ++g) issue_piece(t0 + i, i, g);
+        wait_vmcnt<16>();
+        __builtin_amdgcn_s_barrier();  // tile t0 landed for every wave
+        bf16x8 a0[HM], a1[HM], b[2][T::FN];
+#pragma unroll
+        for (int j = 0; j < T::FN; ++j) b[0][j] = B_TR ? frag_tr<T::BN>(smem + T::A_BYTES, wc0 + j * 16, 0, lane) : frag_rowk<BK>(smem + T::A_BYTES, wc0 + j * 16, 0, lane);
+#pragma unroll
+        for (int i = 0; i < HM; ++i) a0[i] = A_TR ? frag_tr<T::BM>(smem, wr0 + i * 16, 0, lane) : frag_rowk<BK>(smem, wr0 + i * 16, 0, lane);
+        auto body = [&](auto par, int t) {
+            constexpr int CUR = decltype(par)::value;
+            const char* sA = smem + ((t - t0) & 3) * T::STAGE;
+            const char* nA = smem + ((t + 1 - t0) & 3) * T::STAGE;
+            const int nst = (t + 3 - t0) & 3;
+            // -------- phase 0: 8 groups of { 4 MFMAs, 1 DMA piece, (first four) 1 fragment of the lower rows }
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mma(acc[g >> 1][(g & 1) * 4 + q], a0[g >> 1], b[CUR][(g & 1) * 4 + q]);
+                issue_piece(t + 3, nst, g);
+                if (g < HM) a1[g] = A_TR ? frag_tr<T::BM>(sA, wr0 + (HM + g) * 16, 0, lane) : frag_rowk<BK>(sA, wr0 + (HM + g) * 16, 0, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            wait_vmcnt<16>();  // this wave's pieces of tile t+1 have landed (t+2, t+3 in flight)
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // -------- phase 1: 12 groups of { 2 MFMAs, 1 fragment of tile t+1 }, then the last 8 MFMAs
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) mma(acc[HM + (g >> 2)][(g & 3) * 2 + q], a1[g >> 2], b[CUR][(g & 3) * 2 + q]);
+                if (g < T::FN) b[CUR ^ 1][g] = B_TR ? frag_tr<T::BN>(nA + T::A_BYTES, wc0 + g * 16, 0, lane) : frag_rowk<BK>(nA + T::A_BYTES, wc0 + g * 16, 0, lane);
+                else if (g < T::FN + HM) a0[g - T::FN] = A_TR ? frag_tr<T::BM>(nA, wr0 + (g - T::FN) * 16, 0, lane) : frag_rowk<BK>(nA, wr0 + (g - T::FN) * 16, 0, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        int t = t0;
+        for (; t + 1 < nt; t += 2) {
+            body(std::integral_constant<int, 0>{}, t);
+            body(std::integral_constant<int, 1>{}, t + 1);
+        }
+        if (t < nt) body(std::integral_constant<int, 0>{}, t);
+        wait_vmcnt<0>();  // the zero-fill DMAs past the last tile must not land in the epilogue's staging
+    } else if constexpr (T::BK == 32) {
+        // ---- alternating-group loop (8 waves, BK = 32, NS-stage ring).  Waves 4-7 run ONE barrier behind waves 0-3, so on
+        // every SIMD one wave is in its 16-MFMA cluster while its partner is in the load segment (fragment reads, two
+        // LDS-DMA issues, waits).  A phase = { load segment ; lgkmcnt(0) ; s_barrier ; 16 MFMAs ; s_barrier }, two phases per
+        // K-tile (row halves mh = 0, 1).  Hazards: a wave's reads of tile t are complete before the barrier that precedes
+        // its last MFMA cluster of that tile, and the slot is refilled (tile t+NS) only after that wave group's following
+        // barrier, which the other group reaches after completing ITS reads; tile t+1 is waited for (counted vmcnt) in
+        // phase 1 of tile t, a full cluster + barrier before anyone reads it.
+        static_assert(T::NW == 8 && T::KK == 1 && T::NS >= 3 && T::A_PPW == 2 && T::B_PPW == 2, "alternating loop: 8 waves, 2+2 DMA pieces per tile");
+        constexpr int HM = T::FM / 2;
+        const bool late = wave >= 4;  // wave-uniform (readfirstlane above)
+#pragma unroll
+        for (int i = 0; i < T::NS - 1; ++i)
+            if (t0 + i < nt) issue_tile(t0 + i, i);
+        if (t0 < nt) {
+            const int younger = nt - 1 - t0;
+            if (younger >= 2) wait_vmcnt<8>(); else if (younger >= 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();  // tile t0 landed for every wave
+        if (late) __builtin_amdgcn_s_barrier();
+        bf16x8 a[HM], b[T::FN];
+        [[maybe_unused]] unsigned long long gp[8] = {};
+        [[maybe_unused]] const unsigned long long gp_start = GP_T();
+        for (int t = t0; t < nt; ++t) {
+            const char* sA = smem + ((t - t0) % T::NS) * T::STAGE;
+            const char* sB = sA + T::A_BYTES;
+            const int nxt = t + T::NS - 1;
+            const int nst = (nxt - t0) % T::NS;
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                [[maybe_unused]] unsigned long long gt = GP_T();
+                // -------- load segment
+                if (!(p.ablate & 2) || t == t0) {
+                    if (ph == 0) {
+#pragma unroll
+                        for (int j = 0; j < T::FN; ++j) b[j] = B_TR ? frag_tr<T::BN>(sB, wc0 + j * 16, 0, lane) : frag_rowk<BK>(sB, wc0 + j * 16, 0, lane);
+                    }
+#pragma unroll
+                    for (int i = 0; i < HM; ++i) {
+                        const int r0 = wr0 + (ph * HM + i) * 16;
+                        a[i] = A_TR ? frag_tr<T::BM>(sA, r0, 0, lane) : frag_rowk<BK>(sA, r0, 0, lane);
+                    }
+                }
+                GP_ADD(0, gt);  // fragment reads issued
+                if (nxt < nt && !(p.ablate & 1)) {  // two of this wave's four DMA pieces of tile t+NS-1 per phase: A pieces, then B pieces
+                    const int64_t krem = p.K - (int64_t)nxt * BK;
+                    if (ph == 0) {
+                        const bf16_t* pa = baseA + nxt * stepA;
+                        char* dA = smem + nst * T::STAGE + wave * T::A_PPW * 1024;
+#pragma unroll
+                        for (int j = 0; j < T::A_PPW; ++j) dma_piece(pa, kneedA[j] < krem ? voffA[j] : OOB, dA + j * 1024);
+                    } else {
+                        const bf16_t* pb = baseB + nxt * stepB;
+                        char* dB = smem + nst * T::STAGE + T::A_BYTES + wave * T::B_PPW * 1024;
+#pragma unroll
+                        for (int j = 0; j < T::B_PPW; ++j) dma_piece(pb, kneedB[j] < krem ? voffB[j] : OOB, dB + j * 1024);
+                    }
+                }
+                GP_ADD(1, gt);  // DMA issued
+                if (ph == 1 && t + 1 < nt) {  // this wave's share of tile t+1 has landed (tiles t+2.. may stay in flight)
+                    const int younger = min(nt - 1, t + T::NS - 1) - (t + 1);
+                    if (younger >= 2) wait_vmcnt<8>(); else if (younger >= 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+                }
+                GP_ADD(2, gt);  // vmcnt wait
+                const bool wait_late = (p.ablate & 8) || ((p.ablate & 16) && ph == 0);
+                if (!wait_late) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                GP_ADD(3, gt);  // lgkmcnt wait
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                GP_ADD(4, gt);  // barrier in front of the cluster
+                if (wait_late) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                // -------- MFMA cluster
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < HM; ++i)
+#pragma unroll
+                    for (int j = 0; j < T::FN; ++j)
+                        acc[ph * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[ph * HM + i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                GP_ADD(5, gt);  // MFMA cluster issued
+                if (!(p.ablate & 4)) __builtin_amdgcn_s_barrier();
+                GP_ADD(6, gt);  // barrier behind the cluster
+            }
+        }
+#if GEMM_PROF
+        if ((threadIdx.x & 63) == 0 && (wave == 0 || wave == 4)) {
+            const int o = wave == 0 ? 0 : 16;
+            for (int i = 0; i < 7; ++i) atomicAdd(&g_gemm_prof[o + i], gp[i]);
+            atomicAdd(&g_gemm_prof[o + 7], __builtin_readcyclecounter() - gp_start);
+            atomicAdd(&g_gemm_prof[o + 8], (unsigned long long)(2 * (nt - t0)));
+        }
+#endif
+        extra_barrier = !late && !(p.ablate & 4);  // the early group balances the late group's extra barrier
+    } else {
+    // ---- main loop: 4 phases per K-tile = (k-step kk, half of the wave's rows mh); the fragments of phase p+1 are read
+    // from LDS while the MFMAs of phase p run (two register sets for the A half, two for B), so the matrix pipe is not
+    // idle during fragment reads.  The per-tile barrier sits in front of the LAST phase's MFMA cluster: by then every
+    // read of tile t has been issued (and is waited for), tile t+1's DMA is checked with a counted vmcnt, the freed stage
+    // is refilled and the first fragments of tile t+1 are requested -- all under the remaining MFMAs of tile t.
+    constexpr int HM = T::FM / 2;
+    static_assert(T::KK == 2, "the pipelined loop is written for BK = 64");
+    auto loadA = [&](bf16x8 (&a)[HM], const char* sA, int kk, int mh) {
+        if (p.ablate & 2) return;
+#pragma unroll
+        for (int i = 0; i < HM; ++i) {
+            const int r0 = wr0 + (mh * HM + i) * 16;
+            a[i] = A_TR ? frag_tr<T::BM>(sA, r0, kk, lane) : frag_rowk<BK>(sA, r0, kk, lane);
+        }
+    };
+    auto loadB = [&](bf16x8 (&b)[T::FN], const char* sB, int kk) {
+        if (p.ablate & 2) return;
+#pragma unroll
+        for (int j = 0; j < T::FN; ++j) b[j] = B_TR ? frag_tr<T::BN>(sB, wc0 + j * 16, kk, lane) : frag_rowk<BK>(sB, wc0 + j * 16, kk, lane);
+    };
+    auto mma = [&](const bf16x8 (&a)[HM], const bf16x8 (&b)[T::FN], int mh) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < HM; ++i)
+#pragma unroll
+            for (int j = 0; j < T::FN; ++j)
+                acc[mh * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[mh * HM + i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto wait_tile = [&](int younger) {  // returns once at most min(NS-2, younger) younger tiles of this wave are in flight
+        if (T::NS >= 4 && younger >= 2) wait_vmcnt<2 * T::DMA_PER_TILE>();
+        else if (T::NS >= 3 && younger >= 1) wait_vmcnt<T::DMA_PER_TILE>();
+        else wait_vmcnt<0>();
+    };
+
+#pragma unroll
+    for (int i = 0; i < T::NS - 1; ++i)
+        if (t0 + i < nt) issue_tile(t0 + i, i);
+    bf16x8 aE[HM], aO[HM], b0[T::FN], b1[T::FN];
+#pragma unroll
+    for (int i = 0; i < HM; ++i) aE[i] = aO[i] = (bf16x8){1, 2, 3, 4, 5, 6, 7, 8};
+#pragma unroll
+    for (int j = 0; j < T::FN; ++j) b0[j] = b1[j] = (bf16x8){8, 7, 6, 5, 4, 3, 2, 1};
+    if (t0 < nt) {
+        wait_tile(nt - 1 - t0);
+        __builtin_amdgcn_s_barrier();
+        if (t0 + T::NS - 1 < nt) issue_tile(t0 + T::NS - 1, T::NS - 1);
+        loadB(b0, smem + T::A_BYTES, 0);
+        loadA(aE, smem, 0, 0);
+    }
+    for (int t = t0; t < nt; ++t) {
+        const char* sA = smem + ((t - t0) % T::NS) * T::STAGE;
+        const char* sB = sA + T::A_BYTES;
+        loadA(aO, sA, 0, 1);
+        mma(aE, b0, 0);  // phase 0
+        loadB(b1, sB, 1);
+        loadA(aE, sA, 1, 0);
+        mma(aO, b0, 1);  // phase 1
+        loadA(aO, sA, 1, 1);
+        mma(aE, b1, 0);  // phase 2
+        if (t + 1 < nt) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of tile t are complete ...
+            wait_tile(nt - 2 - t);                              // ... and its share of tile t+1 has landed
+            if (!(p.ablate & 4)) __builtin_amdgcn_s_barrier();  // ... for every wave
+            if (t + T::NS < nt && !(p.ablate & 1)) issue_tile(t + T::NS, (t - t0) % T::NS);
+            const char* nA = smem + ((t + 1 - t0) % T::NS) * T::STAGE;
+            loadB(b0, nA + T::A_BYTES, 0);
+            loadA(aE, nA, 0, 0);
+        }
+        mma(aO, b1, 1);  // phase 3
+    }
+
+    }
+    if (extra_barrier) __builtin_amdgcn_s_barrier();
+    // ---- epilogue: acc -> LDS (fp32, 64x64 per wave at a time) -> coalesced rows ---------------------------------
+    __syncthreads();
+    float* stg = reinterpret_cast<float*>(smem) + wave * 64 * EPI_LD;
+    // "No fused form" and "this 64x64 sub-block lies inside the matrix and is 16-byte addressable" are resolved once, outside the store
+    // passes: the plain epilogue (with or without bias / residual) gets a straight-line copy of them for interior sub-blocks.  With the kind
+    // tested inside every pass (all fused forms inlined behind run-time branches) the passes were instruction-issue-bound: 22 us per
+    // 256x256 tile with four waves, ~5 us with eight.  The fused forms keep the run-time dispatch (compile time: every extra copy of the
+    // passes costs about a minute over the 48 kernels of this file).
+    const bool aligned_io = ((p.ldc & 7) == 0) && ((p.ldr & 7) == 0 || p.R == nullptr);
+    auto run_epilogue = [&](auto kind_c) __attribute__((always_inline)) {
+        constexpr int KSEL = decltype(kind_c)::value;
+        const int KIND = KSEL >= 0 ? KSEL : p.epilogue;
+        // residual rows of interior sub-blocks are fetched one sub-block ahead (eight 16-byte loads per lane), so that their HBM latency is
+        // paid once per tile instead of in every store pass (measured: +7.6 us per 256x256 tile on eight waves, +17 us on four).  NT only:
+        // that is where the step's residual adds are (out-projection, down-projection); in the NN / TN kernels the 38 extra registers of the
+        // look-ahead changed the main loop's allocation and cost 1.2 ms/step each in the per-kernel profile, for a path they never take.
+        constexpr bool RES_AHEAD = KSEL == MI355_EPI_NONE && OUT_DT == MI355_DT_BF16 && !A_TR && !B_TR;
+        constexpr int SUBS_N = T::WTN / 64, SUBS = (T::WTM / 64) * SUBS_N;
+        const bool res_ahead = RES_AHEAD && p.R != nullptr && aligned_io && p.ksplit == 1;
+        [[maybe_unused]] u32x4 rnext[8];
+        auto sub_inside = [&](int sm, int sn) { return aligned_io && m0 + wr0 + sm * 64 + 64 <= p.M && n0 + wc0 + sn * 64 + 64 <= p.N; };
+        auto fetch_residual = [&](int sm, int sn) __attribute__((always_inline)) {
+            const bf16_t* r0 = reinterpret_cast<const bf16_t*>(p.R) + (m0 + wr0 + sm * 64 + (lane >> 3)) * p.ldr + n0 + wc0 + sn * 64 + (lane & 7) * 8;
+#pragma unroll
+            for (int tpass = 0; tpass < 8; ++tpass) rnext[tpass] = *reinterpret_cast<const u32x4*>(r0 + (int64_t)tpass * 8 * p.ldr);
+        };
+        if constexpr (RES_AHEAD) {
+            if (res_ahead && sub_inside(0, 0)) fetch_residual(0, 0);
+        }
+#pragma unroll
+        for (int sm = 0; sm < T::WTM / 64; ++sm) {
+#pragma unroll
+            for (int sn = 0; sn < T::WTN / 64; ++sn) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            stg[(i * 16 + (lane >> 4) * 4 + e) * EPI_LD + j * 16 + (lane & 15)] = acc[sm * 4 + i][sn * 4 + j][e];
+                __builtin_amdgcn_wave_barrier();
+                const int64_t gn = n0 + wc0 + sn * 64 + (lane & 7) * 8;
+                const int64_t gm0 = m0 + wr0 + sm * 64;
+                [[maybe_unused]] u32x4 rcur[8];
+                if constexpr (RES_AHEAD) {
+#pragma unroll
+                    for (int tpass = 0; tpass < 8; ++tpass) rcur[tpass] = rnext[tpass];
+                    const int nxt = sm * SUBS_N + sn + 1;
+                    if (nxt < SUBS && res_ahead && sub_inside(nxt / SUBS_N, nxt % SUBS_N)) fetch_residual(nxt / SUBS_N, nxt % SUBS_N);
+                }
+                auto passes = [&](auto full_c) __attribute__((always_inline)) {
+                    constexpr bool FULL = decltype(full_c)::value;
+                    if (p.ksplit > 1) {  // raw fp32 partial sums; residual / conversion happen in splitk_reduce_kernel
+                        if constexpr (OUT_DT == MI355_DT_F32) {
+                            float* slab = p.ws + (int64_t)split * p.M * p.N;
+#pragma unroll
+                            for (int tpass = 0; tpass < 8; ++tpass) {
+                                const int row = tpass * 8 + (lane >> 3);
+                                const int64_t gm = gm0 + row;
+                                if (!FULL && (gm >= p.M || gn >= p.N)) continue;  // N % 8 == 0 is required for split-K
+                                *reinterpret_cast<f32x4*>(slab + gm * p.N + gn) = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + (lane & 7) * 8);
+                                *reinterpret_cast<f32x4*>(slab + gm * p.N + gn + 4) = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + (lane & 7) * 8 + 4);
+                            }
+                        }
+                    } else {
+                        const bool vec_ok = FULL || ((gn + 8 <= p.N) && aligned_io);
+#pragma unroll
+                        for (int tpass = 0; tpass < 8; ++tpass) {
+                            const int row = tpass * 8 + (lane >> 3);
+                            const int64_t gm = gm0 + row;
+                            if (!FULL && (gm >= p.M || gn >= p.N)) continue;
+                            float v[8];
+                            const f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + (lane & 7) * 8);
+                            const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + (lane & 7) * 8 + 4);
+                            v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3];
+                            v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
+                            const int nvalid = FULL ? 8 : (int)min((int64_t)8, p.N - gn);
+                            if (p.bias) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e)
+                                    if (e < nvalid) v[e] += p.bias[gn + e];
+                            }
+                            if (KIND == MI355_EPI_GELU_ERF) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+                            }
+                            if constexpr (OUT_DT == MI355_DT_BF16) {
+                                bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + gm * p.ldc + gn;
+                                const bf16_t* r = p.R ? reinterpret_cast<const bf16_t*>(p.R) + gm * p.ldr + gn : nullptr;
+                                if (KIND == MI355_EPI_GELU_DUAL_ERF || KIND == MI355_EPI_GELU_DUAL_TANH) {
+                                    // v = acc + bias = the pre-activation: C gets it (the backward needs it), R (an OUTPUT here) gets gelu of its bf16 value
+                                    u32x4 y1, act;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        y1[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+                                        const float lo = __uint_as_float(y1[e] << 16), hi = __uint_as_float(y1[e] & 0xffff0000u);
+                                        act[e] = KIND == MI355_EPI_GELU_DUAL_ERF ? pack_bf2(gelu_val<0>(lo), gelu_val<0>(hi)) : pack_bf2(gelu_val<1>(lo), gelu_val<1>(hi));
+                                    }
+                                    *reinterpret_cast<u32x4*>(c) = y1;
+                                    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(const_cast<void*>(p.R)) + gm * p.ldr + gn) = act;
+                                    continue;
+                                }
+                                if (KIND == MI355_EPI_GELU_BWD_ERF || KIND == MI355_EPI_GELU_BWD_TANH) {
+                                    // acc = d(act); R = the forward's pre-activation: C = bf16(acc) * gelu'(R)  (== dgrad GEMM -> mi355_gelu_bwd)
+                                    const u32x4 xv = *reinterpret_cast<const u32x4*>(r);
+                                    u32x4 o;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        const float x0 = __uint_as_float(xv[e] << 16), x1 = __uint_as_float(xv[e] & 0xffff0000u);
+                                        const float d0 = bf2f(f2bf(v[2 * e])), d1 = bf2f(f2bf(v[2 * e + 1]));
+                                        o[e] = KIND == MI355_EPI_GELU_BWD_ERF ? pack_bf2(d0 * gelu_grad<0>(x0), d1 * gelu_grad<0>(x1))
+                                                                                     : pack_bf2(d0 * gelu_grad<1>(x0), d1 * gelu_grad<1>(x1));
+                                    }
+                                    *reinterpret_cast<u32x4*>(c) = o;
+                                    continue;
+                                }
+                                if (KIND == MI355_EPI_SWIGLU_FWD) {
+                                    // this wave's 64 staging columns = [u (32) | g (32)] of hidden units hid0..hid0+31 (see the DMA plan): lanes 0-3 of each
+                                    // row group write u into C[:, hid] and a = u * silu(g) into R[:, hid], lanes 4-7 write g into C[:, N/2 + hid];
+                                    // u, g are rounded to bf16 first, so a equals mi355_swiglu_fwd on the stored gate-up output bit for bit.
+                                    const int l8 = lane & 7;
+                                    const int64_t nh = p.N >> 1;
+                                    const int64_t hid = (n0 >> 1) + ((wc0 + sn * 64) >> 6) * 32 + (l8 & 3) * 8;
+                                    if (hid >= nh) continue;
+                                    bf16_t* gu_row = reinterpret_cast<bf16_t*>(p.C) + gm * p.ldc;
+                                    u32x4 own;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) own[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+                                    if (l8 >= 4) {
+                                        *reinterpret_cast<u32x4*>(gu_row + nh + hid) = own;
+                                        continue;
+                                    }
+                                    *reinterpret_cast<u32x4*>(gu_row + hid) = own;
+                                    const float* gp_ = stg + row * EPI_LD + 32 + l8 * 8;
+                                    u32x4 av;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        float a2[2];
+#pragma unroll
+                                        for (int hlf = 0; hlf < 2; ++hlf) {
+                                            const float u_ = hlf ? __uint_as_float(own[e] & 0xffff0000u) : __uint_as_float(own[e] << 16);
+                                            const float g_ = bf2f(f2bf(gp_[2 * e + hlf]));
+                                            a2[hlf] = u_ * bf2f(f2bf(g_ / (1.0f + __expf(-g_))));
+                                        }
+                                        av[e] = pack_bf2(a2[0], a2[1]);
+                                    }
+                                    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(const_cast<void*>(p.R)) + gm * p.ldr + hid) = av;
+                                    continue;
+                                }
+                                if (KIND == MI355_EPI_SWIGLU_BWD) {
+                                    // acc = d(act) for hidden units gn..gn+7; R = the forward's gate-up output [u | g] (ldr = 2N): write
+                                    // d(gate-up) = [acc * g*sig(g) | acc * u * sig(g) (1 + g (1 - sig(g)))] into C (ldc = 2N).  acc is rounded to
+                                    // bf16 first, so the result equals mi355_swiglu_bwd on the stored bf16 d(act) bit for bit.
+                                    const u32x4 uv = *reinterpret_cast<const u32x4*>(r);
+                                    const u32x4 gv = *reinterpret_cast<const u32x4*>(r + p.N);
+                                    float du[8], dg[8];
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                                        for (int hlf = 0; hlf < 2; ++hlf) {
+                                            const float u_ = hlf ? __uint_as_float(uv[e] & 0xffff0000u) : __uint_as_float(uv[e] << 16);
+                                            const float g_ = hlf ? __uint_as_float(gv[e] & 0xffff0000u) : __uint_as_float(gv[e] << 16);
+                                            const float d_ = bf2f(f2bf(v[2 * e + hlf]));
+                                            const float sg = 1.0f / (1.0f + __expf(-g_));
+                                            du[2 * e + hlf] = d_ * g_ * sg;
+                                            dg[2 * e + hlf] = d_ * u_ * sg * (1.0f + g_ * (1.0f - sg));
+                                        }
+                                    }
+                                    u32x4 o0, o1;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        o0[e] = pack_bf2(du[2 * e], du[2 * e + 1]);
+                                        o1[e] = pack_bf2(dg[2 * e], dg[2 * e + 1]);
+                                    }
+                                    *reinterpret_cast<u32x4*>(c) = o0;
+                                    *reinterpret_cast<u32x4*>(c + p.N) = o1;
+                                    continue;
+                                }
+                                if (vec_ok) {
+                                    if (r) {
+                                        u32x4 rv;
+                                        if constexpr (FULL && RES_AHEAD) rv = rcur[tpass];  // ksplit == 1 on this branch: fetched a sub-block ago
+                                        else rv = *reinterpret_cast<const u32x4*>(r);
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) {
+                                            v[2 * e] += __uint_as_float(rv[e] << 16);
+                                            v[2 * e + 1] += __uint_as_float(rv[e] & 0xffff0000u);
+                                        }
+                                    }
+                                    u32x4 o;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) o[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+                                    *reinterpret_cast<u32x4*>(c) = o;
+                                } else {
+                                    for (int e = 0; e < nvalid; ++e) c[e] = f2bf(v[e] + (r ? bf2f(r[e]) : 0.f));
+                                }
+                            } else {
+                                float* c = reinterpret_cast<float*>(p.C) + gm * p.ldc + gn;
+                                const float* r = p.R ? reinterpret_cast<const float*>(p.R) + gm * p.ldr + gn : nullptr;
+                                if (vec_ok) {
+                                    f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                                    if (r) {
+                                        o0 += *reinterpret_cast<const f32x4*>(r);
+                                        o1 += *reinterpret_cast<const f32x4*>(r + 4);
+                                    }
+                                    *reinterpret_cast<f32x4*>(c) = o0;
+                                    *reinterpret_cast<f32x4*>(c + 4) = o1;
+                                } else {
+                                    for (int e = 0; e < nvalid; ++e) c[e] = v[e] + (r ? r[e] : 0.f);
+                                }
+                            }
+                        }
+                    }
+                };
+                if constexpr (KSEL >= 0) {
+                    if (aligned_io && gm0 + 64 <= p.M && n0 + wc0 + sn * 64 + 64 <= p.N) passes(std::true_type{});
+                    else passes(std::false_type{});
+                } else {
+                    passes(std::false_type{});
+                }
+                __builtin_amdgcn_wave_barrier();  // the staging area is rewritten by the next 64x64 sub-block
+            }
+        }
+    };
+    // a third copy of the passes for the SwiGLU-forward form (231.9 vs 233.6 ms/step); not on the 4-wave tile, where a third copy of its four
+    // sub-blocks stops the unroller and the accumulators land in scratch
+    constexpr bool SWIGLU_FWD_COPY = !A_TR && !B_TR && OUT_DT == MI355_DT_BF16 && T::NW == 8;
+    constexpr bool SWIGLU_BWD_COPY = !A_TR && B_TR && OUT_DT == MI355_DT_BF16 && T::NW == 8;  // the down-projection's dgrad
+    if (p.epilogue == MI355_EPI_NONE) {
+        run_epilogue(std::integral_constant<int, MI355_EPI_NONE>{});
+    } else if (SWIGLU_FWD_COPY && p.epilogue == MI355_EPI_SWIGLU_FWD) {
+        if constexpr (SWIGLU_FWD_COPY) run_epilogue(std::integral_constant<int, MI355_EPI_SWIGLU_FWD>{});  // the step's largest forward GEMM
+    } else if (SWIGLU_BWD_COPY && p.epilogue == MI355_EPI_SWIGLU_BWD) {
+        if constexpr (SWIGLU_BWD_COPY) run_epilogue(std::integral_constant<int, MI355_EPI_SWIGLU_BWD>{});
+    } else {
+        run_epilogue(std::integral_constant<int, -1>{});  // other fused forms: kind read at run time, bounds checked per row
+    }
+}
+
+template <class T, bool A_TR, bool B_TR, int OUT_DT>
+__global__ __launch_bounds__(T::NTHREADS, T::MIN_WAVES) void gemm_bf16_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[T::SMEM];
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int split = blockIdx.x / nwg;
+    gemm_tile<T, A_TR, B_TR, OUT_DT>(p, xcd_chunked(blockIdx.x - split * nwg, nwg), split, smem);
+}
+
+// Several independent problems of one operand form in ONE launch (the four weight gradients of a transformer block:
+// each alone has fewer output tiles than the chip has CUs, together they fill it).  The concatenated tile list is cut
+// into one contiguous chunk per XCD, so the tiles that share operand panels stay behind one L2.
+constexpr int MAX_GROUP = 8;
+struct GroupTable {
+    GemmParams g[MAX_GROUP];
+    int start[MAX_GROUP + 1];  // first tile of each problem in the concatenated list
+    int count;
+};
+
+template <class T, bool A_TR, bool B_TR, int OUT_DT>
+__global__ __launch_bounds__(T::NTHREADS, T::MIN_WAVES) void gemm_grouped_kernel(GroupTable tbl) {
+    __shared__ __attribute__((aligned(16))) char smem[T::SMEM];
+    const int v = xcd_chunked(blockIdx.x, tbl.start[tbl.count]);
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_GROUP; ++i)
+        if (i < tbl.count && v >= tbl.start[i]) g = i;
+    const GemmParams p = tbl.g[g];
+    gemm_tile<T, A_TR, B_TR, OUT_DT>(p, v - tbl.start[g], 0, smem);
+}
+
+// C = sum_s slab[s] (+ R), converted to the output dtype.  4 columns per thread (N % 8 == 0).
+template <int OUT_DT>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(int64_t M, int64_t N, int ksplit, const float* __restrict__ ws,
+                                                            void* __restrict__ C, int64_t ldc, const void* __restrict__ R, int64_t ldr) {
+    const int64_t nv = N >> 2, total = M * nv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / nv, n = (i - m * nv) * 4;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(ws + m * N + n);
+        for (int sidx = 1; sidx < ksplit; ++sidx) acc += *reinterpret_cast<const f32x4*>(ws + ((int64_t)sidx * M + m) * N + n);
+        if constexpr (OUT_DT == MI355_DT_BF16) {
+            bf16_t* c = reinterpret_cast<bf16_t*>(C) + m * ldc + n;
+            if (R) {
+                const bf16_t* r = reinterpret_cast<const bf16_t*>(R) + m * ldr + n;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += bf2f(r[e]);
+            }
+            *reinterpret_cast<u32x2*>(c) = (u32x2){pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3])};
+        } else {
+            float* c = reinterpret_cast<float*>(C) + m * ldc + n;
+            if (R) acc += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(R) + m * ldr + n);
+            *reinterpret_cast<f32x4*>(c) = acc;
+        }
+    }
+}
+
+// K-split heuristic: wgrad-like problems (few output tiles, very long K) leave most CUs idle.
+int choose_ksplit(int64_t tiles, int64_t slots, int64_t K, int64_t M, int64_t N, int epilogue, const float* bias, int64_t ldc, int64_t ldr, int64_t ws_bytes) {
+    if (bias || epilogue != MI355_EPI_NONE || (N & 7) || (ldc & 3) || (ldr & 3)) return 1;
+    const int64_t kt = (K + 63) / 64;
+    if (tiles > slots / 2 || kt < 32) return 1;  // over half the resident slots already: the reduce pass costs more than it buys
+    int64_t ks = (slots + slots / 4 + tiles - 1) / tiles;
+    if (ks > kt / 8) ks = kt / 8;
+    if (ks > 16) ks = 16;
+    while (ks > 1 && ks * M * N * 4 > ws_bytes) --ks;
+    return ks < 2 ? 1 : (int)ks;
+}
+
+template <class T, bool A_TR, bool B_TR>
+int launch(GemmParams p, int out_dtype, void* workspace, int64_t workspace_bytes, hipStream_t s) {
+    p.tiles_m = (int)((p.M + T::BM - 1) / T::BM);
+    p.tiles_n = (int)((p.N + T::BN - 1) / T::BN);
+    const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n;
+    MI355_REQUIRE(tiles < 0x7fffffffLL / 16, "mi355_gemm_bf16: grid too large");
+    constexpr int WG_PER_CU = (T::MIN_WAVES * 256 / T::NTHREADS) > 0 ? (T::MIN_WAVES * 256 / T::NTHREADS) : 1;
+    const int64_t slots = 256 * WG_PER_CU;  // workgroups resident on the chip at once
+    p.ws = (float*)workspace;
+    p.ksplit = workspace ? choose_ksplit(tiles, slots, p.K, p.M, p.N, p.epilogue, p.bias, p.ldc, p.R ? p.ldr : 0, workspace_bytes) : 1;
+    const int grid = (int)(tiles * p.ksplit);
+    if (p.ksplit > 1) {
+        hipLaunchKernelGGL((gemm_bf16_kernel<T, A_TR, B_TR, MI355_DT_F32>), dim3(grid), dim3(T::NTHREADS), 0, s, p);
+        const int64_t work = p.M * (p.N >> 2);
+        const int rgrid = (int)((work + 255) / 256 > 2048 ? 2048 : (work + 255) / 256);
+        if (out_dtype == MI355_DT_BF16)
+            hipLaunchKernelGGL(splitk_reduce_kernel<MI355_DT_BF16>, dim3(rgrid), dim3(256), 0, s, p.M, p.N, p.ksplit, p.ws, p.C, p.ldc, p.R, p.ldr);
+        else
+            hipLaunchKernelGGL(splitk_reduce_kernel<MI355_DT_F32>, dim3(rgrid), dim3(256), 0, s, p.M, p.N, p.ksplit, p.ws, p.C, p.ldc, p.R, p.ldr);
+        MI355_LAUNCH_CHECK("mi355_gemm_bf16(split-K)");
+        return 0;
+    }
+    if (out_dtype == MI355_DT_BF16)
+        hipLaunchKernelGGL((gemm_bf16_kernel<T, A_TR, B_TR, MI355_DT_BF16>), dim3(grid), dim3(T::NTHREADS), 0, s, p);
+    else
+        hipLaunchKernelGGL((gemm_bf16_kernel<T, A_TR, B_TR, MI355_DT_F32>), dim3(grid), dim3(T::NTHREADS), 0, s, p);
+    MI355_LAUNCH_CHECK("mi355_gemm_bf16");
+    return 0;
+}
+
+template <class T>
+int launch_form(int form, const GemmParams& p, int out_dtype, void* ws, int64_t ws_bytes, hipStream_t s) {
+    switch (form) {
+        case MI355_GEMM_NT: return launch<T, false, false>(p, out_dtype, ws, ws_bytes, s);
+        case MI355_GEMM_NN: return launch<T, false, true>(p, out_dtype, ws, ws_bytes, s);
+        default: return launch<T, true, true>(p, out_dtype, ws, ws_bytes, s);
+    }
+}
+
+template <class T, bool A_TR, bool B_TR>
+int launch_grouped(GroupTable& tbl, int out_dtype, hipStream_t s) {
+    int64_t total = 0;
+    for (int i = 0; i < tbl.count; ++i) {
+        GemmParams& p = tbl.g[i];
+        p.tiles_m = (int)((p.M + T::BM - 1) / T::BM);
+        p.tiles_n = (int)((p.N + T::BN - 1) / T::BN);
+        tbl.start[i] = (int)total;
+        total += (int64_t)p.tiles_m * p.tiles_n;
+        MI355_REQUIRE(total < 0x7fffffffLL / 16, "mi355_gemm_bf16_grouped: grid too large");
+    }
+    for (int i = tbl.count; i <= MAX_GROUP; ++i) tbl.start[i] = (int)total;
+    if (out_dtype == MI355_DT_BF16)
+        hipLaunchKernelGGL((gemm_grouped_kernel<T, A_TR, B_TR, MI355_DT_BF16>), dim3((unsigned)total), dim3(T::NTHREADS), 0, s, tbl);
+    else
+        hipLaunchKernelGGL((gemm_grouped_kernel<T, A_TR, B_TR, MI355_DT_F32>), dim3((unsigned)total), dim3(T::NTHREADS), 0, s, tbl);
+    MI355_LAUNCH_CHECK("mi355_gemm_bf16_grouped");
+    return 0;
+}
+
+template <class T>
+int launch_grouped_form(int form, GroupTable& tbl, int out_dtype, hipStream_t s) {
+    switch (form) {
+        case MI355_GEMM_NT: return launch_grouped<T, false, false>(tbl, out_dtype, s);
+        case MI355_GEMM_NN: return launch_grouped<T, false, true>(tbl, out_dtype, s);
+        default: return launch_grouped<T, true, true>(tbl, out_dtype, s);
+    }
+}
+
+int check_operands(const char* who, int form, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, const void* C) {
+    MI355_REQUIRE(M > 0 && N > 0 && K > 0, "%s: empty problem M=%ld N=%ld K=%ld", who, (long)M, (long)N, (long)K);
+    MI355_REQUIRE(A && B && C, "%s: null operand", who);
+    MI355_REQUIRE((lda & 7) == 0 && (ldb & 7) == 0, "%s: lda/ldb must be multiples of 8 (16-byte rows)", who);
+    MI355_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "%s: A/B must be 16-byte aligned", who);
+    if (form == MI355_GEMM_NT) MI355_REQUIRE((K & 7) == 0, "%s(NT): K must be a multiple of 8", who);
+    if (form == MI355_GEMM_NN) MI355_REQUIRE((K & 7) == 0 && (N & 7) == 0, "%s(NN): K,N must be multiples of 8", who);
+    if (form == MI355_GEMM_TN) MI355_REQUIRE((M & 7) == 0 && (N & 7) == 0, "%s(TN): M,N must be multiples of 8", who);
+    // a tile's DMA offsets are 31-bit: 256 rows (or 64 k-rows) of one operand must span < 2 GiB
+    MI355_REQUIRE(lda * 2 * 256 < 0x7fffffffLL && ldb * 2 * 256 < 0x7fffffffLL, "%s: leading dimension too large", who);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- colsum
+template <int DT>
+__global__ __launch_bounds__(256) void colsum_kernel(int64_t M, int64_t N, const void* Xv, int64_t ldx, float* out, int rows_per_block) {
+    // block = 256 threads = 64 columns x 4 row-lanes; grid.x over column groups, grid.y over row slabs
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = min(M, r0 + rows_per_block);
+    float s = 0.f;
+    if (col < N)
+        for (int64_t r = r0 + rl; r < r1; r += 4)
+            s += DT == MI355_DT_BF16 ? bf2f(reinterpret_cast<const bf16_t*>(Xv)[r * ldx + col]) : reinterpret_cast<const float*>(Xv)[r * ldx + col];
+    red[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && col < N) {
+        s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        atomicAdd(out + col, s);
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------- translation-unit split
+// This file is compiled once per tile configuration (-DGEMM_PART=1..5: that configuration's kernels behind two bridge functions) and once
+// for the entry points (-DGEMM_PART=0), so the objects build in parallel; parameter blocks cross the bridge as untyped pointers (every part
+// is this same source, so the layouts agree).  Without -DGEMM_PART everything lands in one object.
+#ifndef GEMM_PART
+#define GEMM_PART -1
+#endif
+#define GEMM_BRIDGE_DECL(N)                                                                                                                       \
+    extern "C" __attribute__((visibility("hidden"))) int mi355_gemm_part##N(int form, const void* params, int out_dtype, void* ws, int64_t ws_bytes, void* stream); \
+    extern "C" __attribute__((visibility("hidden"))) int mi355_gemm_grouped_part##N(int form, void* table, int out_dtype, void* stream);
+#define GEMM_BRIDGE_DEF(N, CFG)                                                                                                                   \
+    extern "C" int mi355_gemm_part##N(int form, const void* params, int out_dtype, void* ws, int64_t ws_bytes, void* stream) {                     \
+        return launch_form<CFG>(form, *static_cast<const GemmParams*>(params), out_dtype, ws, ws_bytes, (hipStream_t)stream);                      \
+    }                                                                                                                                             \
+    extern "C" int mi355_gemm_grouped_part##N(int form, void* table, int out_dtype, void* stream) {                                                \
+        return launch_grouped_form<CFG>(form, *static_cast<GroupTable*>(table), out_dtype, (hipStream_t)stream);                                   \
+    }
+GEMM_BRIDGE_DECL(1) GEMM_BRIDGE_DECL(2) GEMM_BRIDGE_DECL(3) GEMM_BRIDGE_DECL(4) GEMM_BRIDGE_DECL(5)
+#if GEMM_PART == 1 || GEMM_PART == -1
+GEMM_BRIDGE_DEF(1, Cfg128)
+#endif
+#if GEMM_PART == 2 || GEMM_PART == -1
+GEMM_BRIDGE_DEF(2, Cfg256)
+#endif
+#if GEMM_PART == 3 || GEMM_PART == -1
+GEMM_BRIDGE_DEF(3, Cfg256a)
+#endif
+#if GEMM_PART == 4 || GEMM_PART == -1
+GEMM_BRIDGE_DEF(4, Cfg256b)
+#endif
+#if GEMM_PART == 5 || GEMM_PART == -1
+GEMM_BRIDGE_DEF(5, Cfg256w)
+#endif
+
+#if GEMM_PART <= 0
+#if GEMM_PROF
+extern "C" int mi355_debug_gemm_prof(unsigned long long* out, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_prof), sizeof(unsigned long long) * 32) != hipSuccess) return 2;
+    if (reset) {
+        unsigned long long z[32] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_prof), z, sizeof(z)) != hipSuccess) return 3;
+    }
+    return 0;
+}
+#endif
+
+extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                               int64_t ldb, void* C, int64_t ldc, int out_dtype, const float* bias,
+                               const void* residual, int64_t ldr, int epilogue, void* workspace, int64_t workspace_bytes,
+                               int tile_hint, void* stream) {
+    MI355_REQUIRE(form >= 0 && form <= 2, "mi355_gemm_bf16: bad form %d", form);
+    MI355_REQUIRE(out_dtype == MI355_DT_BF16 || out_dtype == MI355_DT_F32, "mi355_gemm_bf16: bad out_dtype");
+    if (int rc = check_operands("mi355_gemm_bf16", form, M, N, K, A, lda, B, ldb, C)) return rc;
+    MI355_REQUIRE(workspace == nullptr || ((uintptr_t)workspace & 15) == 0, "mi355_gemm_bf16: workspace must be 16-byte aligned");
+    MI355_REQUIRE(epilogue == MI355_EPI_NONE || epilogue == MI355_EPI_GELU_ERF || epilogue == MI355_EPI_SWIGLU_BWD || epilogue == MI355_EPI_SWIGLU_FWD || (epilogue >= MI355_EPI_GELU_DUAL_ERF && epilogue <= MI355_EPI_GELU_BWD_TANH), "mi355_gemm_bf16: unknown epilogue %d", epilogue);
+    if (epilogue >= MI355_EPI_GELU_DUAL_ERF && epilogue <= MI355_EPI_GELU_BWD_TANH)
+        MI355_REQUIRE(out_dtype == MI355_DT_BF16 && residual && (N & 7) == 0 && (ldc & 7) == 0 && (ldr & 7) == 0 && ldr >= N &&
+                          (((uintptr_t)residual | (uintptr_t)C) & 15) == 0 && (epilogue <= MI355_EPI_GELU_DUAL_TANH || !bias),
+                      "mi355_gemm_bf16(GELU dual / backward epilogue): bf16 output, N %% 8 == 0, `residual` = the second [M, N] operand (activation output, resp. "
+                      "the forward's pre-activation), no bias in the backward form");
+    if (epilogue == MI355_EPI_SWIGLU_FWD)
+        MI355_REQUIRE(form == MI355_GEMM_NT && out_dtype == MI355_DT_BF16 && residual && !bias && (N & 63) == 0 && ldc >= N && ldr >= N / 2 && (ldc & 7) == 0 &&
+                          (ldr & 7) == 0 && (((uintptr_t)residual | (uintptr_t)C) & 15) == 0,
+                      "mi355_gemm_bf16(SwiGLU forward epilogue): NT form, bf16 gate-up output [M, N] with N = 2F, F %% 32 == 0, `residual` = the activation output [M, F], no bias");
+    if (epilogue == MI355_EPI_SWIGLU_BWD)
+        MI355_REQUIRE(out_dtype == MI355_DT_BF16 && residual && !bias && (N & 7) == 0 && ldc >= 2 * N && ldr >= 2 * N && (ldc & 7) == 0 && (ldr & 7) == 0 &&
+                          (((uintptr_t)residual | (uintptr_t)C) & 15) == 0,
+                      "mi355_gemm_bf16(SwiGLU backward epilogue): bf16 output [M, 2N] (ldc >= 2N), residual = the forward gate-up output [M, 2N], N %% 8 == 0, no bias");
+    const int ablate = tile_hint >> 8;
+    tile_hint &= 0xff;
+    MI355_REQUIRE(tile_hint >= 0 && tile_hint <= 5, "mi355_gemm_bf16: tile_hint must be 0 (auto), 1 (128x128), 2 (256x256), 3 (256x256, alternating wave groups), 4 (3 with one barrier per phase) or 5 (256x256, four waves of 128x128)");
+    GemmParams p;
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.bias = bias; p.R = residual;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
+    p.epilogue = epilogue; p.tiles_m = p.tiles_n = 0; p.ksplit = 1; p.ws = nullptr; p.ablate = ablate;
+    hipStream_t s = (hipStream_t)stream;
+    int cfg = tile_hint;
+    if (cfg == 0) {
+        // measured on MI355X over the VLM step's shapes (tools/gemm_sweep.py): the alternating-group 256x256 kernel wins for
+        // forward / dgrad shapes and for the large weight gradients; small weight gradients (few tiles, K = tokens) do
+        // better on 128x128 tiles with split-K; tiny problems stay on 128x128.
+        // Tile 4 (one barrier per phase, 5 stages) wins every isolated sweep (+5-14 % NT, +10-13 % TN on warm operands) but
+        // LOSES inside the training step, where operands arrive cold from the previous kernel: A/B in one process,
+        // per form, 246.2 ms/step with tile 3 everywhere vs +0.9 (NT) / +4.3 (NN) / +0.5 (TN) ms with tile 4.  The step decides.
+        // The same A/B puts the forward projections (NT) on tile 2 (BK 64, two stages, fragments prefetched one phase ahead):
+        // 239.3 vs 243.8-246 ms/step with NT on tile 3, although tile 3 is 10-20 % faster on every isolated NT shape.
+        // 256x256 tiles need at least half of the 256 CUs' worth of tiles; below that (small token counts: config 5 at B = 8 has 92 tiles for
+        // its N = 1024 outputs) four times as many 128x128 tiles, two workgroups per CU, fill the chip instead
+        const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
+        if (M < 256 || N < 256) cfg = 1;
+        else if (form != MI355_GEMM_TN && tiles256 < 128) cfg = 1;  // measured: 92 tiles -> 128x128 wins (+2.8 % on the config-5 step), 180 tiles -> 256x256 wins
+        else if (form == MI355_GEMM_TN) cfg = (M * N > 5 * 1024 * 1024) ? 3 : 1;
+        else if (form == MI355_GEMM_NT) cfg = 2;
+        else cfg = 3;
+    }
+    switch (cfg) {
+        case 2: return mi355_gemm_part2(form, &p, out_dtype, workspace, workspace_bytes, s);
+        case 3: return mi355_gemm_part3(form, &p, out_dtype, workspace, workspace_bytes, s);
+        case 4: return mi355_gemm_part4(form, &p, out_dtype, workspace, workspace_bytes, s);
+        case 5: return mi355_gemm_part5(form, &p, out_dtype, workspace, workspace_bytes, s);
+        default: return mi355_gemm_part1(form, &p, out_dtype, workspace, workspace_bytes, s);
+    }
+}
+
+extern "C" int mi355_gemm_bf16_grouped(int form, int count, const mi355_gemm_problem* problems, int out_dtype, int tile_hint,
+                                       void* stream) {
+    MI355_REQUIRE(form >= 0 && form <= 2, "mi355_gemm_bf16_grouped: bad form %d", form);
+    MI355_REQUIRE(count >= 1 && count <= MAX_GROUP && problems, "mi355_gemm_bf16_grouped: count must be 1..%d", MAX_GROUP);
+    MI355_REQUIRE(out_dtype == MI355_DT_BF16 || out_dtype == MI355_DT_F32, "mi355_gemm_bf16_grouped: bad out_dtype");
+    MI355_REQUIRE(tile_hint == 0 || tile_hint == 1 || tile_hint == 3 || tile_hint == 4, "mi355_gemm_bf16_grouped: tile_hint must be 0 (auto), 1 (128x128), 3 or 4 (256x256)");
+    GroupTable tbl;
+    tbl.count = count;
+    int64_t tiles256 = 0;
+    bool small = false;
+    for (int i = 0; i < count; ++i) {
+        const mi355_gemm_problem& q = problems[i];
+        if (int rc = check_operands("mi355_gemm_bf16_grouped", form, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C)) return rc;
+        GemmParams& p = tbl.g[i];
+        p.A = (const bf16_t*)q.A; p.B = (const bf16_t*)q.B; p.C = q.C; p.bias = nullptr; p.R = q.residual;
+        p.M = q.M; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc; p.ldr = q.ldr;
+        p.epilogue = MI355_EPI_NONE; p.tiles_m = p.tiles_n = 0; p.ksplit = 1; p.ws = nullptr; p.ablate = 0;
+        tiles256 += ((q.M + 255) / 256) * ((q.N + 255) / 256);
+        small |= q.M < 256 || q.N < 256;
+    }
+    for (int i = count; i < MAX_GROUP; ++i) tbl.g[i] = tbl.g[0];
+    // 256x256 tiles (one workgroup per CU) once they cover most of the chip; otherwise 128x128 (two per CU, 4x the tiles)
+    const int cfg = tile_hint ? tile_hint : ((small || tiles256 < 160) ? 1 : 3);
+    hipStream_t s = (hipStream_t)stream;
+    if (cfg == 4) return mi355_gemm_grouped_part4(form, &tbl, out_dtype, s);
+    if (cfg == 3) return mi355_gemm_grouped_part3(form, &tbl, out_dtype, s);
+    return mi355_gemm_grouped_part1(form, &tbl, out_dtype, s);
+}
+
+extern "C" int mi355_colsum(int64_t M, int64_t N, const void* X, int x_dtype, int64_t ldx, float* out, int accumulate,
+                            void* stream) {
+    MI355_REQUIRE(M > 0 && N > 0 && X && out, "mi355_colsum: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate) {
+        if (hipMemsetAsync(out, 0, N * sizeof(float), s) != hipSuccess) {
+            mi355_set_error("mi355_colsum: memset failed");
+            return 2;
+        }
+    }
+    const int rows_per_block = 512;
+    dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + rows_per_block - 1) / rows_per_block));
+    if (x_dtype == MI355_DT_BF16)
+        hipLaunchKernelGGL(colsum_kernel<MI355_DT_BF16>, grid, dim3(256), 0, s, M, N, X, ldx, out, rows_per_block);
+    else
+        hipLaunchKernelGGL(colsum_kernel<MI355_DT_F32>, grid, dim3(256), 0, s, M, N, X, ldx, out, rows_per_block);
+    MI355_LAUNCH_CHECK("mi355_colsum");
+    return 0;
+}
+#endif  // GEMM_PART <= 0
