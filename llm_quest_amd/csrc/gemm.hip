@@ -171,6 +171,15 @@ __device__ __forceinline__ void frag_tr_issue(TrHalves& f, const char* tile, int
 }
 __device__ __forceinline__ bf16x8 tr_join(const TrHalves& f) { return __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7); }
 #define TRH(x) "+v"((x).lo), "+v"((x).hi)
+// counted wait that names the fragments it covers (N = LDS instructions issued after them; LDS returns in issue order), then joins them
+template <int N, int CNT>
+__device__ __forceinline__ void tr_wait_join(TrHalves (&h)[CNT], bf16x8 (&out)[CNT]) {
+    static_assert(N >= 0 && N <= 15 && CNT % 2 == 0, "lgkmcnt field is 4 bits; fragments are named in pairs");
+#pragma unroll
+    for (int k = 0; k < CNT; k += 2) asm volatile("s_waitcnt lgkmcnt(%4)" : TRH(h[k]), TRH(h[k + 1]) : "n"(N) : "memory");
+#pragma unroll
+    for (int k = 0; k < CNT; ++k) out[k] = tr_join(h[k]);
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -587,6 +596,57 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
     for (int i = 0; i < T::NS - 1; ++i)
         if (t0 + i < nt) issue_tile(t0 + i, i);
     bf16x8 aE[HM], aO[HM], b0[T::FN], b1[T::FN];
+    if constexpr (A_TR && B_TR) {
+        // weight gradients: the same four-phase schedule with the transposing reads issued from asm (see frag_tr_issue) and a counted,
+        // operand-naming lgkmcnt in front of every MFMA cluster: 2 LDS instructions per fragment, so with the reads of the following
+        // phase(s) already in flight a cluster waits for all but the 2*HM (phases 0, 2) or 2*FN + 2*HM (phases 1, 3) youngest.
+        constexpr int YA = 2 * HM < 15 ? 2 * HM : 15, YAB = 2 * T::FN + 2 * HM < 15 ? 2 * T::FN + 2 * HM : 15;
+        TrHalves hE[HM], hO[HM], h0[T::FN], h1[T::FN];
+        auto ldA = [&](TrHalves (&h)[HM], const char* sA, int kk, int mh) {
+#pragma unroll
+            for (int i = 0; i < HM; ++i) frag_tr_issue<T::BM>(h[i], sA, wr0 + (mh * HM + i) * 16, kk, lane);
+        };
+        auto ldB = [&](TrHalves (&h)[T::FN], const char* sB, int kk) {
+#pragma unroll
+            for (int j = 0; j < T::FN; ++j) frag_tr_issue<T::BN>(h[j], sB, wc0 + j * 16, kk, lane);
+        };
+        if (t0 < nt) {
+            wait_tile(nt - 1 - t0);
+            __builtin_amdgcn_s_barrier();
+            if (t0 + T::NS - 1 < nt) issue_tile(t0 + T::NS - 1, T::NS - 1);
+            ldB(h0, smem + T::A_BYTES, 0);
+            ldA(hE, smem, 0, 0);
+        }
+        for (int t = t0; t < nt; ++t) {
+            const char* sA = smem + ((t - t0) % T::NS) * T::STAGE;
+            const char* sB = sA + T::A_BYTES;
+            ldA(hO, sA, 0, 1);
+            tr_wait_join<YA>(h0, b0);
+            tr_wait_join<YA>(hE, aE);
+            mma(aE, b0, 0);  // phase 0
+            ldB(h1, sB, 1);
+            ldA(hE, sA, 1, 0);
+            tr_wait_join<YAB>(hO, aO);
+            mma(aO, b0, 1);  // phase 1
+            ldA(hO, sA, 1, 1);
+            tr_wait_join<YA>(h1, b1);
+            tr_wait_join<YA>(hE, aE);
+            mma(aE, b1, 0);  // phase 2
+            if (t + 1 < nt) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of tile t are complete ...
+                wait_tile(nt - 2 - t);                              // ... and its share of tile t+1 has landed
+                __builtin_amdgcn_s_barrier();                       // ... for every wave
+                if (t + T::NS < nt) issue_tile(t + T::NS, (t - t0) % T::NS);
+                const char* nA = smem + ((t + 1 - t0) % T::NS) * T::STAGE;
+                ldB(h0, nA + T::A_BYTES, 0);
+                ldA(hE, nA, 0, 0);
+                tr_wait_join<YAB>(hO, aO);  // landed before the barrier; the wait only names them
+            } else {
+                tr_wait_join<0>(hO, aO);
+            }
+            mma(aO, b1, 1);  // phase 3
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < HM; ++i) aE[i] = aO[i] = (bf16x8){1, 2, 3, 4, 5, 6, 7, 8};
 #pragma unroll
@@ -619,6 +679,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
         }
         mma(aO, b1, 1);  // phase 3
     }
+    }  // K-contiguous operand(s): compiler-issued reads
 
     }
     if (extra_barrier) __builtin_amdgcn_s_barrier();
