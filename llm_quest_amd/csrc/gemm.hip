@@ -578,13 +578,14 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
         for (int j = 0; j < T::FN; ++j) b[j] = B_TR ? frag_tr<T::BN>(sB, wc0 + j * 16, kk, lane) : frag_rowk<BK>(sB, wc0 + j * 16, kk, lane);
     };
     auto mma = [&](const bf16x8 (&a)[HM], const bf16x8 (&b)[T::FN], int mh) {
-        __builtin_amdgcn_s_setprio(1);
+        // raised priority around the cluster: kept on the 4-wave tile; on the 8-wave tile it costs 1.5 ms/step (206.0 / 206.4 without vs 207.1 / 208.3)
+        if constexpr (T::NW != 8) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < HM; ++i)
 #pragma unroll
             for (int j = 0; j < T::FN; ++j)
                 acc[mh * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[mh * HM + i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (T::NW != 8) __builtin_amdgcn_s_setprio(0);
     };
     auto wait_tile = [&](int younger) {  // returns once at most min(NS-2, younger) younger tiles of this wave are in flight
         if (T::NS >= 4 && younger >= 2) wait_vmcnt<2 * T::DMA_PER_TILE>();
