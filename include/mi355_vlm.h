@@ -348,6 +348,40 @@ int mi355_kv_append(int B, int width, const void* k_rows, int64_t ldk, const voi
  * workspace: rows * 64 * 12 bytes (+8), 8-byte aligned: 64 column ranges per row are scanned in parallel, then merged. */
 int mi355_argmax_rows(int64_t rows, int64_t V, const void* logits, int64_t ld, int64_t* out, void* workspace, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Stand-alone rotary embedding and dropout (csrc/rope_dropout.hip, csrc/attention_generic.hip).
+ * ------------------------------------------------------------------------------------------------------------------- */
+
+/* RoPE.apply / RoPE.apply_mrope / VisionRoPE.apply on a device tensor (common/rope.py:180-243, 297-358, 484-500):
+ *   out = cos * x + sin * cat(-x2, x1) on the first R features of every head, features [R, D) copied (partial rotation),
+ * evaluated with the reference's rounding points (bf16: coefficients, both products and the sum each rounded to bf16).
+ * x / out: (B, H, S, D) views given by element strides (sb, sh, ss / ob, oh, os), unit inner stride; dtype bf16 or fp32.
+ * cos_t / sin_t fp32 [table_rows, R]; coefficient row of (b, s) = idx ? idx[b * S + s] : s.  transpose != 0 applies the
+ * adjoint map (the backward: dx from dy). */
+int mi355_rope_apply(int B, int H, int S, int D, int R, const void* x, int dtype, int64_t sb, int64_t sh, int64_t ss, const float* cos_t,
+                     const float* sin_t, int64_t table_rows, const int32_t* idx, void* out, int64_t ob, int64_t oh, int64_t os, int transpose,
+                     void* stream);
+
+/* nn.Dropout(p) in train mode (vit_model.py:146, vit_transformer_block.py:117,124, vit_engine.py:51):
+ *   y[i] = (residual ? residual[i] : 0) + (keep(i) ? x[i] / (1 - p) : 0),
+ *   keep(i) = Philox4x32-10(key = seed; counter = (i / 4, offset))[i % 4] >= round(p * 2^32).
+ * Nothing is stored: the backward is the same call on dy with the same (seed, offset).  x bf16 / fp32, y (and residual, which
+ * has y's dtype) bf16 / fp32 -- so the residual add of a block and the bf16 cast of its backward are fused into the pass. */
+int mi355_dropout(int64_t n, const void* x, int x_dtype, const void* residual, void* y, int y_dtype, float p, uint64_t seed, uint64_t offset,
+                  void* stream);
+
+/* ViTMultiHeadAttention in train mode (vit_attention.py:74-81): softmax over every key (causal = 0) or the keys <= query
+ * (causal = 1), dropout with probability p on the normalised weights, then the weighted sum of V.  Operand layout as
+ * mi355_attn_fwd/bwd; D in {32, 64, 128, 256}.  Weight (b, h, query, key) keeps iff
+ * Philox4x32-10(seed; (key / 4, (b * Hq + h) * S + query, offset))[key % 4] >= round(p * 2^32); p = 0 skips the generator. */
+int mi355_attn_dropout_fwd(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
+                           int64_t ldv, void* o, int64_t ldo, float* lse, int causal, float scale, float p, uint64_t seed, uint64_t offset,
+                           void* stream);
+int mi355_attn_dropout_bwd(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
+                           int64_t ldv, const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* lse, float* delta, void* dq,
+                           int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int causal, float scale, float p, uint64_t seed,
+                           uint64_t offset, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,7 +20,7 @@ EPI_NONE, EPI_GELU, EPI_SWIGLU_BWD, EPI_SWIGLU_FWD = 0, 1, 2, 3
 EPI_GELU_DUAL_ERF, EPI_GELU_DUAL_TANH, EPI_GELU_BWD_ERF, EPI_GELU_BWD_TANH = 4, 5, 6, 7
 
 _c = ctypes
-_P, _I, _L, _F = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float
+_P, _I, _L, _F, _U = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_uint64
 
 # name -> argtypes; every entry point returns int.  Must list exactly what include/mi355_vlm.h declares.
 SIGNATURES = {
@@ -87,6 +87,11 @@ SIGNATURES = {
     "mi355_attn_decode": [_I, _I, _I, _I, _P, _P, _P, _L, _L, _I, _P, _P, _L, _P, _F, _P],
     "mi355_kv_append": [_I, _I, _P, _L, _P, _L, _P, _P, _L, _L, _I, _P, _P],
     "mi355_argmax_rows": [_L, _L, _P, _L, _P, _P, _P],
+    # stand-alone RoPE and dropout (csrc/rope_dropout.hip, csrc/attention_generic.hip)
+    "mi355_rope_apply": [_I, _I, _I, _I, _I, _P, _I, _L, _L, _L, _P, _P, _L, _P, _P, _L, _L, _L, _I, _P],
+    "mi355_dropout": [_L, _P, _I, _P, _P, _I, _F, _U, _U, _P],
+    "mi355_attn_dropout_fwd": [_I, _I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _I, _F, _F, _U, _U, _P],
+    "mi355_attn_dropout_bwd": [_I, _I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _L, _P, _L, _P, _L, _I, _F, _F, _U, _U, _P],
 }
 # size / constant queries: no stream argument, the return value is the answer (name -> (argtypes, restype))
 QUERIES = {

@@ -9,6 +9,12 @@
 // barrier pair, no pipelining: these layers are 1.2 % of config 5's FLOPs -- correctness and determinism first.
 // Backward: delta = rowsum(dO * O); dQ pass query-major; dK/dV pass key-major (no atomics), with the d_h = 256 accumulators
 // split into two 128-wide passes so a wave's dK^T / dV^T tiles fit the register file.
+//
+// PLAIN = true is the second semantics built on the same kernels (mi355_attn_dropout_fwd / _bwd): softmax over all keys or
+// plain causal (no key mask, no quirk), with nn.Dropout(p) on the NORMALISED weights as ViTMultiHeadAttention applies it
+// (vit_attention.py:79): O = ((P o M) / (1 - p)) V / l with l from the un-dropped P.  The mask is never stored: element
+// (b, h, query, key) keeps iff Philox4x32-10(seed; key / 4, (b Hq + h) S + query, offset)[key % 4] >= round(p 2^32), and the
+// backward regenerates it (dV += (P o M / keep)^T dO, dP = (dO V^T) o M / keep, dS = P (dP - delta), delta = rowsum(dO o O)).
 #include "common.h"
 
 namespace {
@@ -16,6 +22,20 @@ namespace {
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 #define NEG_INF (-__builtin_huge_valf())
+
+struct DropArgs {
+    int causal;       // PLAIN only: 1 = keys <= query, 0 = every key
+    unsigned thresh;  // 0 = no dropout
+    float inv_keep;
+    unsigned k0, k1, o0, o1;
+};
+// keep multipliers (0 or 1 / (1 - p)) of the four consecutive keys key4 .. key4+3 (key4 % 4 == 0) of attention row `row`
+__device__ __forceinline__ void drop4(const DropArgs& da, unsigned row, int key4, float (&mul)[4]) {
+    unsigned bits[4];
+    philox4x32_10((unsigned)key4 >> 2, row, da.o0, da.o1, da.k0, da.k1, bits);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mul[e] = bits[e] >= da.thresh ? da.inv_keep : 0.f;
+}
 
 template <int D>
 struct GA {
@@ -84,11 +104,11 @@ __device__ __forceinline__ void store_t_tiles(const f32x16 (&acc)[NDT], float mu
         }
 }
 
-template <int D>
+template <int D, bool PLAIN>
 __global__ __launch_bounds__(256) void ga_fwd_kernel(int B, int S, int Hq, int Hkv, const bf16_t* __restrict__ q, int64_t ldq,
                                                      const bf16_t* __restrict__ k, int64_t ldk, const bf16_t* __restrict__ v, int64_t ldv,
                                                      bf16_t* __restrict__ o, int64_t ldo, float* __restrict__ lse,
-                                                     const uint8_t* __restrict__ key_mask, float scale_log2) {
+                                                     const uint8_t* __restrict__ key_mask, float scale_log2, DropArgs da) {
     using C = GA<D>;
     __shared__ __attribute__((aligned(16))) char smem[2 * C::IMG];
     char* kimg = smem;
@@ -108,15 +128,17 @@ __global__ __launch_bounds__(256) void ga_fwd_kernel(int B, int S, int Hq, int H
         for (int i = 0; i < 16; ++i) acc[dt][i] = 0.f;
     float m = NEG_INF, l = 0.f;
     const int qlast = (blockIdx.x * 128 + 127 < S ? blockIdx.x * 128 + 127 : S - 1);
-    const int ntiles = key_mask ? (S + 31) / 32 : qlast / 32 + 1;
-    const uint8_t* km = key_mask ? key_mask + tok0 : nullptr;
+    const bool all_keys = PLAIN ? !da.causal : key_mask != nullptr;  // every key tile is walked
+    const int ntiles = all_keys ? (S + 31) / 32 : qlast / 32 + 1;
+    const uint8_t* km = (!PLAIN && key_mask) ? key_mask + tok0 : nullptr;
+    const unsigned drow = (unsigned)(((int64_t)b * Hq + h) * S + query);
     for (int kt = 0; kt < ntiles; ++kt) {
         const int key0 = kt * 32;
         __syncthreads();
         load_tile<D, 256>(kimg, k + (tok0 + key0) * ldk + (int64_t)hkv * D, ldk, S - key0, threadIdx.x);
         load_tile<D, 256>(vimg, v + (tok0 + key0) * ldv + (int64_t)hkv * D, ldv, S - key0, threadIdx.x);
         __syncthreads();
-        if (!km && key0 > q0 + 31) continue;  // tile entirely above this wave's diagonal
+        if (!all_keys && key0 > q0 + 31) continue;  // tile entirely above this wave's diagonal
         f32x16 s;
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = 0.f;
@@ -126,7 +148,7 @@ __global__ __launch_bounds__(256) void ga_fwd_kernel(int B, int S, int Hq, int H
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int key = key0 + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
-            const bool ok = key < S && (key <= query || (km && !km[key]));
+            const bool ok = PLAIN ? (key < S && (!da.causal || key <= query)) : (key < S && (key <= query || (km && !km[key])));
             s[i] = ok ? s[i] * scale_log2 : NEG_INF;
             mx = fmaxf(mx, s[i]);
         }
@@ -147,6 +169,15 @@ __global__ __launch_bounds__(256) void ga_fwd_kernel(int B, int S, int Hq, int H
         for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[dt][i] *= alpha;
+        if (PLAIN && da.thresh) {  // dropout on the weights that multiply V; the row sum above keeps every key
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float mul[4];
+                drop4(da, drow, key0 + 8 * g + 4 * (lane >> 5), mul);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[4 * g + e] *= mul[e];
+            }
+        }
         const bf16x8 p0 = pack_frag(s, 0), p1 = pack_frag(s, 1);
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt) {
@@ -173,12 +204,12 @@ __global__ __launch_bounds__(256) void ga_delta_kernel(int64_t tokens, int S, in
     }
 }
 
-template <int D>
+template <int D, bool PLAIN>
 __global__ __launch_bounds__(256) void ga_bwd_dq_kernel(int B, int S, int Hq, int Hkv, const bf16_t* __restrict__ q, int64_t ldq,
                                                         const bf16_t* __restrict__ k, int64_t ldk, const bf16_t* __restrict__ v, int64_t ldv,
                                                         const bf16_t* __restrict__ d_o, int64_t lddo, const float* __restrict__ lse,
                                                         const float* __restrict__ delta, bf16_t* __restrict__ dq, int64_t lddq,
-                                                        const uint8_t* __restrict__ key_mask, float scale) {
+                                                        const uint8_t* __restrict__ key_mask, float scale, DropArgs da) {
     using C = GA<D>;
     __shared__ __attribute__((aligned(16))) char smem[2 * C::IMG];
     char* kimg = smem;
@@ -201,15 +232,17 @@ __global__ __launch_bounds__(256) void ga_bwd_dq_kernel(int B, int S, int Hq, in
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[dt][i] = 0.f;
     const int qlast = (blockIdx.x * 128 + 127 < S ? blockIdx.x * 128 + 127 : S - 1);
-    const int ntiles = key_mask ? (S + 31) / 32 : qlast / 32 + 1;
-    const uint8_t* km = key_mask ? key_mask + tok0 : nullptr;
+    const bool all_keys = PLAIN ? !da.causal : key_mask != nullptr;
+    const int ntiles = all_keys ? (S + 31) / 32 : qlast / 32 + 1;
+    const uint8_t* km = (!PLAIN && key_mask) ? key_mask + tok0 : nullptr;
+    const unsigned drow = (unsigned)(((int64_t)b * Hq + h) * S + query);
     for (int kt = 0; kt < ntiles; ++kt) {
         const int key0 = kt * 32;
         __syncthreads();
         load_tile<D, 256>(kimg, k + (tok0 + key0) * ldk + (int64_t)hkv * D, ldk, S - key0, threadIdx.x);
         load_tile<D, 256>(vimg, v + (tok0 + key0) * ldv + (int64_t)hkv * D, ldv, S - key0, threadIdx.x);
         __syncthreads();
-        if (!km && key0 > q0 + 31) continue;
+        if (!all_keys && key0 > q0 + 31) continue;
         f32x16 s, dp;
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = dp[i] = 0.f;
@@ -218,10 +251,19 @@ __global__ __launch_bounds__(256) void ga_bwd_dq_kernel(int B, int S, int Hq, in
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(kimg, ks, lane), qf[ks], s, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(vimg, ks, lane), gf[ks], dp, 0, 0, 0);
         }
+        if (PLAIN && da.thresh) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float mul[4];
+                drop4(da, drow, key0 + 8 * g + 4 * (lane >> 5), mul);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dp[4 * g + e] *= mul[e];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int key = key0 + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
-            const bool ok = qvalid && key < S && (key <= query || (km && !km[key]));
+            const bool ok = PLAIN ? (qvalid && key < S && (!da.causal || key <= query)) : (qvalid && key < S && (key <= query || (km && !km[key])));
             const float p = ok ? exp2f(s[i] * scale_log2 - lse_q) : 0.f;
             s[i] = p * (dp[i] - delta_q) * scale;
         }
@@ -237,12 +279,13 @@ __global__ __launch_bounds__(256) void ga_bwd_dq_kernel(int B, int S, int Hq, in
 
 // key-major pass: a wave owns 32 keys of one kv head; NP = number of d-slices the dK^T / dV^T accumulators are split into
 // (blockIdx.x = key_block * NP + slice); all q heads of the group and all query tiles from the diagonal on are walked.
-template <int D, int NP>
+template <int D, int NP, bool PLAIN>
 __global__ __launch_bounds__(256) void ga_bwd_dkv_kernel(int B, int S, int Hq, int Hkv, const bf16_t* __restrict__ q, int64_t ldq,
                                                          const bf16_t* __restrict__ k, int64_t ldk, const bf16_t* __restrict__ v, int64_t ldv,
                                                          const bf16_t* __restrict__ d_o, int64_t lddo, const float* __restrict__ lse,
                                                          const float* __restrict__ delta, bf16_t* __restrict__ dk, int64_t lddk,
-                                                         bf16_t* __restrict__ dv, int64_t lddv, const uint8_t* __restrict__ key_mask, float scale) {
+                                                         bf16_t* __restrict__ dv, int64_t lddv, const uint8_t* __restrict__ key_mask, float scale,
+                                                         DropArgs da) {
     using C = GA<D>;
     constexpr int NDT = C::DT / NP;
     __shared__ __attribute__((aligned(16))) char smem[2 * C::IMG];
@@ -259,14 +302,15 @@ __global__ __launch_bounds__(256) void ga_bwd_dkv_kernel(int B, int S, int Hq, i
     bf16x8 kf[C::KS], vf[C::KS];
     load_row_frags<D>(k + (tok0 + key) * ldk + (int64_t)hkv * D, kvalid, lane, kf);
     load_row_frags<D>(v + (tok0 + key) * ldv + (int64_t)hkv * D, kvalid, lane, vf);
-    const bool padded = key_mask && kvalid && !key_mask[tok0 + key];
+    const bool padded = !PLAIN && key_mask && kvalid && !key_mask[tok0 + key];
+    const bool all_queries = PLAIN ? !da.causal : key_mask != nullptr;  // every query tile is walked
     const float scale_log2 = scale * LOG2E;
     f32x16 adk[NDT], adv[NDT];
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) adk[dt][i] = adv[dt][i] = 0.f;
-    const int qt0 = key_mask ? 0 : (kb * 128) / 32;
+    const int qt0 = all_queries ? 0 : (kb * 128) / 32;
     const int nqt = (S + 31) / 32;
     for (int hq = hkv * rep; hq < (hkv + 1) * rep; ++hq) {
         for (int qt = qt0; qt < nqt; ++qt) {
@@ -280,7 +324,7 @@ __global__ __launch_bounds__(256) void ga_bwd_dkv_kernel(int B, int S, int Hq, i
                 stat[1][threadIdx.x] = okq ? delta[((int64_t)b * Hq + hq) * S + qs + threadIdx.x] : 0.f;
             }
             __syncthreads();
-            if (!key_mask && qs + 31 < k0) continue;  // every query of the tile precedes this wave's keys
+            if (!all_queries && qs + 31 < k0) continue;  // every query of the tile precedes this wave's keys
             f32x16 s, dp;
 #pragma unroll
             for (int i = 0; i < 16; ++i) s[i] = dp[i] = 0.f;
@@ -293,10 +337,17 @@ __global__ __launch_bounds__(256) void ga_bwd_dkv_kernel(int B, int S, int Hq, i
             for (int i = 0; i < 16; ++i) {
                 const int r = 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
                 const int qi = qs + r;
-                const bool ok = kvalid && qi < S && (key <= qi || padded);
+                const bool ok = PLAIN ? (kvalid && qi < S && (!da.causal || key <= qi)) : (kvalid && qi < S && (key <= qi || padded));
                 const float p = ok ? exp2f(s[i] * scale_log2 - stat[0][r]) : 0.f;
-                s[i] = p;
-                dp[i] = p * (dp[i] - stat[1][r]) * scale;
+                float keep = 1.f;
+                if (PLAIN && da.thresh) {  // this lane's key inside its group of four, for attention row (b, hq, qi)
+                    unsigned bits[4];
+                    philox4x32_10((unsigned)key >> 2, (unsigned)(((int64_t)b * Hq + hq) * S + qi), da.o0, da.o1, da.k0, da.k1, bits);
+                    const unsigned bsel = (key & 3) == 0 ? bits[0] : (key & 3) == 1 ? bits[1] : (key & 3) == 2 ? bits[2] : bits[3];
+                    keep = bsel >= da.thresh ? da.inv_keep : 0.f;
+                }
+                s[i] = p * keep;
+                dp[i] = p * (dp[i] * keep - stat[1][r]) * scale;
             }
             const bf16x8 p0 = pack_frag(s, 0), p1 = pack_frag(s, 1), d0 = pack_frag(dp, 0), d1 = pack_frag(dp, 1);
 #pragma unroll
@@ -332,7 +383,8 @@ extern "C" int mi355_attn_generic_fwd(int B, int S, int Hq, int Hkv, int D, cons
     if (check_ga(B, S, Hq, Hkv, D, ldq, ldk, ldv, ldo)) return 1;
     MI355_REQUIRE(q && k && v && o && lse, "attn_generic_fwd: null pointer");
     dim3 grid((S + 127) / 128, Hq, B);
-#define LAUNCH(DD) ga_fwd_kernel<DD><<<grid, 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, key_mask, scale * LOG2E)
+    const DropArgs da = {};
+#define LAUNCH(DD) ga_fwd_kernel<DD, false><<<grid, 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, key_mask, scale * LOG2E, da)
     switch (D) {
         case 32: LAUNCH(32); break;
         case 64: LAUNCH(64); break;
@@ -356,8 +408,9 @@ extern "C" int mi355_attn_generic_bwd(int B, int S, int Hq, int Hkv, int D, cons
     ga_delta_kernel<<<(int)(dg > 8192 ? 8192 : dg), 256, 0, ST(stream)>>>(tokens, S, Hq, D, (const bf16_t*)o, ldo, (const bf16_t*)d_o, lddo, delta);
     MI355_LAUNCH_CHECK("attn_generic_bwd(delta)");
     dim3 gq((S + 127) / 128, Hq, B);
-#define LAUNCH_DQ(DD) ga_bwd_dq_kernel<DD><<<gq, 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dq, lddq, key_mask, scale)
-#define LAUNCH_DKV(DD, NP) ga_bwd_dkv_kernel<DD, NP><<<dim3(((S + 127) / 128) * NP, Hkv, B), 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, key_mask, scale)
+    const DropArgs da = {};
+#define LAUNCH_DQ(DD) ga_bwd_dq_kernel<DD, false><<<gq, 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dq, lddq, key_mask, scale, da)
+#define LAUNCH_DKV(DD, NP) ga_bwd_dkv_kernel<DD, NP, false><<<dim3(((S + 127) / 128) * NP, Hkv, B), 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, key_mask, scale, da)
     switch (D) {
         case 32: LAUNCH_DQ(32); LAUNCH_DKV(32, 1); break;
         case 64: LAUNCH_DQ(64); LAUNCH_DKV(64, 1); break;
@@ -367,5 +420,64 @@ extern "C" int mi355_attn_generic_bwd(int B, int S, int Hq, int Hkv, int D, cons
 #undef LAUNCH_DQ
 #undef LAUNCH_DKV
     MI355_LAUNCH_CHECK("attn_generic_bwd");
+    return 0;
+}
+
+// ---- PLAIN semantics: full or plain-causal softmax with dropout on the weights (ViTMultiHeadAttention in train mode) -------------
+static int make_drop_args(const char* who, int B, int S, int Hq, int causal, float p, uint64_t seed, uint64_t offset, DropArgs* da) {
+    MI355_REQUIRE(p >= 0.f && p < 1.f, "%s: p must be in [0, 1) (got %f)", who, (double)p);
+    MI355_REQUIRE((int64_t)B * Hq * S < (int64_t)1 << 32, "%s: B * Hq * S must fit 32 bits (dropout counter)", who);
+    da->causal = causal != 0;
+    da->thresh = p > 0.f ? mi355_dropout_threshold(p) : 0u;
+    da->inv_keep = 1.0f / (1.0f - p);
+    da->k0 = (unsigned)seed, da->k1 = (unsigned)(seed >> 32), da->o0 = (unsigned)offset, da->o1 = (unsigned)(offset >> 32);
+    return 0;
+}
+
+extern "C" int mi355_attn_dropout_fwd(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
+                                      int64_t ldv, void* o, int64_t ldo, float* lse, int causal, float scale, float p, uint64_t seed, uint64_t offset,
+                                      void* stream) {
+    if (check_ga(B, S, Hq, Hkv, D, ldq, ldk, ldv, ldo)) return 1;
+    MI355_REQUIRE(q && k && v && o && lse, "attn_dropout_fwd: null pointer");
+    DropArgs da;
+    if (make_drop_args("attn_dropout_fwd", B, S, Hq, causal, p, seed, offset, &da)) return 1;
+    dim3 grid((S + 127) / 128, Hq, B);
+#define LAUNCH(DD) ga_fwd_kernel<DD, true><<<grid, 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, nullptr, scale * LOG2E, da)
+    switch (D) {
+        case 32: LAUNCH(32); break;
+        case 64: LAUNCH(64); break;
+        case 128: LAUNCH(128); break;
+        default: LAUNCH(256); break;
+    }
+#undef LAUNCH
+    MI355_LAUNCH_CHECK("attn_dropout_fwd");
+    return 0;
+}
+
+extern "C" int mi355_attn_dropout_bwd(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
+                                      int64_t ldv, const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* lse, float* delta,
+                                      void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int causal, float scale, float p,
+                                      uint64_t seed, uint64_t offset, void* stream) {
+    if (check_ga(B, S, Hq, Hkv, D, ldq, ldk, ldv, ldo)) return 1;
+    if (check_ga(B, S, Hq, Hkv, D, lddq, lddk, lddv, lddo)) return 1;
+    MI355_REQUIRE(q && k && v && o && d_o && lse && delta && dq && dk && dv, "attn_dropout_bwd: null pointer");
+    DropArgs da;
+    if (make_drop_args("attn_dropout_bwd", B, S, Hq, causal, p, seed, offset, &da)) return 1;
+    const int64_t tokens = (int64_t)B * S;
+    int64_t dg = (tokens * Hq + 3) / 4;
+    ga_delta_kernel<<<(int)(dg > 8192 ? 8192 : dg), 256, 0, ST(stream)>>>(tokens, S, Hq, D, (const bf16_t*)o, ldo, (const bf16_t*)d_o, lddo, delta);
+    MI355_LAUNCH_CHECK("attn_dropout_bwd(delta)");
+    dim3 gq((S + 127) / 128, Hq, B);
+#define LAUNCH_DQ(DD) ga_bwd_dq_kernel<DD, true><<<gq, 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dq, lddq, nullptr, scale, da)
+#define LAUNCH_DKV(DD, NP) ga_bwd_dkv_kernel<DD, NP, true><<<dim3(((S + 127) / 128) * NP, Hkv, B), 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, nullptr, scale, da)
+    switch (D) {
+        case 32: LAUNCH_DQ(32); LAUNCH_DKV(32, 1); break;
+        case 64: LAUNCH_DQ(64); LAUNCH_DKV(64, 1); break;
+        case 128: LAUNCH_DQ(128); LAUNCH_DKV(128, 1); break;
+        default: LAUNCH_DQ(256); LAUNCH_DKV(256, 2); break;
+    }
+#undef LAUNCH_DQ
+#undef LAUNCH_DKV
+    MI355_LAUNCH_CHECK("attn_dropout_bwd");
     return 0;
 }

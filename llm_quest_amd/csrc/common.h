@@ -61,6 +61,32 @@ __device__ __forceinline__ float gelu_grad(float x) {
     return 0.5f * (1.0f + th) + 0.5f * x * (1.0f - th * th) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
 }
 
+// ---- counter-based random bits for dropout: Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as
+// 1, 2, 3", SC'11).  One call = 4 x 32 bits for counter (c0..c3) under key (k0, k1); no state, so the backward regenerates the
+// forward's mask from (seed, offset) alone.  The oracle restates the same function in numpy (oracle/dropout.py).
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
+}
+// Dropout keep rule shared by every site: element e of a group of four keeps its value iff bits[e] >= thresh, thresh = round(p * 2^32).
+
+static inline unsigned mi355_dropout_threshold(float p) {
+    double t = (double)p * 4294967296.0 + 0.5;
+    if (t < 0.0) t = 0.0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    return (unsigned)t;
+}
+
 // ---- host side error plumbing -------------------------------------------------------------
 void mi355_set_error(const char* fmt, ...);
 #define MI355_REQUIRE(cond, ...)          \

@@ -270,12 +270,58 @@ def training_eval_loop(train_loader, val_loader, model, optimizer, num_epoch, lr
     return train_losses, val_losses
 
 
-def profile_training_eval_loop(train_loader, val_loader, model, optimizer, num_epoch, lr_scheduler, eval_freq, eval_iter, device,
-                               accumulation_steps=1, use_amp=True, log_dir="./profiler_logs", wait=1, warmup=1, active=3, repeat=1):
-    """Same loop under torch.profiler (reference: engine.py:499-640); kernel-level numbers come from rocprofv3."""
-    acts = [torch.profiler.ProfilerActivity.CPU]
-    if torch.cuda.is_available():
-        acts.append(torch.profiler.ProfilerActivity.CUDA)
-    sched = torch.profiler.schedule(wait=wait, warmup=warmup, active=active, repeat=repeat)
-    with torch.profiler.profile(activities=acts, schedule=sched, on_trace_ready=torch.profiler.tensorboard_trace_handler(log_dir), record_shapes=True):
-        return training_eval_loop(train_loader, val_loader, model, optimizer, num_epoch, lr_scheduler, eval_freq, eval_iter, device, accumulation_steps, use_amp)
+def profile_training_eval_loop(train_loader, val_loader, model, optimizer, num_epoch, warmup_percent, init_lr, peak_lr, min_lr, eval_freq,
+                               eval_iter, device, use_amp=True, profile_dir="./torch_profile_logs", wait=1, warmup=1, active=3, repeat=1,
+                               record_shapes=True, profile_memory=True):
+    """A short training run under ``torch.profiler`` (reference: engine.py:499-640): inline linear warm-up / cosine schedule
+    over ``len(train_loader) * num_epoch`` steps, one optimizer step per batch with clip 1.0, eval every ``eval_freq`` steps,
+    and an early stop once ``wait + warmup + active`` steps were traced.  Kernel-level numbers for the HIP path come from
+    rocprofv3; this entry gives the host-side timeline the reference's users expect."""
+    import os
+
+    from torch.profiler import ProfilerActivity, profile
+
+    os.makedirs(profile_dir, exist_ok=True)
+    dev_type = device.type if isinstance(device, torch.device) else str(device).split(":")[0]
+    acts = [ProfilerActivity.CPU] + ([ProfilerActivity.CUDA] if dev_type == "cuda" else [])
+    total_steps = len(train_loader) * num_epoch
+    warmup_steps = int(warmup_percent * total_steps)
+    lr_step = (peak_lr - init_lr) / warmup_steps if (warmup_percent and warmup_steps) else 0.0
+    budget = wait + warmup + active
+    train_losses, val_losses = [], []
+    step, traced, done = -1, 0, False
+    with profile(activities=acts, schedule=torch.profiler.schedule(wait=wait, warmup=warmup, active=active, repeat=repeat),
+                 on_trace_ready=torch.profiler.tensorboard_trace_handler(profile_dir), record_shapes=record_shapes,
+                 profile_memory=profile_memory, with_stack=True) as prof:
+        for epoch in range(1, num_epoch + 1):
+            model.train()
+            for X, y in train_loader:
+                step += 1
+                if step < warmup_steps:
+                    lr = init_lr + step * lr_step
+                else:
+                    lr = min_lr + (peak_lr - min_lr) * 0.5 * (1 + math.cos(math.pi * (step - warmup_steps) / (total_steps - warmup_steps)))
+                for group in optimizer.param_groups:
+                    if not group.get("custom_lr", False):
+                        group["lr"] = lr
+                X, y = X.to(device), y.to(device)
+                with _amp(device, use_amp):
+                    loss = global_loss(model(X), y, model=model)
+                optimizer.zero_grad()
+                loss.backward()
+                clip_grad_norm_(model.parameters(), max_norm=1)
+                optimizer.step()
+                if step % eval_freq == 0:
+                    tr, va = evaluate(train_loader, val_loader, model, eval_iter, device)
+                    train_losses.append(tr)
+                    val_losses.append(va)
+                    print(f"Epoch: {epoch}, Step: {step}", f"Train loss: {tr:.5f}, Val loss: {va:.5f}")
+                prof.step()
+                if traced >= budget:
+                    done = True
+                    break
+                traced += 1
+            if done:
+                break
+    print(f"Profiling complete. Logs saved to {profile_dir}")
+    return train_losses, val_losses

@@ -583,3 +583,78 @@ def scatter_rows_bwd(g2d, n_vis_rows, mask_u8, slot_i32):
     d_vis = torch.zeros((n_vis_rows, g2d.shape[1]), dtype=g2d.dtype, device=g2d.device)
     L.call("mi355_scatter_rows", g2d.shape[0], g2d.shape[1] * g2d.element_size(), L.ptr(mask_u8), L.ptr(slot_i32), L.ptr(g2d), None, L.ptr(d_emb), L.ptr(d_vis), 1)
     return d_emb, d_vis
+
+
+# ----------------------------------------------------------------------------------------------- stand-alone RoPE, dropout
+def _bhsd_strides(t, name):
+    if t.dim() != 4 or t.stride(3) != 1:
+        raise ValueError(f"{name}: expected (b, heads, seq, head_dim) with unit inner stride, got shape {tuple(t.shape)} strides {t.stride()}")
+    return t.stride(0), t.stride(1), t.stride(2)
+
+
+def rope_apply(x, cos_t, sin_t, idx=None, transpose=False):
+    """RoPE on x (b, heads, s, head_dim) bf16 / fp32, any outer strides: rows of cos_t / sin_t (fp32 [rows, R], R <= head_dim) are
+    picked by idx (int32 [b*s]) or by the sequence position.  transpose=True applies the adjoint (backward).  The result has x's layout."""
+    L.require_gpu(x, cos_t, sin_t, idx)
+    if x.dtype not in (BF16, F32):
+        raise TypeError(f"rope_apply: bf16 or fp32 input expected, got {x.dtype}")
+    sb, sh, ss = _bhsd_strides(x, "rope_apply")
+    B, H, S, D = x.shape
+    if cos_t.dtype != F32 or sin_t.dtype != F32 or cos_t.dim() != 2 or cos_t.shape != sin_t.shape or not cos_t.is_contiguous() or not sin_t.is_contiguous():
+        raise ValueError("rope_apply: cos/sin must be contiguous fp32 [rows, R]")
+    R = cos_t.shape[1]
+    if R > D or R % 2:
+        raise ValueError(f"rope_apply: rotation width {R} must be even and <= head_dim {D}")
+    if idx is not None:
+        if idx.dtype != torch.int32 or idx.numel() != B * S or not idx.is_contiguous():
+            raise ValueError("rope_apply: idx must be contiguous int32 [b*s]")
+    elif cos_t.shape[0] < S:
+        raise ValueError(f"rope_apply: sequence length {S} exceeds the {cos_t.shape[0]} rows of the coefficient table")
+    out = torch.empty_like(x)  # preserve_format: x's strides when x is dense (a transposed token-major view stays one), else contiguous
+    ob, oh, os_ = _bhsd_strides(out, "rope_apply(out)")
+    L.call("mi355_rope_apply", B, H, S, D, R, L.ptr(x), L.dt_code(x.dtype), sb, sh, ss, L.ptr(cos_t), L.ptr(sin_t), cos_t.shape[0], L.ptr(idx),
+           L.ptr(out), ob, oh, os_, int(transpose))
+    return out
+
+
+def dropout(x, p, seed, offset, residual=None, out_dtype=None):
+    """y = residual + keep ? x / (1 - p) : 0 with the Philox mask of (seed, offset); x contiguous bf16 / fp32; the backward is the
+    same call on the incoming gradient."""
+    L.require_gpu(x, residual)
+    if not x.is_contiguous() or x.dtype not in (BF16, F32):
+        raise ValueError("dropout: contiguous bf16 / fp32 input expected")
+    out_dtype = x.dtype if out_dtype is None else out_dtype
+    if residual is not None and (residual.dtype != out_dtype or residual.shape != x.shape or not residual.is_contiguous()):
+        raise ValueError("dropout: residual must be contiguous, shaped like x, in the output dtype")
+    if not 0.0 <= p < 1.0:
+        raise ValueError(f"dropout probability has to be in [0, 1), got {p}")
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    L.call("mi355_dropout", x.numel(), L.ptr(x), L.dt_code(x.dtype), L.ptr(residual), L.ptr(y), L.dt_code(out_dtype), float(p), int(seed), int(offset))
+    return y
+
+
+def attn_dropout_fwd(q, k, v, B, S, Hq, Hkv, D, p, seed, offset, causal=False, scale=None):
+    """Softmax attention with dropout(p) on the normalised weights (ViT train mode).  Layout as attn_fwd."""
+    L.require_gpu(q, k, v)
+    _check_attn_operand(q, "q", B * S, Hq * D)
+    _check_attn_operand(k, "k", B * S, Hkv * D)
+    _check_attn_operand(v, "v", B * S, Hkv * D)
+    o = torch.empty((B * S, Hq * D), dtype=BF16, device=q.device)
+    lse = torch.empty((B, Hq, S), dtype=F32, device=q.device)
+    scale = D ** -0.5 if scale is None else scale
+    L.call("mi355_attn_dropout_fwd", B, S, Hq, Hkv, D, L.ptr(q), q.stride(0), L.ptr(k), k.stride(0), L.ptr(v), v.stride(0), L.ptr(o), o.stride(0),
+           L.ptr(lse), int(causal), scale, float(p), int(seed), int(offset))
+    return o, lse
+
+
+def attn_dropout_bwd(q, k, v, o, do, lse, B, S, Hq, Hkv, D, dq, dk, dv, p, seed, offset, causal=False, scale=None):
+    L.require_gpu(q, k, v, o, do, lse, dq, dk, dv)
+    for t, n, w in ((q, "q", Hq), (k, "k", Hkv), (v, "v", Hkv), (o, "o", Hq), (do, "do", Hq), (dq, "dq", Hq), (dk, "dk", Hkv), (dv, "dv", Hkv)):
+        _check_attn_operand(t, n, B * S, w * D)
+    if not (lse.dtype == F32 and lse.is_contiguous() and tuple(lse.shape) == (B, Hq, S)):
+        raise ValueError("attention: lse must be contiguous fp32 [B,Hq,S]")
+    delta = torch.empty_like(lse)
+    scale = D ** -0.5 if scale is None else scale
+    L.call("mi355_attn_dropout_bwd", B, S, Hq, Hkv, D, L.ptr(q), q.stride(0), L.ptr(k), k.stride(0), L.ptr(v), v.stride(0), L.ptr(o), o.stride(0),
+           L.ptr(do), do.stride(0), L.ptr(lse), L.ptr(delta), L.ptr(dq), dq.stride(0), L.ptr(dk), dk.stride(0), L.ptr(dv), dv.stride(0),
+           int(causal), scale, float(p), int(seed), int(offset))

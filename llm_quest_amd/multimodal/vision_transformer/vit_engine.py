@@ -139,39 +139,39 @@ class ViT:
     """Evaluation helpers with the reference's static-method API (vit_engine.py:150-265)."""
 
     @staticmethod
-    @torch.no_grad()
-    def accuracy_loader(dataloader, model, device, num_batches=None):
+    def accuracy_loader(data_loader, model, device):
         model.eval()
-        n = len(dataloader) if num_batches is None else min(num_batches, len(dataloader))
-        if n == 0:
-            return float("nan")
         correct = total = 0
-        for i, (x, y) in enumerate(dataloader):
-            if i >= n:
-                break
-            pred = model(x.to(device)).argmax(dim=-1)
-            correct += int((pred == y.to(device)).sum())
-            total += y.numel()
+        with torch.no_grad():
+            for X, y in data_loader:
+                pred = model(X.to(device)).argmax(dim=-1)
+                correct += int((pred == y.to(device)).sum())
+                total += len(pred)
         return correct / total
-
-    @staticmethod
-    @torch.no_grad()
-    def calc_loss_loader(dataloader, model, device, num_batches=None):
-        n = len(dataloader) if num_batches is None else min(num_batches, len(dataloader))
-        if n == 0:
-            return float("nan")
-        tot = 0.0
-        for i, (x, y) in enumerate(dataloader):
-            if i >= n:
-                break
-            from llm_quest_amd.engine import _cross_entropy
-
-            tot += float(_cross_entropy(model(x.to(device)), y.to(device)))
-        return tot / n
 
     @staticmethod
     def evaluate(train_loader, val_loader, model, eval_iter, device):
         model.eval()
-        out = (ViT.calc_loss_loader(train_loader, model, device, eval_iter), ViT.calc_loss_loader(val_loader, model, device, eval_iter))
+        with torch.no_grad():
+            out = (ViT.calc_loss_loader(train_loader, model, device, num_batches=eval_iter), ViT.calc_loss_loader(val_loader, model, device, num_batches=eval_iter))
         model.train()
         return out
+
+    @staticmethod
+    def calc_loss_loader(dataloader, model, device, num_batches=None):
+        if len(dataloader) == 0:
+            return float("NaN")
+        num_batches = len(dataloader) if num_batches is None else min(num_batches, len(dataloader))
+        total = 0.0
+        for i, (X, y) in enumerate(dataloader):
+            if i >= num_batches:
+                break
+            total += ViT._calc_loss_batch(X, y, model, device).item()
+        return total / num_batches
+
+    @staticmethod
+    def _calc_loss_batch(X, y, model, device):
+        """CE of one classification batch (reference vit_engine.py:246-265); the HIP CE kernel for device logits."""
+        from llm_quest_amd.engine import _cross_entropy
+
+        return _cross_entropy(model(X.to(device)), y.to(device))

@@ -35,6 +35,9 @@ class LayerNorm(nn.Module):
 class GELU(nn.Module):
     """x * 0.5 * (1 + erf(x / sqrt(2))) (reference: :34-44)."""
 
+    def __init__(self):
+        super().__init__()
+
     def forward(self, x):
         L.require_gpu(x)
         if torch.is_grad_enabled() and x.requires_grad:

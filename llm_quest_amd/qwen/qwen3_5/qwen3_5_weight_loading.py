@@ -11,12 +11,7 @@ from collections import namedtuple
 
 import torch
 
-from llm_quest_amd.qwen.qwen3.qwen3_weight_loading import (
-    convert_weights,
-    handle_weight_tying,
-    read_local_checkpoint,
-    report_loading_status,
-)
+from llm_quest_amd.utils import convert_weights, handle_weight_tying, report_loading_status, resolve_checkpoint
 
 _TEXT_ROOT = "model.language_model."
 _VISION_ROOT = "model.visual."
@@ -83,17 +78,10 @@ def get_vision_remapping_rules():
     return rules
 
 
-def _require(source, fn):
-    if source is None:
-        raise ValueError(f"{fn}: pass a local checkpoint (dict, .safetensors file or shard directory); downloading from the "
-                         "Hugging Face hub is not available in this environment")
-    return read_local_checkpoint(source)
-
-
 def load_qwen3_5_text_weights(model, model_cfg, source=None, verbose=True):
     """Text-only model from a full Qwen3.5 checkpoint: ``model.visual.*`` and ``mtp.*`` are skipped
     (reference qwen3_5_weight_loading.py:85-117)."""
-    hf_state_dict = _require(source, "load_qwen3_5_text_weights")
+    hf_state_dict = resolve_checkpoint(source, model_cfg)
     converted = convert_weights(hf_state_dict, model.state_dict(), get_remapping_rules(),
                                 ignored_prefixes=(_VISION_ROOT, _MTP_ROOT))
     with torch.no_grad():
@@ -110,7 +98,7 @@ _LoadResult = namedtuple("_LoadResult", ["missing_keys", "unexpected_keys"])
 def load_qwen3_5_vlm_weights(model, model_cfg, source=None, verbose=True):
     """Text stack + vision tower of a ``Qwen3_5VLM`` from one checkpoint; the two halves are converted separately and reported
     together, prefixed with the attribute they live under (reference qwen3_5_weight_loading.py:120-178)."""
-    hf_state_dict = _require(source, "load_qwen3_5_vlm_weights")
+    hf_state_dict = resolve_checkpoint(source, model_cfg)
     halves = (
         ("language_model", model.language_model, get_remapping_rules(), (_VISION_ROOT, _MTP_ROOT)),
         ("vision_model", model.vision_model, get_vision_remapping_rules(), (_TEXT_ROOT, _MTP_ROOT)),

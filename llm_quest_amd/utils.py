@@ -136,3 +136,118 @@ class Qwen3_5Cache:
 
     def set_recurrent_state(self, layer_idx, recurrent_state):
         self.recurrent_states[layer_idx] = recurrent_state
+
+
+# ----------------------------------------------------------------------------------------------- checkpoint import (row f2)
+# API of the "WEIGHTS LOADING" helpers of llm_quest/utils.py:921-1035.  The build / GPU boxes have no network, so
+# ``download_hf_weights`` resolves its argument against the local filesystem (a .safetensors file, a directory of shards with
+# or without ``model.safetensors.index.json``) instead of the hub; everything downstream of it behaves as upstream.
+def read_local_checkpoint(source):
+    """dict of tensors, a ``.safetensors`` file, or a directory of ``*.safetensors`` shards -> one state dict."""
+    import glob
+    import json
+    import os
+
+    if isinstance(source, dict):
+        return source
+    from safetensors.torch import load_file
+
+    if os.path.isdir(source):
+        index = os.path.join(source, "model.safetensors.index.json")
+        if os.path.exists(index):
+            with open(index) as f:
+                names = sorted(set(json.load(f)["weight_map"].values()))
+            files = [os.path.join(source, n) for n in names]
+        else:
+            files = sorted(glob.glob(os.path.join(source, "*.safetensors")))
+        if not files:
+            raise FileNotFoundError(f"no .safetensors shards under {source}")
+    elif os.path.exists(source):
+        files = [source]
+    else:
+        raise FileNotFoundError(
+            f"'{source}' is not a local checkpoint.  This package never opens a network connection: fetch the Hugging Face "
+            "snapshot yourself and pass its directory (as model_cfg['model_path'] or as source=...)")
+    state = {}
+    for f in files:
+        state.update(load_file(f))
+    return state
+
+
+def resolve_checkpoint(source, model_cfg):
+    """``source`` (dict / file / shard directory) or, without it, the local snapshot that ``model_cfg["model_path"]`` names."""
+    if source is not None:
+        return read_local_checkpoint(source)
+    if not model_cfg.get("model_path"):
+        raise ValueError("no checkpoint given: pass source=<dict | .safetensors file | shard directory> or set model_cfg['model_path'] "
+                         "to a local snapshot (downloading from the Hugging Face hub is not available in this environment)")
+    return download_hf_weights(model_cfg["model_path"])
+
+
+def download_hf_weights(hf_model_name):
+    """The reference downloads ``hf_model_name`` from the hub (utils.py:921-953); here the name must be a local snapshot."""
+    print(f"Loading {hf_model_name} from local storage...")
+    state = read_local_checkpoint(hf_model_name)
+    print(f"Successfully loaded weights from {hf_model_name}")
+    return state
+
+
+def _target_name(hf_name, rules):
+    """Name a checkpoint tensor gets here: the (pattern, replacement) pairs rewrite substrings one after the other, and a pair
+    whose pattern is the COMPLETE original name closes the rewriting as soon as it fired (top-level tensors such as
+    ``model.norm.weight`` must not be touched by the per-layer suffix rules that follow)."""
+    name, k = hf_name, 0
+    while k < len(rules):
+        pattern, replacement = rules[k]
+        k += 1
+        if pattern not in name:
+            continue
+        name = name.replace(pattern, replacement)
+        if pattern == hf_name:
+            k = len(rules)
+    return name
+
+
+def convert_weights(hf_state_dict, our_state_dict, remapping_rules, ignored_prefixes=None):
+    """Hugging Face tensors under this package's parameter names (reference utils.py:956-1000).  A tensor is kept when its
+    target name exists in ``our_state_dict`` with the same shape; the others are reported and left out, tensors under
+    ``ignored_prefixes`` silently (counted)."""
+    ignored = tuple(ignored_prefixes) if ignored_prefixes else ()
+    wanted = {n: w for n, w in hf_state_dict.items() if not (ignored and n.startswith(ignored))}
+    plan = {n: _target_name(n, remapping_rules) for n in wanted}
+    converted = {}
+    for hf_name, ours in plan.items():
+        have = our_state_dict.get(ours)
+        if have is None:
+            print(f"WARNING: No match for HF weight '{hf_name}' → tried '{ours}'")
+        elif have.shape != wanted[hf_name].shape:
+            print(f"WARNING: Shape mismatch: {ours}: HF {wanted[hf_name].shape} vs Ours {have.shape}")
+        else:
+            converted[ours] = wanted[hf_name].clone()
+    if len(wanted) != len(hf_state_dict):
+        print(f"Skipped {len(hf_state_dict) - len(wanted)} weights")
+    return converted
+
+
+def handle_weight_tying(model):
+    """After ``load_state_dict``: make ``out_head.weight`` the embedding matrix again when the model ties them
+    (reference utils.py:1003-1022)."""
+    if not getattr(model, "tie_embeddings", False):
+        print("Tie_embeddings=False, skipping weight tying\n")
+        return
+    emb, head = model.emb_dict.weight, model.out_head.weight
+    if emb.shape != head.shape:
+        print(f"WARNING: Shape mismatch for weight tying: {emb.shape} vs {head.shape}")
+        return
+    model.out_head.weight = emb
+    print("Weight tied successfully\n" if model.out_head.weight is model.emb_dict.weight else "WARNING: Weight tying failed!\n")
+
+
+def report_loading_status(model, load_result, converted_weights):
+    """What was loaded, what the model still misses, what the checkpoint had in excess (reference utils.py:1025-1035)."""
+    print(f"Loaded {len(converted_weights)}/{len(model.state_dict())} weights successfully\n")
+    if load_result.missing_keys:
+        print(f"Missing keys ({len(load_result.missing_keys)}): {load_result.missing_keys}")
+        print("-> out_head is expected here with tie_embeddings=True, and so are the locally rebuilt buffers (mask, cos, sin)\n")
+    if load_result.unexpected_keys:
+        print(f"Unexpected keys: {load_result.unexpected_keys}")

@@ -513,6 +513,155 @@ def gen_pipeline(out):
     print("wrote pipeline.safetensors", len(t), "tensors")
 
 
+def gen_signatures(out):
+    """Names + argument lists of every symbol on the drop-in boundary, read from the reference's source
+    with ast (oracle/signatures.py): data only, no source text."""
+    import json
+
+    sys.path.append(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from oracle import signatures as S
+
+    ref_root = os.path.join(sys.path[0], "llm_quest")
+    table = S.collect_tree(ref_root)
+    path = os.path.join(out, "signatures.json")
+    with open(path, "w") as f:
+        json.dump({"note": "reference call signatures (ast, annotations dropped); generated by oracle/gen_golden.py::gen_signatures",
+                   "out_of_scope": {m: {k: v for k, v in d.items() if k not in ("*", "keep")} for m, d in S.OUT_OF_SCOPE.items() if d},
+                   "modules": table}, f, indent=1, sort_keys=True)
+    print(f"wrote {path} ({sum(len(v) for v in table.values())} symbols in {len(table)} modules)")
+
+
+def _hf_qwen3_tensors(cfg):
+    """(name, shape) of a Hugging Face Qwen3 dense checkpoint, from the published architecture (Qwen3ForCausalLM)."""
+    d, hd, nq, nkv, ff = cfg["emb_dim"], cfg["head_dim"], cfg["n_heads"], cfg["num_kv_groups"], cfg["hidden_dim"]
+    t = [("model.embed_tokens.weight", (cfg["vocab_size"], d)), ("model.norm.weight", (d,)), ("lm_head.weight", (cfg["vocab_size"], d))]
+    for i in range(cfg["n_layers"]):
+        p = f"model.layers.{i}."
+        t += [(p + "self_attn.q_proj.weight", (nq * hd, d)), (p + "self_attn.k_proj.weight", (nkv * hd, d)), (p + "self_attn.v_proj.weight", (nkv * hd, d)),
+              (p + "self_attn.o_proj.weight", (d, nq * hd)), (p + "self_attn.q_norm.weight", (hd,)), (p + "self_attn.k_norm.weight", (hd,)),
+              (p + "input_layernorm.weight", (d,)), (p + "post_attention_layernorm.weight", (d,)),
+              (p + "mlp.gate_proj.weight", (ff, d)), (p + "mlp.up_proj.weight", (ff, d)), (p + "mlp.down_proj.weight", (d, ff)),
+              (p + "self_attn.rotary_emb.inv_freq", (hd // 2,))]  # a tensor older checkpoints carry and no model has: must be reported
+    t.append(("model.layers.0.mlp.down_proj.weight_scale", (1,)))  # unknown suffix on a known stem
+    return t
+
+
+def _hf_qwen35_tensors(cfg):
+    """(name, shape) of a Hugging Face Qwen3.5 checkpoint (text stack + vision tower + mtp head), from the published architecture."""
+    d, hd, nq, nkv, ff = cfg["emb_dim"], cfg["head_dim"], cfg["n_heads"], cfg["num_kv_groups"], cfg["hidden_dim"]
+    hk, hv, dk, dv, ks = cfg["linear_num_qk_heads"], cfg["linear_num_value_heads"], cfg["linear_qk_head_dim"], cfg["linear_value_head_dim"], cfg["linear_conv_kernel_size"]
+    conv_dim = 2 * hk * dk + hv * dv
+    root = "model.language_model."
+    t = [(root + "embed_tokens.weight", (cfg["vocab_size"], d)), (root + "norm.weight", (d,)), ("lm_head.weight", (cfg["vocab_size"], d)), ("mtp.fc.weight", (d, 2 * d))]
+    for i in range(cfg["n_layers"]):
+        p = f"{root}layers.{i}."
+        t += [(p + "input_layernorm.weight", (d,)), (p + "post_attention_layernorm.weight", (d,)),
+              (p + "mlp.gate_proj.weight", (ff, d)), (p + "mlp.up_proj.weight", (ff, d)), (p + "mlp.down_proj.weight", (d, ff))]
+        if (i + 1) % cfg["linear_sdpa_ratio"] == 0:
+            t += [(p + "self_attn.q_proj.weight", (2 * nq * hd, d)), (p + "self_attn.k_proj.weight", (nkv * hd, d)), (p + "self_attn.v_proj.weight", (nkv * hd, d)),
+                  (p + "self_attn.o_proj.weight", (d, nq * hd)), (p + "self_attn.q_norm.weight", (hd,)), (p + "self_attn.k_norm.weight", (hd,))]
+        else:
+            t += [(p + "linear_attn.A_log", (hv,)), (p + "linear_attn.dt_bias", (hv,)), (p + "linear_attn.in_proj_qkv.weight", (conv_dim, d)),
+                  (p + "linear_attn.in_proj_z.weight", (hv * dv, d)), (p + "linear_attn.in_proj_b.weight", (hv, d)), (p + "linear_attn.in_proj_a.weight", (hv, d)),
+                  (p + "linear_attn.conv1d.weight", (conv_dim, 1, ks)), (p + "linear_attn.norm.weight", (dv,)), (p + "linear_attn.out_proj.weight", (d, hv * dv))]
+    ve, vh, ps, tp, m = cfg["vision_emb_dim"], cfg["vision_hidden_dim"], cfg["patch_size"], cfg["temporal_patch_size"], cfg["spatial_merge_size"]
+    v = "model.visual."
+    t += [(v + "patch_embed.proj.weight", (ve, cfg["in_channels"], tp, ps, ps)), (v + "patch_embed.proj.bias", (ve,)), (v + "pos_embed.weight", (cfg["num_position_embeddings"], ve))]
+    for i in range(cfg["vision_n_layers"]):
+        p = f"{v}blocks.{i}."
+        t += [(p + "norm1.weight", (ve,)), (p + "norm1.bias", (ve,)), (p + "norm2.weight", (ve,)), (p + "norm2.bias", (ve,)),
+              (p + "attn.qkv.weight", (3 * ve, ve)), (p + "attn.qkv.bias", (3 * ve,)), (p + "attn.proj.weight", (ve, ve)), (p + "attn.proj.bias", (ve,)),
+              (p + "mlp.linear_fc1.weight", (vh, ve)), (p + "mlp.linear_fc1.bias", (vh,)), (p + "mlp.linear_fc2.weight", (ve, vh)), (p + "mlp.linear_fc2.bias", (ve,))]
+    t += [(v + "merger.norm.weight", (ve,)), (v + "merger.norm.bias", (ve,)), (v + "merger.linear_fc1.weight", (ve * m * m, ve * m * m)),
+          (v + "merger.linear_fc1.bias", (ve * m * m,)), (v + "merger.linear_fc2.weight", (cfg["llm_d_in"], ve * m * m)), (v + "merger.linear_fc2.bias", (cfg["llm_d_in"],))]
+    t.append((root + "layers.0.linear_attn.dt_bias_extra", (hv,)))  # unknown tensor: must be reported, not loaded
+    return t
+
+
+
+
+def gen_weight_maps(out):
+    """Row f2: the REFERENCE's ``convert_weights`` + rule tables applied to synthetic Hugging-Face-named checkpoints.  The fixture
+    holds the checkpoint's (name, shape) list and, per loader, which of this package's parameter names each tensor reached."""
+    import contextlib
+    import io
+    import json
+
+    from llm_quest.qwen.qwen3 import qwen3_weight_loading as W3
+    from llm_quest.qwen.qwen3.qwen3_model import Qwen3Model
+    from llm_quest.qwen.qwen3_5 import qwen3_5_weight_loading as W35
+    from llm_quest.qwen.qwen3_5.qwen3_5_vlm_model import Qwen3_5VLM
+    from llm_quest.utils import convert_weights
+
+    def run(tensors, state, rules, ignored=None):
+        hf = {n: torch.zeros(s) for n, s in tensors}
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            conv = convert_weights(hf, state, rules, ignored_prefixes=ignored)
+        return {"loaded": sorted(conv), "warnings": sum(1 for line in buf.getvalue().splitlines() if line.startswith("WARNING")),
+                "skipped": sum(1 for n, _ in tensors if ignored and n.startswith(tuple(ignored)))}
+
+    res = {}
+    for tie in (True, False):
+        cfg = dict(TINY_QWEN, head_dim=32, tie_embeddings=tie, model_type="dense")
+        tensors = _hf_qwen3_tensors(cfg)
+        res[f"qwen3_tie{int(tie)}"] = {"cfg": {k: v for k, v in cfg.items() if k != "dtype"}, "tensors": [[n, list(s)] for n, s in tensors],
+                                        "result": run(tensors, Qwen3Model(cfg).state_dict(), W3.get_remapping_rules(cfg))}
+    cfg = dict(TINY_Q35_TEXT, **TINY_Q35_VISION, image_token_id=250, dtype=torch.bfloat16)
+    vlm = Qwen3_5VLM(cfg)
+    tensors = _hf_qwen35_tensors(cfg)
+    res["qwen35"] = {
+        "cfg": {k: v for k, v in cfg.items() if k != "dtype"}, "tensors": [[n, list(s)] for n, s in tensors],
+        "text": run(tensors, vlm.language_model.state_dict(), W35.get_remapping_rules(), ("model.visual.", "mtp.")),
+        "vision": run(tensors, vlm.vision_model.state_dict(), W35.get_vision_remapping_rules(), ("model.language_model.", "mtp.")),
+    }
+    path = os.path.join(out, "weight_maps.json")
+    with open(path, "w") as f:
+        json.dump(res, f, indent=1, sort_keys=True)
+    print(f"wrote {path}")
+
+
+def gen_rope_extra(out):
+    """The rest of the RoPE / VisionRoPE boundary (common/rope.py): YaRN / NTK tables, fp32 and partial-rotation apply, 2-D axial
+    apply over two frames, and the gradients autograd gives through apply / apply_mrope."""
+    from llm_quest.common.rope import RoPE, VisionRoPE
+
+    t = {}
+    torch.manual_seed(SEED)
+    yarn = dict(factor=4.0, alpha=1.0, beta=32.0, og_ctx_len=64, ctx_len=256)
+    for tag, ntk in (("ntk", True), ("plain", False)):
+        c, s_ = RoPE.compute_angles(10_000, 64, 256, smooth_scaling_cfg=yarn, ntk_aware_scaling=ntk)
+        t[f"yarn.{tag}.cos"], t[f"yarn.{tag}.sin"] = c, s_
+    t["yarn.theta"] = RoPE.wavelength_scaling(10_000, 64, yarn)
+    # partial rotation (32 of 64 features) with position ids, bf16 and fp32, forward + gradient
+    cos, sin = RoPE.compute_angles(10_000, 64, 48, rotation_factor=0.5)
+    pid = torch.randint(0, 48, (2, 16))
+    t["part.cos"], t["part.sin"], t["part.pid"] = cos, sin, pid
+    for tag, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+        x = torch.randn(2, 3, 16, 64).to(dt).requires_grad_(True)
+        g = torch.randn(2, 3, 16, 64).to(dt)
+        y = RoPE.apply(x, cos, sin, pid)
+        y.backward(g)
+        t[f"part.{tag}.x"], t[f"part.{tag}.g"], t[f"part.{tag}.y"], t[f"part.{tag}.gx"] = x.detach(), g, y.detach(), x.grad
+    # heads stored token-major (b, s, h, d) and handed over as the transposed view, as the attention modules do
+    xt = torch.randn(2, 16, 3, 64).to(torch.bfloat16)
+    t["tm.x"] = xt
+    t["tm.y"] = RoPE.apply(xt.transpose(1, 2), cos, sin).contiguous()
+    # MRoPE-I gradient
+    mc, ms = RoPE.compute_angles(10_000_000, 32, 64, rotation_factor=0.5)
+    q = torch.randn(2, 2, 10, 32).to(torch.bfloat16).requires_grad_(True)
+    mp = torch.randint(0, 40, (3, 2, 10))
+    gq = torch.randn(2, 2, 10, 32).to(torch.bfloat16)
+    yo = RoPE.apply_mrope(q, mc, ms, mp, [3, 3, 2])
+    yo.backward(gq)
+    t["mrope.cos"], t["mrope.sin"], t["mrope.pid"], t["mrope.q"], t["mrope.g"], t["mrope.y"], t["mrope.gq"] = mc, ms, mp, q.detach(), gq, yo.detach(), q.grad
+    # 2-D axial RoPE over two frames
+    vc, vs = VisionRoPE.compute_angles_2d(10_000, 64, 3, 5, num_frames=2)
+    xv = torch.randn(2, 2, 30, 64).to(torch.bfloat16)
+    t["vis.cos"], t["vis.sin"], t["vis.x"], t["vis.y"] = vc, vs, xv, VisionRoPE.apply(xv, vc, vs)
+    _save(os.path.join(out, "rope_extra.safetensors"), t, "RoPE / VisionRoPE boundary: YaRN tables, partial / fp32 / token-major / MRoPE / 2-D apply and gradients")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -523,7 +672,7 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
     only = os.environ.get("GOLDEN_ONLY")
-    for fn in (gen_index, gen_ops, gen_qwen, gen_vit, gen_vlm, gen_gpt, gen_qwen35, gen_qwen35_text, gen_pipeline, gen_decode, gen_decode35):
+    for fn in (gen_index, gen_ops, gen_qwen, gen_vit, gen_vlm, gen_gpt, gen_qwen35, gen_qwen35_text, gen_pipeline, gen_decode, gen_decode35, gen_signatures, gen_weight_maps, gen_rope_extra):
         if only and fn.__name__ != only:
             continue
         fn(args.out)

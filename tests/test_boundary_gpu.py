@@ -1,0 +1,141 @@
+"""Drop-in boundary entry points that run on their own: ``RoPE.apply`` / ``apply_mrope`` / ``VisionRoPE.apply`` on
+device tensors (``mi355_rope_apply``) and the ``forward`` of every Qwen3.5 vision sub-module, against fixtures the reference produced
+(``tests/golden/rope_extra.safetensors``, ``per_op``, ``qwen35_text_tiny``, ``qwen35_vision_tiny``)."""
+
+import pytest
+import torch
+
+from conftest import sub_dict
+from oracle.gen_golden import TINY_Q35_VISION
+
+pytestmark = pytest.mark.gpu
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def test_rope_apply_on_device_is_bit_exact(golden):
+    """bf16: coefficients, both products and the sum round to bf16 exactly where the reference's torch ops do -> identical bits;
+    fp32: plain fp32 multiplies and one add, no contraction -> identical bits."""
+    from llm_quest_amd.common.rope import RoPE, VisionRoPE
+
+    t = golden("per_op")
+    x = t["rope.x"].cuda()
+    assert torch.equal(RoPE.apply(x, t["rope.cos"].cuda(), t["rope.sin"].cuda()).cpu(), t["rope.y"])
+    assert torch.equal(RoPE.apply(x, t["rope.cos"], t["rope.sin"], t["rope.pid"].cuda()).cpu(), t["rope.y_pid"])  # host tables are moved
+    e = golden("rope_extra")
+    cos, sin, pid = e["part.cos"].cuda(), e["part.sin"].cuda(), e["part.pid"].cuda()
+    for tag in ("bf16", "fp32"):
+        xx = e[f"part.{tag}.x"].cuda().requires_grad_(True)
+        y = RoPE.apply(xx, cos, sin, pid)  # 32 of 64 features rotate, the rest pass through
+        assert y.dtype == xx.dtype and torch.equal(y.cpu(), e[f"part.{tag}.y"]), tag
+        y.backward(e[f"part.{tag}.g"].cuda())
+        assert torch.equal(xx.grad.cpu(), e[f"part.{tag}.gx"]), tag
+    # token-major heads handed over as a transposed view (no copy: the kernel takes the strides)
+    xt = e["tm.x"].cuda()
+    yt = RoPE.apply(xt.transpose(1, 2), cos, sin)
+    assert yt.stride() == xt.transpose(1, 2).stride() and torch.equal(yt.contiguous().cpu(), e["tm.y"])
+    # 2-D axial tables over two frames
+    assert torch.equal(VisionRoPE.apply(e["vis.x"].cuda(), e["vis.cos"].cuda(), e["vis.sin"].cuda()).cpu(), e["vis.y"])
+    # an odd half width takes the scalar path of the kernel
+    c6, s6 = RoPE.compute_angles(10_000, 12, 8, rotation_factor=0.5)  # 6 features rotate: half = 3
+    x6 = torch.randn(1, 2, 8, 12).to(BF16)
+    assert torch.equal(RoPE.apply(x6.cuda(), c6.cuda(), s6.cuda()).cpu(), RoPE.apply(x6, c6, s6))
+
+
+def test_apply_mrope_on_device_is_bit_exact(golden):
+    from llm_quest_amd.common.rope import RoPE
+
+    t = golden("qwen35_text_tiny")
+    out = RoPE.apply_mrope(t["mrope.q"].cuda(), t["mrope.cos"].cuda(), t["mrope.sin"].cuda(), t["mrope.pid"].cuda(), [3, 3, 2])
+    assert torch.equal(out.cpu(), t["mrope.out"])
+    e = golden("rope_extra")
+    q = e["mrope.q"].cuda().requires_grad_(True)
+    y = RoPE.apply_mrope(q, e["mrope.cos"].cuda(), e["mrope.sin"].cuda(), e["mrope.pid"].cuda(), [3, 3, 2])
+    assert torch.equal(y.cpu(), e["mrope.y"])
+    y.backward(e["mrope.g"].cuda())
+    assert torch.equal(q.grad.cpu(), e["mrope.gq"])
+
+
+def _tower(golden):
+    from llm_quest_amd.qwen.qwen3_5.qwen3_5_vision_model import Qwen3_5VisionModel
+
+    t = golden("qwen35_vision_tiny")
+    m = Qwen3_5VisionModel(dict(TINY_Q35_VISION))
+    m.load_state_dict(sub_dict(t, "vis.sd."))
+    return t, m.cuda().train()
+
+
+def test_vision_submodule_forwards_compose_to_the_reference_tower(golden):
+    """PatchEmbedding3D.forward -> + pos_embed -> Qwen3_5VisionTransformerBlock.forward(x, cos, sin) x L -> ViTMergeAdapter.forward, each
+    called through its own ``forward`` as a user of the reference would, reproduces the reference tower's output and every parameter
+    gradient at the tolerances of the whole-model test, and agrees with this package's one-node tower."""
+    t, m = _tower(golden)
+    pixels = t["vis.in"].cuda()
+    x = m.patch_embed(pixels)
+    nsp = m.n_spatial_patches
+    frames = x.shape[1] // nsp
+    assert x.shape == (pixels.shape[0], frames * nsp, m.emb_dim) and x.dtype == F32
+    x = x + m.pos_embed(torch.arange(nsp, device="cuda")).unsqueeze(0).repeat(1, frames, 1)
+    cos, sin = m.cos.repeat(frames, 1), m.sin.repeat(frames, 1)
+    for blk in m.blocks:
+        x = blk(x, cos, sin)
+    out = m.merge_adapter(x)
+    assert out.shape == t["vis.out"].shape
+    assert rel_l2(out, t["vis.out"]) < 1.5e-2
+    out.backward(t["vis.gout"].cuda())
+    ref = sub_dict(t, "vis.grad.")
+    for name, p in m.named_parameters():
+        assert p.grad is not None, name
+        err = float((p.grad.double().cpu() - ref[name].double()).norm())
+        assert err <= 4e-2 * float(ref[name].double().norm()) + 1e-3, f"{name}: |err| {err:.3e} |ref| {float(ref[name].norm()):.3e}"
+    with torch.no_grad():
+        assert rel_l2(out, m(pixels)) < 2e-3  # the tower fuses the positional add into the patch GEMM's epilogue
+
+
+def test_vision_attention_and_ffn_forward_alone(golden):
+    """Qwen3_5VisionAttention.forward(x, cos, sin) and Qwen3_5VisionFFN.forward(x) against the same arithmetic in fp32 torch ops on the
+    module's own weights (the reference's forward bodies, qwen3_5_vision_model.py:124-125, 153-198), forward and input gradient."""
+    from llm_quest_amd.common.rope import VisionRoPE
+
+    t, m = _tower(golden)
+    blk = m.blocks[0]
+    torch.manual_seed(5)
+    B, S, d = 2, 2 * m.n_spatial_patches, m.emb_dim
+    x = torch.randn(B, S, d, device="cuda").requires_grad_(True)
+    g = torch.randn(B, S, d, device="cuda")
+    cos, sin = m.cos.repeat(2, 1), m.sin.repeat(2, 1)
+    # --- attention
+    y = blk.att(x, cos, sin)
+    y.backward(g)
+    gx, x.grad = x.grad.clone(), None
+    att, H, Dh = blk.att, blk.att.num_heads, blk.att.head_dim
+    xr = x.detach().clone().requires_grad_(True)
+    q, k, v = torch.nn.functional.linear(xr, att.qkv.weight, att.qkv.bias).chunk(3, dim=-1)
+    q, k, v = (u.view(B, S, H, Dh).transpose(1, 2) for u in (q, k, v))
+    rot = lambda u: cos[:S] * u + sin[:S] * torch.cat((-u[..., Dh // 2 :], u[..., : Dh // 2]), dim=-1)
+    ctx = torch.nn.functional.scaled_dot_product_attention(rot(q), rot(k), v)
+    yr = torch.nn.functional.linear(ctx.transpose(1, 2).reshape(B, S, d), att.proj.weight, att.proj.bias)
+    yr.backward(g)
+    assert y.dtype == F32 and rel_l2(y, yr) < 1.5e-2 and rel_l2(gx, xr.grad) < 2e-2
+    assert att.qkv.weight.grad is not None and att.proj.bias.grad is not None
+    # --- FFN (tanh GELU)
+    y2 = blk.ffn(x)
+    y2.backward(g)
+    ffn = blk.ffn
+    xr2 = x.detach().clone().requires_grad_(True)
+    yr2 = torch.nn.functional.linear(torch.nn.functional.gelu(torch.nn.functional.linear(xr2, ffn.lin1.weight, ffn.lin1.bias), approximate="tanh"), ffn.lin2.weight, ffn.lin2.bias)
+    yr2.backward(g)
+    assert rel_l2(y2, yr2) < 1.5e-2 and rel_l2(x.grad, xr2.grad) < 2e-2
+    # bf16 input gives a bf16 result, eval / no_grad works
+    with torch.no_grad():
+        assert blk.ffn(x.detach().to(BF16)).dtype == BF16

@@ -256,3 +256,42 @@ def test_hf_qwen3_5_checkpoint_import_round_trip(tmp_path, capsys):
     assert torch.equal(keep.trf_blocks[0].att.dt_bias, before)
     with pytest.raises(ValueError):
         load_qwen3_5_vlm_weights(Qwen3_5VLM(cfg), cfg)
+
+
+def test_hf_checkpoint_key_maps_match_the_reference_converter(capsys):
+    """Row f2 pinned to the reference: ``tests/golden/weight_maps.json`` holds synthetic Hugging-Face-named checkpoints ((name, shape)
+    lists written from the published HF layouts) and what the REFERENCE's ``convert_weights`` + rule tables made of them
+    (``oracle/gen_golden.py::gen_weight_maps``).  The same checkpoints through this package's converter, against this package's models,
+    must reach exactly the same parameter names, report as many problems and skip as many tensors."""
+    import json
+    import os
+
+    from llm_quest_amd.qwen.qwen3 import qwen3_weight_loading as W3
+    from llm_quest_amd.qwen.qwen3.qwen3_model import Qwen3Model
+    from llm_quest_amd.qwen.qwen3_5 import qwen3_5_weight_loading as W35
+    from llm_quest_amd.qwen.qwen3_5.qwen3_5_vlm_model import Qwen3_5VLM
+    from llm_quest_amd.utils import convert_weights
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "weight_maps.json")) as f:
+        fx = json.load(f)
+
+    def run(tensors, state, rules, ignored=None):
+        hf = {n: torch.zeros(tuple(s)) for n, s in tensors}
+        capsys.readouterr()
+        conv = convert_weights(hf, state, rules, ignored_prefixes=ignored)
+        out = capsys.readouterr().out
+        skipped = [int(line.split()[1]) for line in out.splitlines() if line.startswith("Skipped ")]
+        return {"loaded": sorted(conv), "warnings": sum(1 for line in out.splitlines() if line.startswith("WARNING")), "skipped": skipped[0] if skipped else 0}
+
+    for case in ("qwen3_tie1", "qwen3_tie0"):
+        cfg = dict(fx[case]["cfg"], dtype=torch.bfloat16)
+        got = run(fx[case]["tensors"], Qwen3Model(cfg).state_dict(), W3.get_remapping_rules(cfg))
+        assert got == fx[case]["result"], case
+    cfg = dict(fx["qwen35"]["cfg"], dtype=torch.bfloat16)
+    vlm = Qwen3_5VLM(cfg)
+    assert run(fx["qwen35"]["tensors"], vlm.language_model.state_dict(), W35.get_remapping_rules(), ("model.visual.", "mtp.")) == fx["qwen35"]["text"]
+    assert run(fx["qwen35"]["tensors"], vlm.vision_model.state_dict(), W35.get_vision_remapping_rules(), ("model.language_model.", "mtp.")) == fx["qwen35"]["vision"]
+    # every parameter of either model that a checkpoint can fill was filled (the rule tables cover the whole state dict)
+    loaded = set(fx["qwen35"]["text"]["loaded"])
+    missing = [k for k in vlm.language_model.state_dict() if k not in loaded and k not in ("mask", "cos", "sin", "out_head.weight")]
+    assert not missing, missing
