@@ -1,6 +1,10 @@
 """Headline benchmark: img+tokens/sec of the early-fusion VLM forward+backward step (BASELINE config 4).
 
-    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 runs one rank per GPU over RCCL.  Under ``torch.distributed.run`` (WORLD_SIZE set) this process IS a rank; started
+plainly with ``--gpus N`` it starts the N ranks itself -- a child ``python -m torch.distributed.run --nproc-per-node N bench.py ...``
+spawned before this process has touched the GPU -- and relays rank 0's JSON line and the child's exit status.
 
 A step = vision tower (frozen ViT-B/16, eval) -> ffn adapter -> early-fusion concat -> Qwen3-0.6B decoder on the fused
 709-token sequence -> tied LM head + cross entropy on the 512 text positions -> full backward (adapter + LLM), plus the
@@ -183,6 +187,21 @@ def dominant_kernel_rate(batch, device):
     return out
 
 
+def launch_ranks(n):
+    """``python bench.py --gpus N`` without a torchrun environment: run the N ranks as a child ``torch.distributed.run`` job (a fresh
+    process tree; nothing in THIS process has initialised the GPU yet) and pass its output and exit status through."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -194,12 +213,20 @@ def main():
     ap.add_argument("--optimizer", choices=["on", "off"], default="on", help="also time the same steps with clip + AdamW (reported beside the fwd+bwd metric)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        n_dev = torch.cuda.device_count()  # counts devices without creating a HIP context
+        if n_dev < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but only {n_dev} GPU(s) are visible")
+        raise SystemExit(launch_ranks(args.gpus))
+
     from llm_quest_amd import _lib, ddp
     from llm_quest_amd.multimodal.vlm_engine import vlm_step_loss
 
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:  # before any rendezvous: a mismatched launch must fail at once, not wait for peers
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: start one rank per GPU (python bench.py --gpus N does it itself)")
     rank, world, local = ddp.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -211,10 +238,12 @@ def main():
     sync.broadcast_parameters([llm, ad, vit])
     img, ids, mask = synthetic_batch(args.batch, device, seed=123 + rank, ragged=args.ragged)
 
+    n_targets = mask.sum()  # this rank's target tokens: ragged shards weight their mean loss by it (ddp.GradSync.loss_weight)
+
     def step():
         loss = vlm_step_loss(vit, llm, ad, img, ids, mask, hf_vit_model=False)
         sync.begin_step()
-        loss.backward()
+        (loss * sync.loss_weight(n_targets) if (args.ragged and world > 1) else loss).backward()
         sync.finish_step()
         llm.zero_grad(set_to_none=True)
         ad.zero_grad(set_to_none=True)
@@ -256,7 +285,7 @@ def main():
         def full_step():
             loss_ = vlm_step_loss(vit, llm, ad, img, ids, mask, hf_vit_model=False)
             sync.begin_step()
-            loss_.backward()
+            (loss_ * sync.loss_weight(n_targets) if (args.ragged and world > 1) else loss_).backward()
             sync.finish_step()
             opt.step()
             opt.zero_grad(set_to_none=True)
@@ -283,7 +312,7 @@ def main():
         achieved = ALGO_FLOP_PER_SAMPLE * args.batch / (elapsed / args.steps) / 1e12  # per GPU
         line = {
             "metric": "img+tokens/sec fwd+bwd, ViT-B+Qwen3-0.6B VLM, 224px+512tok",
-            "value": round(value, 1), "unit": "img+tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 1), "unit": "img+tok/s", "n_gpus": world, "rccl_ranks": world if world > 1 else 0, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {

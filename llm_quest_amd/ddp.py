@@ -14,10 +14,16 @@ pure data parallelism over one 8 x MI355X node.  Design:
     step are large enough to be link-bound, not launch-bound, and small enough to overlap at block granularity.
 
 Loss weighting: ``vlm_loss`` is a mean over non-ignored tokens per rank; averaging gradients across ranks equals the
-single-process global-batch gradient when every rank has the same number of target tokens (the synthetic all-ones mask).
-For ragged masks use ``token_weighted=True``: gradients are pre-scaled by this rank's token count and divided by the
-all-reduced total.
+single-process global-batch gradient only when every rank has the same number of target tokens (the synthetic all-ones
+mask).  For ragged masks multiply the loss by ``sync.loss_weight(n_target_tokens)`` before ``backward()``: the factor is
+``n_r * world / sum_r n_r`` (one 1-element all-reduce of the counts, no host sync), so the AVG all-reduce of the buckets
+returns ``sum_r grad(sum-loss_r) / sum_r n_r`` -- the gradient of the global-batch mean.
+
+Gradient accumulation: wrap every micro-step but the last in ``with sync.no_sync():`` -- the hooks then leave the buckets
+alone (they keep accumulating locally) and ``finish_step`` is a no-op; the last micro-step exchanges the sums.
 """
+
+import contextlib
 
 import os
 
@@ -66,6 +72,39 @@ class GradSync:
         for m in self.owners:
             object.__setattr__(m, "_grad_ready", self._on_ready)
         self.enabled = self.world > 1
+        self._sync_on = True
+
+    # ---------------------------------------------------------------- loss weighting / accumulation
+    def loss_weight(self, n_tokens):
+        """Factor that turns this rank's per-token MEAN loss into its share of the global-batch mean under the AVG exchange:
+        n_r * world / sum_r n_r.  ``n_tokens``: python int or 0-d / 1-element tensor (stays on its device).  1.0 when single-process."""
+        if not self.enabled:
+            return 1.0
+        if torch.is_tensor(n_tokens):
+            mine = n_tokens.detach().reshape(1).to(torch.float32)
+        else:
+            dev = self._device()
+            mine = torch.tensor([float(n_tokens)], dtype=torch.float32, device=dev)
+        total = mine.clone()
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)
+        return (mine * self.world / total.clamp_min(1.0)).reshape(())
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Micro-steps of a gradient-accumulation window that must NOT exchange: buckets keep accumulating locally."""
+        prev, self._sync_on = self._sync_on, False
+        try:
+            yield self
+        finally:
+            self._sync_on = prev
+
+    def _device(self):
+        for m in self.owners:
+            for p in m.parameters():
+                return p.device
+        for p in self.tail_params:
+            return p.device
+        return torch.device("cpu")
 
     # ---------------------------------------------------------------- helpers
     def _arena(self, module):
@@ -93,7 +132,7 @@ class GradSync:
             buf.div_(self.world)
 
     def _on_ready(self, module):
-        if not self.enabled:
+        if not self.enabled or not self._sync_on:
             return
         ar = self._arena(module)
         if id(ar) in self._done:
@@ -108,7 +147,7 @@ class GradSync:
 
     def finish_step(self):
         """Reduce buckets not yet sent, then order the compute stream after the communication stream."""
-        if not self.enabled:
+        if not self.enabled or not self._sync_on:
             return
         for m in self.owners:  # anything whose hook never fired (e.g. unused in this step)
             ar = self._arena(m)
@@ -136,16 +175,30 @@ class GradSync:
             by_dtype.setdefault(p.grad.dtype, []).append(p)
         for group_ps in by_dtype.values():
             flat = torch.cat([p.grad.reshape(-1) for p in group_ps])  # bucket assembly (communication plumbing)
-            if self.backend == "nccl":
-                dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+            if flat.is_cuda:  # same hand-off as the arenas: the exchange and the copy back run on the communication stream
+                if self.comm_stream is None:
+                    self.comm_stream = torch.cuda.Stream(device=flat.device)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(flat.device))
+                ctx = torch.cuda.stream(self.comm_stream)
+                self.comm_stream.wait_event(ev)
             else:
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-                flat.div_(self.world)
-            off = 0
-            for p in group_ps:
-                n = p.grad.numel()
-                p.grad.copy_(flat[off : off + n].view_as(p.grad))
-                off += n
+                ctx = contextlib.nullcontext()
+            with ctx:
+                if self.backend == "nccl":
+                    dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+                else:
+                    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+                    flat.div_(self.world)
+                off = 0
+                for p in group_ps:
+                    n = p.grad.numel()
+                    p.grad.copy_(flat[off : off + n].view_as(p.grad))
+                    off += n
+            if flat.is_cuda:
+                flat.record_stream(self.comm_stream)
+                for p in group_ps:
+                    p.grad.record_stream(self.comm_stream)
 
     def broadcast_parameters(self, modules, src=0):
         """Make every replica start from rank ``src``'s weights (one broadcast per arena / parameter)."""

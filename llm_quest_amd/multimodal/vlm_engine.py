@@ -144,9 +144,11 @@ def vlm_training_loop_simple(vit_model, vlm_model, adapter, train_loader, optimi
             loss = vlm_step_loss(vit_model, vlm_model, adapter, images, input_ids, mask, hf_vit_model)
             if grad_sync is not None:
                 grad_sync.begin_step()
-            loss.backward()
-            if grad_sync is not None:
+                # ragged captions: weight this rank's mean by its share of the global batch's target tokens (ddp.py)
+                (loss * grad_sync.loss_weight(mask.sum())).backward()
                 grad_sync.finish_step()
+            else:
+                loss.backward()
             total_loss += loss.detach().float()  # stays on the device: no per-step host sync (upstream calls .item())
             clip_grad_norm_(list(vlm_model.parameters()) + list(adapter.parameters()), max_norm=1.0)
             optimizer.step()

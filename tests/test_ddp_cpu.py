@@ -105,3 +105,81 @@ def test_gradsync_single_process_is_a_noop():
     s.begin_step()
     m._grad_ready(m)
     s.finish_step()
+
+
+def _ragged_worker(rank, world, port, out):
+    """Token-weighted exchange + gradient accumulation against the single-process global batch, on real autograd graphs."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from llm_quest_amd.ddp import GradSync, init_from_env
+    from llm_quest_amd.ops import arena_for
+
+    init_from_env(backend="gloo")
+    torch.manual_seed(7)
+    lin = torch.nn.Linear(6, 4)  # the same weights on every rank (seeded)
+    g = torch.Generator().manual_seed(11)
+    X = torch.randn(2 * world, 5, 6, generator=g)  # global batch: 2 samples per rank, 5 positions each
+    Y = torch.randint(0, 4, (2 * world, 5), generator=g)
+    lengths = torch.tensor([5, 2, 1, 4][: 2 * world])  # ragged: rank 0 has 7 target tokens, rank 1 has 5
+    M = torch.arange(5).unsqueeze(0) < lengths.unsqueeze(1)
+
+    def mean_loss(x, y, m):
+        return torch.nn.functional.cross_entropy(lin(x).flatten(0, 1), y.masked_fill(~m, -100).flatten(), ignore_index=-100)
+
+    # reference: one process, the whole batch
+    want_w, want_b = torch.autograd.grad(mean_loss(X, Y, M), [lin.weight, lin.bias])
+    # data parallel: this rank's shard, gradients written into the arena by autograd's .grad views
+    ar = arena_for(lin)
+    sync = GradSync([lin])
+
+    def shard_backward(weighted):
+        lin.zero_grad(set_to_none=True)
+        ar.grad.zero_()
+        sl = slice(2 * rank, 2 * rank + 2)
+        loss = mean_loss(X[sl], Y[sl], M[sl])
+        w = sync.loss_weight(M[sl].sum()) if weighted else 1.0
+        sync.begin_step()
+        grads = torch.autograd.grad(loss * w, list(lin.parameters()))
+        for p, g_ in zip(lin.parameters(), grads):  # what the wgrad kernels do on the GPU: the gradient is written into the arena
+            view, _ = ar.grad_target(p)
+            view.copy_(g_)
+        lin._grad_ready(lin)
+        sync.finish_step()
+
+    shard_backward(weighted=True)
+    ok = bool(torch.allclose(lin.weight.grad, want_w, atol=1e-6)) and bool(torch.allclose(lin.bias.grad, want_b, atol=1e-6))
+    shard_backward(weighted=False)  # the plain average of per-rank means is NOT the global-batch gradient on ragged shards
+    ok &= not bool(torch.allclose(lin.weight.grad, want_w, atol=1e-4))
+    # accumulation window of two micro-steps: nothing is exchanged inside no_sync, the sums are exchanged once
+    lin.zero_grad(set_to_none=True)
+    ar.grad.zero_()
+    with sync.no_sync():
+        sync.begin_step()
+        view, _ = ar.grad_target(lin.bias)
+        view.copy_(torch.full_like(view, float(rank + 1)))
+        lin._grad_ready(lin)
+        sync.finish_step()
+    ok &= bool(torch.equal(lin.bias.grad, torch.full_like(lin.bias, float(rank + 1))))  # still local
+    sync.begin_step()
+    view, acc = ar.grad_target(lin.bias)
+    ok &= acc is True
+    view.add_(10.0)
+    lin._grad_ready(lin)
+    sync.finish_step()
+    ok &= bool(torch.allclose(lin.bias.grad, torch.full_like(lin.bias, sum(r + 1 for r in range(world)) / world + 10.0)))
+    out.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_token_weighted_exchange_and_no_sync_world2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]
