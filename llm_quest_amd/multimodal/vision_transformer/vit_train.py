@@ -5,13 +5,19 @@ stream, bf16 MFMA operands (weights cast once per step, LayerNorm outputs writte
 encoder is ONE autograd node: forward keeps what backward needs (28 KB per token per layer), backward runs the dgrad /
 wgrad GEMMs, flash-attention backward (non-causal, D=64), exact-GELU and LayerNorm(sigma+eps) backward kernels and writes
 every parameter gradient (fp32) straight into ``p.grad``.
+
+Dropout (``drop_rate`` > 0 in train mode; reference vit_model.py:146, vit_attention.py:79, vit_transformer_block.py:117,124) runs on
+the HIP path with counter-based Philox masks that are regenerated, never stored (``llm_quest_amd/rng.py``): the embedding site is one
+element-wise pass, the two residual sites fuse the residual add (forward) and the bf16 cast of the incoming gradient (backward) into
+their pass, and the attention-weight site runs inside the attention kernels (``mi355_attn_dropout_fwd/bwd``).  With ``drop_rate`` 0 or
+in eval mode nothing changes: residual adds stay GEMM epilogues and attention stays on the tuned kernels.
 """
 
 import torch
 
 from llm_quest_amd import _lib as L
 from llm_quest_amd import kernels as K
-from llm_quest_amd import ops
+from llm_quest_amd import ops, rng
 from llm_quest_amd.multimodal.vision_transformer.vit_attention import bf16_cached, f32_cat_cached
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -66,12 +72,15 @@ def vit_forward_train(m, img, output_hidden_states):
     pe = m.patch_embedding
     B = img.shape[0]
     S, d = pe.num_patches + 1, m.pos_embedding.shape[-1]
-    if m.training and m.dropout.p > 0:
-        raise NotImplementedError("dropout is not implemented on the HIP path; train with drop_rate=0 (SURVEY.md section 7, hard parts)")
+    p_emb = m.dropout.p if m.training else 0.0
     rows = K.patchify(img.contiguous().to(F32), pe.patch_size, out_dtype=BF16)
     wconv = bf16_cached(pe, "wconv", [pe.conv_proj.weight])
     proj = K.gemm(L.GEMM_NT, rows, wconv, bias=pe.conv_proj.bias.detach(), out_dtype=F32)
     x = K.vit_embed_assemble(proj, pe.cls_token.detach().reshape(-1).contiguous(), m.pos_embedding.detach().reshape(S, d).contiguous(), B, S, d).view(B * S, d)
+    s_emb = None
+    if p_emb > 0:
+        s_emb = rng.draw()
+        x = K.dropout(x, p_emb, *s_emb)
     saved_blocks = []
     for blk in m.transformer_blocks:
         att, ffn = blk.att, blk.ffn
@@ -80,15 +89,30 @@ def vit_forward_train(m, img, output_hidden_states):
         wqkv = bf16_cached(att, "wqkv", [att.w_queries.weight, att.w_keys.weight, att.w_values.weight])
         bqkv = f32_cat_cached(att, "bqkv", [att.w_queries.bias, att.w_keys.bias, att.w_values.bias]) if att.w_queries.bias is not None else None
         qkv = K.gemm(L.GEMM_NT, h1, wqkv, bias=bqkv)
-        ctx, lse = K.attn_fwd(qkv[:, :d], qkv[:, d : 2 * d], qkv[:, 2 * d :], B, S, H, H, Dh, key_mask=None, causal=False, scale=att.att_scaling)
+        p_att = att.dropout.p if m.training else 0.0
+        p_res = blk.dropout.p if m.training else 0.0
+        s_att = s_proj = s_ffn = None
+        if p_att > 0:  # dropout on the softmax weights, inside the kernel
+            s_att = rng.draw()
+            ctx, lse = K.attn_dropout_fwd(qkv[:, :d], qkv[:, d : 2 * d], qkv[:, 2 * d :], B, S, H, H, Dh, p_att, *s_att, causal=False, scale=att.att_scaling)
+        else:
+            ctx, lse = K.attn_fwd(qkv[:, :d], qkv[:, d : 2 * d], qkv[:, 2 * d :], B, S, H, H, Dh, key_mask=None, causal=False, scale=att.att_scaling)
         wo = bf16_cached(att, "wo", [att.out_proj.weight])
-        x2 = K.gemm(L.GEMM_NT, ctx, wo, bias=att.out_proj.bias.detach(), residual=x, out_dtype=F32)
+        if p_res > 0:  # x2 = x + dropout(proj): the residual add moves from the GEMM epilogue into the dropout pass
+            s_proj = rng.draw()
+            x2 = K.dropout(K.gemm(L.GEMM_NT, ctx, wo, bias=att.out_proj.bias.detach(), out_dtype=F32), p_res, *s_proj, residual=x)
+        else:
+            x2 = K.gemm(L.GEMM_NT, ctx, wo, bias=att.out_proj.bias.detach(), residual=x, out_dtype=F32)
         h2, mean2, rsig2 = K.layernorm_fwd(x2, blk.ln_2.scale.detach(), blk.ln_2.shift.detach(), out_dtype=BF16, eps=blk.ln_2.eps, want_stats=True)
         w1 = bf16_cached(ffn, "w1", [ffn.layers[0].weight])
         y1, f = K.gemm_gelu_dual(h2, w1, bias=ffn.layers[0].bias.detach())  # Linear + GELU in one launch (pre-activation kept for the backward)
         w2 = bf16_cached(ffn, "w2", [ffn.layers[2].weight])
-        x3 = K.gemm(L.GEMM_NT, f, w2, bias=ffn.layers[2].bias.detach(), residual=x2, out_dtype=F32)
-        saved_blocks.append((x, mean1, rsig1, h1, qkv, ctx, lse, x2, mean2, rsig2, h2, y1, f))
+        if p_res > 0:
+            s_ffn = rng.draw()
+            x3 = K.dropout(K.gemm(L.GEMM_NT, f, w2, bias=ffn.layers[2].bias.detach(), out_dtype=F32), p_res, *s_ffn, residual=x2)
+        else:
+            x3 = K.gemm(L.GEMM_NT, f, w2, bias=ffn.layers[2].bias.detach(), residual=x2, out_dtype=F32)
+        saved_blocks.append((x, mean1, rsig1, h1, qkv, ctx, lse, x2, mean2, rsig2, h2, y1, f, (p_att, s_att, p_res, s_proj, s_ffn)))
         x = x3
     ln = m.final_ln
     if output_hidden_states:
@@ -102,12 +126,12 @@ def vit_forward_train(m, img, output_hidden_states):
         wc = bf16_cached(m, "wcls", [m.classifier.weight])
         out = K.gemm(L.GEMM_NT, cls_n, wc, bias=m.classifier.bias.detach(), out_dtype=BF16)
         tail = ("logits", cls_rows, meanf, rsigf, cls_n)
-    return out, (rows, saved_blocks, tail, (B, S, d))
+    return out, (rows, saved_blocks, tail, (B, S, d), (p_emb, s_emb))
 
 
 # ------------------------------------------------------------------------------------------- backward
 def vit_backward(m, saved, dout):
-    rows, saved_blocks, tail, (B, S, d) = saved
+    rows, saved_blocks, tail, (B, S, d), (p_emb, s_emb) = saved
     pe = m.patch_embedding
     ln = m.final_ln
     if tail[0] == "hidden":
@@ -138,12 +162,12 @@ def vit_backward(m, saved, dout):
         dx = torch.zeros((B * S, d), dtype=F32, device=dcls.device)
         K.copy2d(dcls, dx.view(B, S * d)[:, :d])
     for blk, sv in zip(reversed(m.transformer_blocks), reversed(saved_blocks)):
-        x, mean1, rsig1, h1, qkv, ctx, lse, x2, mean2, rsig2, h2, y1, f = sv
+        x, mean1, rsig1, h1, qkv, ctx, lse, x2, mean2, rsig2, h2, y1, f, (p_att, s_att, p_res, s_proj, s_ffn) = sv
         att, ffn = blk.att, blk.ffn
         H, Dh = att.num_heads, att.head_dim
         wg = []  # this block's six weight gradients, one grouped launch
-        # ---- FFN half
-        dx3b = K.cast(dx, BF16)
+        # ---- FFN half (the dropout site's backward is the same mask on the gradient, fused with the bf16 cast)
+        dx3b = K.dropout(dx, p_res, *s_ffn, out_dtype=BF16) if p_res > 0 else K.cast(dx, BF16)
         dy1 = K.gemm_dgrad_gelu_bwd(dx3b, bf16_cached(ffn, "w2", [ffn.layers[2].weight]), y1)  # GELU backward in the dgrad epilogue
         _wgrad(ffn.layers[2].weight, dx3b, f, wg)
         _bgrad(ffn.layers[2].bias, dx3b)
@@ -152,13 +176,17 @@ def vit_backward(m, saved, dout):
         _bgrad(ffn.layers[0].bias, dy1)
         dx2 = _ln_bwd(blk.ln_2, x2, mean2, rsig2, dh2, dx)
         # ---- attention half
-        dx2b = K.cast(dx2, BF16)
+        dx2b = K.dropout(dx2, p_res, *s_proj, out_dtype=BF16) if p_res > 0 else K.cast(dx2, BF16)
         dctx = K.dgrad(dx2b, bf16_cached(att, "wo", [att.out_proj.weight]))
         _wgrad(att.out_proj.weight, dx2b, ctx, wg)
         _bgrad(att.out_proj.bias, dx2b)
         dqkv = torch.empty_like(qkv)
-        K.attn_bwd(qkv[:, :d], qkv[:, d : 2 * d], qkv[:, 2 * d :], ctx, dctx, lse, B, S, H, H, Dh,
-                   dqkv[:, :d], dqkv[:, d : 2 * d], dqkv[:, 2 * d :], key_mask=None, causal=False, scale=att.att_scaling)
+        if p_att > 0:
+            K.attn_dropout_bwd(qkv[:, :d], qkv[:, d : 2 * d], qkv[:, 2 * d :], ctx, dctx, lse, B, S, H, H, Dh,
+                               dqkv[:, :d], dqkv[:, d : 2 * d], dqkv[:, 2 * d :], p_att, *s_att, causal=False, scale=att.att_scaling)
+        else:
+            K.attn_bwd(qkv[:, :d], qkv[:, d : 2 * d], qkv[:, 2 * d :], ctx, dctx, lse, B, S, H, H, Dh,
+                       dqkv[:, :d], dqkv[:, d : 2 * d], dqkv[:, 2 * d :], key_mask=None, causal=False, scale=att.att_scaling)
         wqkv = bf16_cached(att, "wqkv", [att.w_queries.weight, att.w_keys.weight, att.w_values.weight])
         dh1 = K.dgrad(dqkv, wqkv)
         for i, lin in enumerate((att.w_queries, att.w_keys, att.w_values)):
@@ -169,7 +197,9 @@ def vit_backward(m, saved, dout):
                 _acc(lin.bias, gb[i * d : (i + 1) * d])
         dx = _ln_bwd(blk.ln_1, x, mean1, rsig1, dh1, dx2)
         ops._flush_wgrads(wg)
-    # ---- embedding: pos / cls sums over the batch, patch projection wgrad
+    # ---- embedding: dropout site, pos / cls sums over the batch, patch projection wgrad
+    if p_emb > 0:
+        dx = K.dropout(dx, p_emb, *s_emb)
     gpos = K.colsum(dx.view(B, S * d))  # sum_b dh[b, s, :]
     _acc(m.pos_embedding, gpos)
     _acc(pe.cls_token, gpos[:d].contiguous())
@@ -198,7 +228,10 @@ class ViTTrainFn(torch.autograd.Function):
 
 
 def needs_training_path(model):
-    return torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
+    """Trainable parameters under grad mode, or train-mode dropout (which the forward-only path does not carry)."""
+    if torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters()):
+        return True
+    return model.training and (model.dropout.p > 0 or any(b.dropout.p > 0 or b.att.dropout.p > 0 for b in model.transformer_blocks))
 
 
 def run_train(model, img, output_hidden_states):

@@ -84,15 +84,21 @@ class ViTTransformerBlock(nn.Module):
 
     def run(self, x2d, B, S):
         """x2d fp32 [B*S, d] -> fp32 [B*S, d]."""
-        if self.training and self.dropout.p > 0:
-            raise NotImplementedError("dropout is not implemented on the HIP path; use eval() or drop_rate=0")
+        p = self.dropout.p if self.training else 0.0
         h = self.ln_1.normalize(x2d, BF16)
         ctx = self.att.context(h, B, S)
         wo = bf16_cached(self.att, "wo", [self.att.out_proj.weight])
-        x2 = K.gemm(L.GEMM_NT, ctx, wo, bias=self.att.out_proj.bias.detach(), residual=x2d, out_dtype=F32)
+        if p > 0:  # x + dropout(.) (reference :117, :124): the residual add is fused into the dropout pass
+            from llm_quest_amd import rng
+
+            x2 = K.dropout(K.gemm(L.GEMM_NT, ctx, wo, bias=self.att.out_proj.bias.detach(), out_dtype=F32), p, *rng.draw(), residual=x2d)
+        else:
+            x2 = K.gemm(L.GEMM_NT, ctx, wo, bias=self.att.out_proj.bias.detach(), residual=x2d, out_dtype=F32)
         h = self.ln_2.normalize(x2, BF16)
         f = self.ffn.hidden(h)
         w2 = bf16_cached(self.ffn, "w2", [self.ffn.layers[2].weight])
+        if p > 0:
+            return K.dropout(K.gemm(L.GEMM_NT, f, w2, bias=self.ffn.layers[2].bias.detach(), out_dtype=F32), p, *rng.draw(), residual=x2)
         return K.gemm(L.GEMM_NT, f, w2, bias=self.ffn.layers[2].bias.detach(), residual=x2, out_dtype=F32)
 
     def forward(self, x):

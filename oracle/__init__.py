@@ -20,4 +20,4 @@ writes inputs + expected outputs + gradients to ``tests/golden/*.safetensors``.
 ``tests/test_oracle_golden.py`` checks every oracle function against those.
 """
 
-from . import index_ops, ops, models, qwen3_5, qwen3_5_text  # noqa: F401
+from . import dropout, index_ops, ops, models, qwen3_5, qwen3_5_text  # noqa: F401

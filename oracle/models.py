@@ -48,31 +48,40 @@ def qwen3_forward(sd, cfg, tokens=None, key_mask=None, position_ids=None, inputs
 
 
 # --------------------------------------------------------------------------- ViT encoder
-def vit_attention(sd, pfx, x, n_heads):
-    """ViTMultiHeadAttention.forward (multimodal/vision_transformer/vit_attention.py:43-91)."""
+def vit_attention(sd, pfx, x, n_heads, att_mul=None):
+    """ViTMultiHeadAttention.forward (multimodal/vision_transformer/vit_attention.py:43-91).  ``att_mul`` stands for the
+    reference's ``self.dropout(att_weights)`` (:79) with the mask given: a (b, heads, s, s) tensor of 0 or 1 / (1 - p)."""
     b, s, d = x.shape
     dh = d // n_heads
 
     def proj(name):
         return F.linear(x, sd[pfx + name + ".weight"], sd.get(pfx + name + ".bias")).view(b, s, n_heads, dh).transpose(1, 2)
 
-    ctx = ops.full_attention_core(proj("w_queries"), proj("w_keys"), proj("w_values"))
+    if att_mul is None:
+        ctx = ops.full_attention_core(proj("w_queries"), proj("w_keys"), proj("w_values"))
+    else:
+        q, k, v = proj("w_queries"), proj("w_keys"), proj("w_values")
+        ctx = (torch.softmax((q @ k.mT) * (dh**-0.5), dim=-1) * att_mul) @ v
     ctx = ctx.transpose(1, 2).contiguous().view(b, s, d)
     return F.linear(ctx, sd[pfx + "out_proj.weight"], sd[pfx + "out_proj.bias"])
 
 
-def vit_block(sd, pfx, x, n_heads):
-    """ViTTransformerBlock.forward with drop_rate=0 (vit_transformer_block.py:102-127)."""
+def vit_block(sd, pfx, x, n_heads, drop=None):
+    """ViTTransformerBlock.forward (vit_transformer_block.py:102-127).  ``drop`` = None (drop_rate 0 / eval) or a dict of given
+    dropout multipliers: "att" (b, heads, s, s), "proj" and "ffn" (b, s, d) for the two ``self.dropout`` sites (:117, :124)."""
+    drop = drop or {}
     h = ops.layernorm_sigma_eps(x, sd[pfx + "ln_1.scale"], sd[pfx + "ln_1.shift"])
-    x = vit_attention(sd, pfx + "att.", h, n_heads) + x
+    a = vit_attention(sd, pfx + "att.", h, n_heads, drop.get("att"))
+    x = (a * drop["proj"] if "proj" in drop else a) + x
     h = ops.layernorm_sigma_eps(x, sd[pfx + "ln_2.scale"], sd[pfx + "ln_2.shift"])
     h = F.linear(h, sd[pfx + "ffn.layers.0.weight"], sd[pfx + "ffn.layers.0.bias"])
     h = F.linear(ops.gelu_erf(h), sd[pfx + "ffn.layers.2.weight"], sd[pfx + "ffn.layers.2.bias"])
-    return h + x
+    return (h * drop["ffn"] if "ffn" in drop else h) + x
 
 
-def vit_forward(sd, cfg, img, output_hidden_states=False):
-    """ViTModel.forward in eval / drop_rate=0 (multimodal/vision_transformer/vit_model.py:134-160)."""
+def vit_forward(sd, cfg, img, output_hidden_states=False, drop=None):
+    """ViTModel.forward (multimodal/vision_transformer/vit_model.py:134-160).  ``drop`` = None for eval / drop_rate 0, or
+    {"embed": (b, s, d), "blocks": [per-block dict as in vit_block]} = the train-mode dropout sites with their masks given."""
     x = ops.patch_embed(
         img,
         sd["patch_embedding.conv_proj.weight"],
@@ -81,8 +90,10 @@ def vit_forward(sd, cfg, img, output_hidden_states=False):
         cfg["patch_size"],
     )
     x = x + sd["pos_embedding"]
+    if drop is not None:
+        x = x * drop["embed"]
     for i in range(cfg["n_layers"]):
-        x = vit_block(sd, f"transformer_blocks.{i}.", x, cfg["n_heads"])
+        x = vit_block(sd, f"transformer_blocks.{i}.", x, cfg["n_heads"], None if drop is None else drop["blocks"][i])
     x = ops.layernorm_sigma_eps(x, sd["final_ln.scale"], sd["final_ln.shift"])
     if output_hidden_states:
         return x
