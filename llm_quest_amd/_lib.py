@@ -150,25 +150,46 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def stream():
-    return torch.cuda.current_stream().cuda_stream
+_call_device = None  # device of the tensors checked by the last require_gpu(): the launch that follows runs there
+
+
+def stream(device=None):
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def call(name, *args):
-    """Invoke an entry point on the current HIP stream; raise RuntimeError with the library's message on failure."""
+    """Invoke an entry point on the current HIP stream OF THE DEVICE THE OPERANDS LIVE ON (``require_gpu`` recorded it); raise
+    RuntimeError with the library's message on failure.  Without the guard a model on cuda:1 under a current device of cuda:0
+    would be enqueued on cuda:0's stream with cuda:1's pointers."""
+    global _call_device
     lib = load()
-    rc = getattr(lib, name)(*args, stream())
+    dev, _call_device = _call_device, None
+    if dev is not None and dev.index is not None and dev.index != torch.cuda.current_device():
+        with torch.cuda.device(dev):
+            rc = getattr(lib, name)(*args, stream(dev))
+    else:
+        rc = getattr(lib, name)(*args, stream(dev))
     if rc != 0:
         raise RuntimeError(f"{name} failed (rc={rc}): {lib.mi355_last_error().decode()}")
 
 
 def require_gpu(*tensors):
+    """Every operand must be a HIP tensor, and all of them on ONE device; remembers that device for the ``call`` that follows."""
+    global _call_device
+    dev = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError(
                 "llm_quest_amd ops run only on an MI355X (HIP) device; got a CPU tensor. "
                 "There is no CPU fallback for this path."
             )
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"llm_quest_amd ops: operands live on different devices ({dev} and {t.device})")
+    _call_device = dev
 
 
 def dt_code(dtype):

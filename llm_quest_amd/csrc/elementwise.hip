@@ -175,7 +175,9 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(int64_t tokens, int r
 // ----------------------------------------------------------------------------------------- cross entropy
 // One 256-thread block per row.  Pass 1: online max / sum-exp over V (16-byte loads).  Pass 2 (optional):
 // dlogits = (exp(l - lse) - onehot) * scale, written bf16 (in place allowed).  The row (V*2 bytes ~ 300 KB)
-// is re-read from L2/Infinity Cache in pass 2.
+// is re-read from L2/Infinity Cache in pass 2.  Targets: -100 = ignore_index (zero loss, zero gradient); anything else
+// outside [0, V) is an error -- torch raises a device assert there; here the row's loss is NaN (which poisons the mean:
+// loud, not silent) and its gradient row is zero, and nothing is read out of bounds.
 __global__ __launch_bounds__(256) void ce_rows_kernel(int64_t rows, int64_t V, const bf16_t* __restrict__ logits, int64_t ldl,
                                                       const int64_t* __restrict__ targets, float* __restrict__ loss_rows,
                                                       bf16_t* dlogits, const float* __restrict__ grad_scale) {
@@ -185,8 +187,8 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(int64_t rows, int64_t V, c
         const int64_t tgt = targets[row];
         const bf16_t* lr = logits + row * ldl;
         bf16_t* dr = dlogits ? dlogits + row * ldl : nullptr;
-        if (tgt < 0) {  // ignore_index (-100): zero loss, zero gradient
-            if (threadIdx.x == 0) loss_rows[row] = 0.f;
+        if (tgt < 0 || tgt >= V) {  // ignore_index (-100): zero loss, zero gradient; any other value out of range: NaN loss
+            if (threadIdx.x == 0) loss_rows[row] = tgt == -100 ? 0.f : __builtin_nanf("");
             if (dr) {
                 const int64_t nv = V >> 3;
                 for (int64_t i = threadIdx.x; i < nv; i += 256) *reinterpret_cast<u32x4*>(dr + i * 8) = (u32x4){0, 0, 0, 0};
@@ -194,6 +196,9 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(int64_t rows, int64_t V, c
             }
             continue;
         }
+        // the target logit is read BEFORE the barriers below: in place (dr == lr) the other waves start overwriting the row with
+        // the gradient as soon as they pass the last barrier
+        const float tgt_logit = threadIdx.x == 0 ? bf2f(lr[tgt]) : 0.f;
         float m = -INFINITY, s = 0.f;
         const int64_t nv = V >> 3;
         for (int64_t i = threadIdx.x; i < nv; i += 256) {
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(int64_t rows, int64_t V, c
 #pragma unroll
         for (int wv = 0; wv < 4; ++wv) bs += red_m[wv] == -INFINITY ? 0.f : red_s[wv] * __expf(red_m[wv] - bm);
         const float lse = bm + __logf(bs);
-        if (threadIdx.x == 0) loss_rows[row] = lse - bf2f(lr[tgt]);
+        if (threadIdx.x == 0) loss_rows[row] = lse - tgt_logit;
         if (dr) {
             const float sc = *grad_scale;
             for (int64_t i = threadIdx.x; i < nv; i += 256) {
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(256) void ce_finalize_kernel(int64_t rows, const fl
     __shared__ float rs[4], rc[4];
     float s = 0.f, c = 0.f;
     for (int64_t i = threadIdx.x; i < rows; i += 256) {
-        if (targets[i] >= 0) {
+        if (targets[i] != -100) {  // an out-of-range target carries a NaN row loss: the mean shows it
             s += loss_rows[i];
             c += 1.f;
         }

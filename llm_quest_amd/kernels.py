@@ -29,10 +29,12 @@ WS_BYTES = 512 << 20  # split-K scratch per device (fp32 slabs of the largest we
 
 
 def _workspace(device):
-    ws = _WS.get(device)
+    """Split-K scratch of the (device, stream) the launch goes to: two streams issuing split-K GEMMs never share slabs."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WS.get(key)
     if ws is None:
         ws = torch.empty(WS_BYTES // 4, dtype=F32, device=device)
-        _WS[device] = ws
+        _WS[key] = ws
     return ws
 
 

@@ -183,32 +183,45 @@ def block_backward(blk, saved, dx3, rt):
 
 
 class Qwen3BlockFn(torch.autograd.Function):
+    """``keep``: True = keep the block's activations for the backward; "recompute" = gradient checkpointing (the reference's
+    ``torch.utils.checkpoint`` around every block, qwen3_model.py:72-80): only the block INPUT stays alive between forward and
+    backward, and the backward first re-runs the forward kernels (bit-identical: the kernels are deterministic) to rebuild what
+    it needs; False = inference."""
+
     @staticmethod
     def forward(ctx, x, blk, rt, keep, *params):
         B, S, d = x.shape
-        y, saved = block_forward(blk, x.reshape(B * S, d), rt, keep)
+        x2 = x.reshape(B * S, d)
+        y, saved = block_forward(blk, x2, rt, keep is True)
         ctx.blk, ctx.rt, ctx.saved, ctx.shape = blk, rt, saved, (B, S, d)
+        ctx.x_in = x2 if keep == "recompute" else None
         return y.view(B, S, d)
 
     @staticmethod
     def backward(ctx, dy):
         B, S, d = ctx.shape
-        if ctx.saved is None:
+        saved = ctx.saved
+        if saved is None and ctx.x_in is not None:
+            _, saved = block_forward(ctx.blk, ctx.x_in, ctx.rt, True)
+            ctx.x_in = None
+        if saved is None:
             raise RuntimeError("Qwen3BlockFn: backward through a forward that ran without grad mode")
         dy2 = dy.reshape(B * S, d)
         dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
-        dx = block_backward(ctx.blk, ctx.saved, dy2, ctx.rt)
+        dx = block_backward(ctx.blk, saved, dy2, ctx.rt)
         ctx.saved = None
         return (dx.view(B, S, d), None, None, None) + (None,) * len(ctx.blk._param_list)
 
 
-def run_block(blk, x, rt):
+def run_block(blk, x, rt, recompute=False):
     if not hasattr(blk, "_param_list"):
         object.__setattr__(blk, "_param_list", list(blk.parameters()))
     L.require_gpu(x)
     if x.dtype != BF16:
         raise TypeError(f"Qwen3 block expects bf16 activations, got {x.dtype}")
     keep = torch.is_grad_enabled()
+    if keep and recompute:
+        keep = "recompute"
     return Qwen3BlockFn.apply(x, blk, rt, keep, *blk._param_list)
 
 

@@ -9,7 +9,6 @@ Extensions over the reference signature (both needed by BASELINE config 4, see S
 
 import torch
 import torch.nn as nn
-from torch.utils.checkpoint import checkpoint
 
 from llm_quest_amd import _lib as L
 from llm_quest_amd import ops
@@ -95,8 +94,8 @@ class Qwen3Model(nn.Module):
         rt = ops.make_runtime(B, S, x.device, self.cos, self.sin, attn_mask, position_ids)
         use_ckpt = self.gradient_checkpointing and self.training and torch.is_grad_enabled()
         for blk in self.trf_blocks:
-            if use_ckpt:
-                x = checkpoint(blk, x, self.mask, self.cos, self.sin, attn_mask, None, position_ids, rt, use_reentrant=False)
+            if use_ckpt:  # activation recomputation inside the block's own autograd node (ops.Qwen3BlockFn)
+                x = ops.run_block(blk, x, rt, recompute=True)
             else:
                 x = blk(x, self.mask, self.cos, self.sin, attn_mask, None, position_ids, _runtime=rt)
         return self.final_norm(x)

@@ -272,6 +272,20 @@ def gen_vlm(out):
     ad2 = ViTAdapter(64, 128, adapter_type="simple", dtype=torch.bfloat16)
     t["ad_simple.weight"] = ad2.adapter.weight
     t["ad_simple.out"] = ad2(h.to(torch.bfloat16))
+    # fp32 twin of the whole step (the same bf16 weights upcast, the same inputs): what the bf16 step's gradients are noise around
+    llm32 = Qwen3Model(dict(TINY_QWEN, dtype=torch.float32)).train()
+    llm32.load_state_dict({k: (v.float() if v.is_floating_point() else v) for k, v in llm.state_dict().items()})
+    ad32 = ViTAdapter(64, 128, adapter_type="ffn", dtype=torch.float32).train()
+    ad32.load_state_dict({k: v.float() for k, v in ad.state_dict().items()})
+    x32 = torch.cat([ad32(h), llm32.emb_dict(ids)], dim=1)
+    for blk in llm32.trf_blocks:
+        x32 = blk(x32, llm32.mask, llm32.cos, llm32.sin, cm, None, None)
+    logits32 = llm32.out_head(llm32.final_norm(x32))
+    loss32 = vlm_loss(logits32, ids, tm, nv)
+    loss32.backward()
+    t["twin.logits"], t["twin.loss"] = logits32, loss32
+    t.update(_grads(llm32, "twin.grad.llm."))
+    t.update(_grads(ad32, "twin.grad.ad."))
     _save(os.path.join(out, "vlm_tiny.safetensors"), t, "composed ViT+adapter+Qwen3 early-fusion step (config 4 harness)")
 
 

@@ -188,3 +188,154 @@ def test_full_size_step_loss_at_init_and_determinism():
     assert abs(float(l1) - math.log(V)) < 0.05
     assert torch.isfinite(g1.float()).all() and float(g1.float().norm()) > 0
     assert torch.equal(l1, l2) and torch.equal(g1, g2) and torch.equal(a1, a2)
+
+
+def test_full_size_step_matches_the_cpu_oracle():
+    """BASELINE config 4 at FULL model size against the CPU oracle itself (2 samples, all 28 layers, S = 709, V = 151 936): the oracle --
+    pinned to the reference by the fixtures -- runs the same weights and inputs twice, in bf16 (the reference's arithmetic) and in fp32
+    (the twin).  Loss: within 1e-3 relative of the fp32-evaluated loss.  Gradients of the first and last block's query projection, of a
+    down projection and of the adapter: within 1.5x the oracle's own bf16-vs-fp32 distance (the 1.5x rule).  A deterministic but wrong
+    kernel at a shape the tiny fixtures never reach (16 heads x 28 layers, N = 151 936) cannot pass this."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import bench
+    from llm_quest_amd.multimodal.vlm_engine import vlm_step_loss
+    from oracle import models
+
+    torch.set_num_threads(min(16, bench.usable_cores()))
+    dev = torch.device("cuda", 0)
+    vit, vit_cfg, ad, llm, llm_cfg = bench.build_models(dev)
+    img, ids, mask = bench.synthetic_batch(2, "cpu", seed=11, ragged=True)
+    loss = vlm_step_loss(vit, llm, ad, img.to(dev), ids.to(dev), mask.to(dev), hf_vit_model=False)
+    loss.backward()
+    picks = {"llm": ["trf_blocks.0.att.w_queries.weight", "trf_blocks.27.att.w_queries.weight", "trf_blocks.13.ffn.lin2.weight", "final_norm.weight"],
+             "ad": ["adapter.0.weight", "adapter.3.weight"]}
+    mine = {}
+    for key, mod in (("llm", llm), ("ad", ad)):
+        named = dict(mod.named_parameters())
+        for n in picks[key]:
+            mine[key + "." + n] = named[n].grad.float().cpu()
+    vit_sd = {k: v.detach().cpu() for k, v in vit.state_dict().items()}
+    skip = ("mask", "cos", "sin", "out_head.weight")
+
+    def oracle_run(dtype):
+        ad_sd = {k: v.detach().cpu().to(dtype).requires_grad_(True) for k, v in ad.state_dict().items()}
+        llm_sd = {k: v.detach().cpu().to(dtype).requires_grad_(True) for k, v in llm.state_dict().items() if k not in skip}
+        llm_sd["out_head.weight"] = llm_sd["emb_dict.weight"]
+        _, logits, _ = models.vlm_forward_loss(vit_sd, vit_cfg, ad_sd, llm_sd, dict(llm_cfg, dtype=dtype), img, ids, mask)
+        nv = 197
+        l32 = torch.nn.functional.cross_entropy(logits.float()[:, nv - 1 : -1].flatten(0, 1), ids.masked_fill(~mask, -100).flatten(), ignore_index=-100)
+        l32.backward()
+        grads = {"llm." + n: llm_sd[n].grad.float() for n in picks["llm"]}
+        grads.update({"ad." + n: ad_sd[n].grad.float() for n in picks["ad"]})
+        return float(l32), grads
+
+    l_bf16, g_bf16 = oracle_run(BF16)
+    l_fp32, g_fp32 = oracle_run(F32)
+    assert abs(float(loss) - l_fp32) / l_fp32 < 1e-3, (float(loss), l_fp32, l_bf16)
+    for name, twin in g_fp32.items():
+        floor = float((g_bf16[name].double() - twin.double()).norm() / twin.double().norm())
+        err = float((mine[name].double() - twin.double()).norm() / twin.double().norm())
+        assert err <= 1.5 * floor + 2e-3, f"{name}: vs fp32 oracle {err:.3e}, bf16 oracle floor {floor:.3e}"
+
+
+def test_baseline_size_properties_config2_vit_base():
+    """BASELINE configs[1]: ViT-Base/16 224x224 fwd+bwd at B = 64 (full size): loss ~ ln(100) at init, finite gradients, bit-identical
+    repeat (no atomics anywhere on this path)."""
+    import math
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from llm_quest_amd.config import VIT_BASE_CONFIG
+    from llm_quest_amd.engine import _cross_entropy
+    from llm_quest_amd.multimodal.vision_transformer.vit_model import ViTModel
+
+    torch.manual_seed(0)
+    with torch.device("cuda"):
+        m = ViTModel(dict(VIT_BASE_CONFIG, drop_rate=0.0)).train()
+    img = torch.randn(64, 3, 224, 224, device="cuda")
+    y = torch.randint(0, VIT_BASE_CONFIG["num_classes"], (64,), device="cuda")
+
+    def step():
+        m.zero_grad(set_to_none=True)
+        loss = _cross_entropy(m(img), y)
+        loss.backward()
+        return loss.detach().float().clone(), m.transformer_blocks[5].att.w_keys.weight.grad.clone(), m.patch_embedding.conv_proj.weight.grad.clone()
+
+    l1, a1, c1 = step()
+    l2, a2, c2 = step()
+    assert abs(float(l1) - math.log(VIT_BASE_CONFIG["num_classes"])) < 1.0
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+    assert torch.equal(l1, l2) and torch.equal(a1, a2) and torch.equal(c1, c2)
+
+
+def test_baseline_size_properties_config3_qwen3_text_s1024():
+    """BASELINE configs[2]: Qwen3-0.6B text-only at S = 1024 (B = 8): loss ~ ln V at init, finite gradients, bit-identical repeat, and a
+    change to the LAST token changes no earlier row of the final hidden states (causality at full depth and length)."""
+    import math
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from llm_quest_amd.config import qwen3_config_creator
+    from llm_quest_amd.qwen.qwen3.qwen3_model import Qwen3Model
+
+    torch.manual_seed(0)
+    with torch.device("cuda"):
+        m = Qwen3Model(dict(qwen3_config_creator("0.6B"), context_length=1024)).train()
+    ids = torch.randint(0, V, (8, 1024), device="cuda")
+
+    def step():
+        m.zero_grad(set_to_none=True)
+        h = m.forward_hidden(ids)
+        loss = m.lm_loss(h.reshape(-1, h.shape[-1]), torch.roll(ids, -1, 1).reshape(-1))
+        loss.backward()
+        return loss.detach().clone(), m.trf_blocks[27].att.w_values.weight.grad.clone(), h.detach()
+
+    l1, g1, h1 = step()
+    l2, g2, _ = step()
+    assert abs(float(l1) - math.log(V)) < 0.05 and torch.equal(l1, l2) and torch.equal(g1, g2)
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad.float()).all()) for p in m.parameters())
+    ids2 = ids.clone()
+    ids2[:, -1] = (ids2[:, -1] + 1) % V
+    with torch.no_grad():
+        h2 = m.forward_hidden(ids2)
+    assert torch.equal(h2[:, :-1], h1[:, :-1]) and not torch.equal(h2[:, -1], h1[:, -1])
+
+
+def test_baseline_size_properties_config5_qwen35_vlm():
+    """BASELINE configs[4]: Qwen3.5-style VLM, 8 frames of 224x224 + 512 text tokens (S = 708), B = 2 at full model size: loss ~ ln V at
+    init, finite gradients on every parameter, bit-identical repeat of loss and gradients."""
+    import math
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from llm_quest_amd.config import QWEN3_5_08B_CONFIG
+    from llm_quest_amd.qwen.qwen3_5.qwen3_5_vlm_model import Qwen3_5VLM, fuse_vision_embeddings
+
+    cfg = dict(QWEN3_5_08B_CONFIG, img_width=224, img_height=224, context_length=1024)
+    torch.manual_seed(123)
+    with torch.device("cuda"):
+        vlm = Qwen3_5VLM(cfg).train()
+    n_img = (8 // 2) * (14 // 2) * (14 // 2)
+    ids = torch.randint(0, 248_000, (2, 512 + n_img), device="cuda")
+    ids[:, 100 : 100 + n_img] = cfg["image_token_id"]
+    pix = torch.randn(2, 3, 8, 224, 224, device="cuda")
+    tgt = torch.roll(ids, -1, 1)
+    lm = vlm.language_model
+
+    def step():
+        vlm.zero_grad(set_to_none=True)
+        mask = ids == cfg["image_token_id"]
+        emb = fuse_vision_embeddings(lm.emb_dict(ids), mask, vlm.vision_model(pix))
+        pos = vlm.compute_3d_position_ids(ids, vlm.get_feeds_3d_shape(pix), image_mask=mask)
+        h = lm.forward_hidden(inputs_embs=emb, position_ids=pos)
+        loss = lm.lm_loss(h.reshape(-1, h.shape[-1]), tgt.reshape(-1))
+        loss.backward()
+        return loss.detach().clone(), lm.trf_blocks[0].att.w_qkv.weight.grad.clone(), vlm.vision_model.blocks[0].att.qkv.weight.grad.clone()
+
+    l1, g1, v1 = step()
+    l2, g2, v2 = step()
+    assert abs(float(l1) - math.log(cfg["vocab_size"])) < 0.1, float(l1)
+    missing = [n for n, p in vlm.named_parameters() if p.requires_grad and (p.grad is None or not bool(torch.isfinite(p.grad.float()).all()))]
+    assert not missing, missing[:5]
+    assert torch.equal(l1, l2) and torch.equal(g1, g2) and torch.equal(v1, v2)

@@ -26,17 +26,19 @@ def timed(fn, steps):
 
 
 torch.manual_seed(1)
-with torch.device(dev):
-    vit = ViTModel(dict(VIT_BASE_CONFIG, drop_rate=0.0)).train()
 img = torch.randn(args.vit_batch, 3, 224, 224, device=dev)
 y = torch.randint(0, VIT_BASE_CONFIG.get("num_classes", 100), (args.vit_batch,), device=dev)
-def vit_step():
-    vit.zero_grad(set_to_none=True)
-    torch.nn.functional.cross_entropy(vit(img).float(), y).backward()
-t = timed(vit_step, args.steps)
-print(f"configs[1] ViT-B/16 fwd+bwd  B={args.vit_batch}: {t*1e3:7.1f} ms/step  {args.vit_batch/t:9.0f} img/s  {105.4e9*args.vit_batch/t/1e12:6.1f} TFLOP/s algorithmic (105.4 GF/img)")
-del vit, img
-torch.cuda.empty_cache()
+for drop in (0.0, VIT_BASE_CONFIG["drop_rate"]):  # config 2 "with drop_rate=0.1 (as config) and 0.0 (parity)"
+    with torch.device(dev):
+        vit = ViTModel(dict(VIT_BASE_CONFIG, drop_rate=drop)).train()
+    def vit_step():
+        vit.zero_grad(set_to_none=True)
+        torch.nn.functional.cross_entropy(vit(img).float(), y).backward()
+    t = timed(vit_step, args.steps)
+    print(f"configs[1] ViT-B/16 fwd+bwd  B={args.vit_batch} drop_rate={drop}: {t*1e3:7.1f} ms/step  {args.vit_batch/t:9.0f} img/s  {105.4e9*args.vit_batch/t/1e12:6.1f} TFLOP/s algorithmic (105.4 GF/img)")
+    del vit
+    torch.cuda.empty_cache()
+del img
 
 with torch.device(dev):
     llm = Qwen3Model(dict(qwen3_config_creator("0.6B"), context_length=1024)).train()
