@@ -91,10 +91,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_rowreg_kernel(int64_t rows, i
                                                                  const bf16_t* __restrict__ w, const float* __restrict__ rstd,
                                                                  const bf16_t* __restrict__ dy, const bf16_t* __restrict__ dres,
                                                                  bf16_t* __restrict__ dx, float* __restrict__ dw_partial) {
-    __shared__ float dw_lds[512 * VPL];
+    __shared__ float dw_lds[4][512 * VPL];  // one region per wave: the block's sum is taken in a FIXED order (bit-reproducible)
     const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < width; i += 256) dw_lds[i] = 0.f;
-    __syncthreads();
     float wf[VPL][8], dwacc[VPL][8];
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
@@ -130,9 +128,10 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_rowreg_kernel(int64_t rows, i
 #pragma unroll
     for (int i = 0; i < VPL; ++i)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) atomicAdd(&dw_lds[(i * 64 + lane) * 8 + e], dwacc[i][e]);
+        for (int e = 0; e < 8; ++e) dw_lds[wv_id][(i * 64 + lane) * 8 + e] = dwacc[i][e];
     __syncthreads();
-    for (int i = threadIdx.x; i < width; i += 256) dw_partial[(int64_t)blockIdx.x * width + i] = dw_lds[i];
+    for (int i = threadIdx.x; i < width; i += 256)
+        dw_partial[(int64_t)blockIdx.x * width + i] = ((dw_lds[0][i] + dw_lds[1][i]) + dw_lds[2][i]) + dw_lds[3][i];
 }
 
 // generic width (multiple of 8): three sweeps over the row
@@ -140,10 +139,11 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(int64_t rows, int widt
                                                           const bf16_t* __restrict__ w, const float* __restrict__ rstd,
                                                           const bf16_t* __restrict__ dy, const bf16_t* __restrict__ dres,
                                                           bf16_t* __restrict__ dx, float* __restrict__ dw_partial) {
-    extern __shared__ __attribute__((aligned(16))) float dw_lds_dyn[];  // [width]
+    extern __shared__ __attribute__((aligned(16))) float dw_lds_dyn[];  // [4][width]: one region per wave, summed in a fixed order
     const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
     const int nvec = width >> 3;
-    for (int i = threadIdx.x; i < width; i += 256) dw_lds_dyn[i] = 0.f;
+    float* dw_mine = dw_lds_dyn + wv_id * width;  // element i*8+e is touched by lane i % 64 of this wave only: plain adds
+    for (int i = threadIdx.x; i < 4 * width; i += 256) dw_lds_dyn[i] = 0.f;
     __syncthreads();
     for (int64_t row = (int64_t)blockIdx.x * 4 + wv_id; row < rows; row += (int64_t)gridDim.x * 4) {
         const float r = rstd[row];
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(int64_t rows, int widt
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 dot += dyv[e] * wf[e] * xv[e];
-                atomicAdd(&dw_lds_dyn[i * 8 + e], dyv[e] * xv[e] * r);
+                dw_mine[i * 8 + e] += dyv[e] * xv[e] * r;
             }
         }
         dot = wave_sum(dot) * r * r / (float)width;
@@ -173,7 +173,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(int64_t rows, int widt
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < width; i += 256) dw_partial[(int64_t)blockIdx.x * width + i] = dw_lds_dyn[i];
+    for (int i = threadIdx.x; i < width; i += 256)
+        dw_partial[(int64_t)blockIdx.x * width + i] = ((dw_lds_dyn[i] + dw_lds_dyn[width + i]) + dw_lds_dyn[2 * width + i]) + dw_lds_dyn[3 * width + i];
 }
 
 // out[n] (+)= sum_p partial[p][n]: 64 columns per block, 16 waves split the parts (the loads are the latency: keep many in flight)
@@ -309,14 +310,12 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(int64_t tokens, in
                                                               const bf16_t* __restrict__ dq, const bf16_t* __restrict__ dk,
                                                               bf16_t* __restrict__ dqkv, float* __restrict__ dw_partial) {
     using G = QkGeom<D>;
-    __shared__ float dw_lds[2 * D];
+    __shared__ float dw_lds[4 * G::HPW][2 * D];  // one region per (wave, head slot): summed in a fixed order (bit-reproducible)
     const int lane = threadIdx.x & 63;
     const int sub = lane / G::LPH, i = (lane % G::LPH) * QV;
     const int H = Hq + Hkv;
     const int groups = (H + G::HPW - 1) / G::HPW;
     const int64_t ld = (int64_t)(Hq + 2 * Hkv) * D;
-    for (int j = threadIdx.x; j < 2 * D; j += 256) dw_lds[j] = 0.f;
-    __syncthreads();
     float dwq1[QV] = {0, 0, 0, 0, 0, 0, 0, 0}, dwq2[QV] = {0, 0, 0, 0, 0, 0, 0, 0}, dwk1[QV] = {0, 0, 0, 0, 0, 0, 0, 0}, dwk2[QV] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool norm = qw != nullptr;
     float wq1[QV] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, wq2[QV] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, wk1[QV] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, wk2[QV] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
@@ -379,15 +378,21 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(int64_t tokens, in
             }
         }
     }
+    float* mine = dw_lds[(threadIdx.x >> 6) * G::HPW + sub];
 #pragma unroll
     for (int e = 0; e < QV; ++e) {
-        atomicAdd(&dw_lds[i + e], dwq1[e]);
-        atomicAdd(&dw_lds[G::HALF + i + e], dwq2[e]);
-        atomicAdd(&dw_lds[D + i + e], dwk1[e]);
-        atomicAdd(&dw_lds[D + G::HALF + i + e], dwk2[e]);
+        mine[i + e] = dwq1[e];
+        mine[G::HALF + i + e] = dwq2[e];
+        mine[D + i + e] = dwk1[e];
+        mine[D + G::HALF + i + e] = dwk2[e];
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < 2 * D; j += 256) dw_partial[(int64_t)blockIdx.x * 2 * D + j] = dw_lds[j];
+    for (int j = threadIdx.x; j < 2 * D; j += 256) {
+        float acc = 0.f;
+#pragma unroll
+        for (int rgn = 0; rgn < 4 * G::HPW; ++rgn) acc += dw_lds[rgn][j];
+        dw_partial[(int64_t)blockIdx.x * 2 * D + j] = acc;
+    }
 }
 
 // ------------------------------------------------------------------------ ViT LayerNorm (sigma + eps)
@@ -447,9 +452,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int wi
                                                             const float* __restrict__ rsig, const void* __restrict__ dy,
                                                             const float* __restrict__ dres, float* __restrict__ dx,
                                                             float* __restrict__ dparam_partial, float eps, int mode) {
-    extern __shared__ __attribute__((aligned(16))) float dp_lds[];  // [2*width]
+    extern __shared__ __attribute__((aligned(16))) float dp_lds[];  // [4][2*width]: one region per wave, summed in a fixed order
     const int lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < 2 * width; i += 256) dp_lds[i] = 0.f;
+    float* dp_mine = dp_lds + (threadIdx.x >> 6) * 2 * width;  // column c belongs to lane c % 64 of this wave only: plain adds
+    for (int i = threadIdx.x; i < 8 * width; i += 256) dp_lds[i] = 0.f;
     __syncthreads();
     auto load_dy = [&](int64_t row, int c) -> float {
         if (DY_DT == MI355_DT_BF16) return bf2f(reinterpret_cast<const bf16_t*>(dy)[row * width + c]);
@@ -464,8 +470,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int wi
             const float dn = g * scale[c];
             s1 += dn;
             s2 += dn * n;
-            atomicAdd(&dp_lds[c], g * n);
-            atomicAdd(&dp_lds[width + c], g);
+            dp_mine[c] += g * n;
+            dp_mine[width + c] += g;
         }
         s1 = wave_sum(s1) / (float)width;
         s2 = wave_sum(s2) / (float)width;
@@ -477,7 +483,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int wi
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * width; i += 256) dparam_partial[(int64_t)blockIdx.x * 2 * width + i] = dp_lds[i];
+    for (int i = threadIdx.x; i < 2 * width; i += 256)
+        dparam_partial[(int64_t)blockIdx.x * 2 * width + i] = ((dp_lds[i] + dp_lds[2 * width + i]) + dp_lds[4 * width + i]) + dp_lds[6 * width + i];
 }
 
 // Same, for widths that are multiples of 256 (ViT 768): the row lives in registers (VPL float4 per lane), the parameter
@@ -488,10 +495,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rowreg_kernel(int64_t rows,
                                                                    const float* __restrict__ rsig, const void* __restrict__ dy,
                                                                    const float* __restrict__ dres, float* __restrict__ dx,
                                                                    float* __restrict__ dparam_partial, float eps, int mode) {
-    extern __shared__ __attribute__((aligned(16))) float dp_lds[];  // [2*width]
+    extern __shared__ __attribute__((aligned(16))) float dp_lds[];  // [4][2*width]: one region per wave, summed in a fixed order
     const int lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < 2 * width; i += 256) dp_lds[i] = 0.f;
-    __syncthreads();
+    float* dp_mine = dp_lds + (threadIdx.x >> 6) * 2 * width;
     f32x4 sc[VPL], dsc[VPL], dsh[VPL];
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
@@ -541,11 +547,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rowreg_kernel(int64_t rows,
     for (int v = 0; v < VPL; ++v)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            atomicAdd(&dp_lds[(v * 64 + lane) * 4 + e], dsc[v][e]);
-            atomicAdd(&dp_lds[width + (v * 64 + lane) * 4 + e], dsh[v][e]);
+            dp_mine[(v * 64 + lane) * 4 + e] = dsc[v][e];
+            dp_mine[width + (v * 64 + lane) * 4 + e] = dsh[v][e];
         }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * width; i += 256) dparam_partial[(int64_t)blockIdx.x * 2 * width + i] = dp_lds[i];
+    for (int i = threadIdx.x; i < 2 * width; i += 256)
+        dparam_partial[(int64_t)blockIdx.x * 2 * width + i] = ((dp_lds[i] + dp_lds[2 * width + i]) + dp_lds[4 * width + i]) + dp_lds[6 * width + i];
 }
 
 inline int row_grid(int64_t rows) {
@@ -571,7 +578,7 @@ extern "C" int mi355_rmsnorm_fwd(int64_t rows, int width, const void* x, const v
 
 extern "C" int mi355_rmsnorm_bwd(int64_t rows, int width, const void* x, const void* w, const float* rstd, const void* dy,
                                  const void* dres, void* dx, float* dw_partial, int parts, void* stream) {
-    MI355_REQUIRE(rows > 0 && (width & 7) == 0 && width <= 8192, "mi355_rmsnorm_bwd: bad width %d", width);
+    MI355_REQUIRE(rows > 0 && (width & 7) == 0 && width <= 4096, "mi355_rmsnorm_bwd: bad width %d (multiple of 8, <= 4096: four per-wave LDS regions of width floats)", width);
     MI355_REQUIRE(x && w && rstd && dy && dx && dw_partial && parts > 0, "mi355_rmsnorm_bwd: null pointer / parts");
     hipStream_t s = (hipStream_t)stream;
     if (width == 1024)
@@ -581,7 +588,7 @@ extern "C" int mi355_rmsnorm_bwd(int64_t rows, int width, const void* x, const v
         hipLaunchKernelGGL(rmsnorm_bwd_rowreg_kernel<1>, dim3(parts), dim3(256), 0, s, rows, width, (const bf16_t*)x,
                            (const bf16_t*)w, rstd, (const bf16_t*)dy, (const bf16_t*)dres, (bf16_t*)dx, dw_partial);
     else
-        hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(parts), dim3(256), width * sizeof(float), s, rows, width, (const bf16_t*)x,
+        hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(parts), dim3(256), 4 * width * sizeof(float), s, rows, width, (const bf16_t*)x,
                            (const bf16_t*)w, rstd, (const bf16_t*)dy, (const bf16_t*)dres, (bf16_t*)dx, dw_partial);
     MI355_LAUNCH_CHECK("mi355_rmsnorm_bwd");
     return 0;
@@ -644,11 +651,11 @@ extern "C" int mi355_layernorm_fwd(int64_t rows, int width, const float* x, cons
 extern "C" int mi355_layernorm_bwd(int64_t rows, int width, const float* x, const float* scale, const float* mean, const float* rsig,
                                    const void* dy, int dy_dtype, const float* dres, float* dx, float* dparam_partial, int parts,
                                    float eps, int mode, void* stream) {
-    MI355_REQUIRE(rows > 0 && width > 0 && width <= 8192 && parts > 0, "mi355_layernorm_bwd: bad shape");
+    MI355_REQUIRE(rows > 0 && width > 0 && width <= 2048 && parts > 0, "mi355_layernorm_bwd: bad shape (width %d: 1 .. 2048, four per-wave LDS regions of 2 * width floats)", width);
     MI355_REQUIRE(x && scale && mean && rsig && dy && dx && dparam_partial, "mi355_layernorm_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
 #define LN_BWD(KERNEL) \
-    hipLaunchKernelGGL(KERNEL, dim3(parts), dim3(256), 2 * width * sizeof(float), s, rows, width, x, scale, mean, rsig, dy, dres, dx, dparam_partial, eps, mode)
+    hipLaunchKernelGGL(KERNEL, dim3(parts), dim3(256), 8 * width * sizeof(float), s, rows, width, x, scale, mean, rsig, dy, dres, dx, dparam_partial, eps, mode)
     const bool aligned = (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)dres | (uintptr_t)scale) & 15) == 0;
     if (width == 768 && aligned) {
         if (dy_dtype == MI355_DT_BF16) LN_BWD((layernorm_bwd_rowreg_kernel<MI355_DT_BF16, 3>));
