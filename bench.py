@@ -211,6 +211,7 @@ def main():
     ap.add_argument("--cpu-baseline", choices=["auto", "off"], default="auto")
     ap.add_argument("--ragged", action="store_true", help="text lengths ~ U[256, 512] (padding mask active in attention and loss) instead of all-ones masks")
     ap.add_argument("--optimizer", choices=["on", "off"], default="on", help="also time the same steps with clip + AdamW (reported beside the fwd+bwd metric)")
+    ap.add_argument("--vision-ahead", choices=["on", "off"], default="on", help="frozen ViT of the next step's batch on a second stream (vlm_engine.VisionAhead), as the training loop runs it")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -222,7 +223,7 @@ def main():
         raise SystemExit(launch_ranks(args.gpus))
 
     from llm_quest_amd import _lib, ddp
-    from llm_quest_amd.multimodal.vlm_engine import vlm_step_loss
+    from llm_quest_amd.multimodal.vlm_engine import VisionAhead, vlm_step_loss
 
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:  # before any rendezvous: a mismatched launch must fail at once, not wait for peers
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: start one rank per GPU (python bench.py --gpus N does it itself)")
@@ -239,9 +240,22 @@ def main():
     img, ids, mask = synthetic_batch(args.batch, device, seed=123 + rank, ragged=args.ragged)
 
     n_targets = mask.sum()  # this rank's target tokens: ragged shards weight their mean loss by it (ddp.GradSync.loss_weight)
+    # The frozen tower runs one batch ahead on a second stream, exactly as vlm_training_loop_simple runs it: every step takes the hidden
+    # states submitted during the previous step and submits the next batch's (here the same synthetic images) -- one ViT forward per
+    # step, inside the timed region, concurrent with the decoder instead of in front of it.
+    ahead = VisionAhead(vit) if args.vision_ahead == "on" else None
+    if ahead is not None:
+        ahead.submit(img)
+
+    def vision():
+        if ahead is None:
+            return None
+        h = ahead.take(img)
+        ahead.submit(img)
+        return h
 
     def step():
-        loss = vlm_step_loss(vit, llm, ad, img, ids, mask, hf_vit_model=False)
+        loss = vlm_step_loss(vit, llm, ad, img, ids, mask, hf_vit_model=False, vit_hidden=vision())
         sync.begin_step()
         (loss * sync.loss_weight(n_targets) if (args.ragged and world > 1) else loss).backward()
         sync.finish_step()
@@ -283,7 +297,7 @@ def main():
         opt.attach(llm, ad)
 
         def full_step():
-            loss_ = vlm_step_loss(vit, llm, ad, img, ids, mask, hf_vit_model=False)
+            loss_ = vlm_step_loss(vit, llm, ad, img, ids, mask, hf_vit_model=False, vit_hidden=vision())
             sync.begin_step()
             (loss_ * sync.loss_weight(n_targets) if (args.ragged and world > 1) else loss_).backward()
             sync.finish_step()
@@ -320,6 +334,7 @@ def main():
                             "224x224 image + 512 text tokens (S=709), fwd+loss+bwd, no optimizer step",
                 "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}", "text_mask": "ragged U[256,512]" if args.ragged else "all ones",
                 "units_per_sample": UNITS_PER_SAMPLE,
+                "vision_tower": "frozen ViT forward of the NEXT step's batch on a second HIP stream, one per timed step (vlm_engine.VisionAhead)" if ahead is not None else "in front of the decoder, same stream",
             },
             "roofline": {
                 "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

@@ -95,10 +95,55 @@ class _RowsFn(torch.autograd.Function):
         return full, None, None
 
 
-def vlm_step_loss(vit_model, vlm_model, adapter, images, input_ids, text_attention_mask, hf_vit_model=False):
-    """Forward of one early-fusion step -> scalar loss (fp32 on the native path).  Used by the train and eval loops."""
-    with torch.no_grad():
-        vit_hidden = _vision_states(vit_model, images, hf_vit_model)
+class VisionAhead:
+    """The FROZEN vision tower of the next batch on a second HIP stream, under the current batch's LLM forward / backward.
+
+    The tower is frozen in this path (``requires_grad=False``, ``eval()``; reference vlm_engine.py:80-83), so its output for batch
+    i+1 depends on nothing step i computes: ``submit(images)`` enqueues its forward on a side stream, ``take(images)`` hands the
+    hidden states to the main stream (event hand-off, one tensor crosses).  The tower's launches are small (M = 197 tokens per image;
+    most of its GEMM grids cover half the chip) and leave CUs idle when they run alone; next to the decoder's kernels they fill the
+    tails of those grids instead.  Same work per step, same results (the kernels are deterministic); only WHEN the tower runs changes.
+    """
+
+    def __init__(self, vit_model, hf_vit_model=False):
+        self.vit, self.hf = vit_model, hf_vit_model
+        self.stream = None
+        self.queue = []  # [(images, hidden, done event)], oldest first
+
+    def submit(self, images):
+        if any(p.requires_grad for p in self.vit.parameters()):
+            raise RuntimeError("VisionAhead: the vision tower must be frozen (its forward runs outside autograd, one batch early)")
+        dev = images.device
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=dev)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))  # whatever produced `images` on the main stream
+        with torch.cuda.stream(self.stream), torch.no_grad():
+            self.stream.wait_event(ready)
+            hidden = _vision_states(self.vit, images, self.hf)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        images.record_stream(self.stream)
+        self.queue.append((images, hidden, done))
+
+    def take(self, images):
+        """Hidden states of ``images``: the oldest submission if it was made for this very tensor, else computed now."""
+        if self.queue and self.queue[0][0] is images:
+            _, hidden, done = self.queue.pop(0)
+            main = torch.cuda.current_stream(images.device)
+            main.wait_event(done)
+            hidden.record_stream(main)
+            return hidden
+        with torch.no_grad():
+            return _vision_states(self.vit, images, self.hf)
+
+
+def vlm_step_loss(vit_model, vlm_model, adapter, images, input_ids, text_attention_mask, hf_vit_model=False, vit_hidden=None):
+    """Forward of one early-fusion step -> scalar loss (fp32 on the native path).  Used by the train and eval loops.
+    ``vit_hidden``: the frozen tower's hidden states of ``images`` when they were computed ahead (``VisionAhead``)."""
+    if vit_hidden is None:
+        with torch.no_grad():
+            vit_hidden = _vision_states(vit_model, images, hf_vit_model)
     vision_emb = adapter(vit_hidden)
     nv = vision_emb.shape[1]
     B = images.shape[0]
@@ -135,13 +180,29 @@ def vlm_training_loop_simple(vit_model, vlm_model, adapter, train_loader, optimi
     vit_model.to(device)
     vlm_model.to(device)
     adapter.to(device)
+    on_gpu = torch.device(device).type == "cuda"
+    ahead = VisionAhead(vit_model, hf_vit_model) if on_gpu else None
+
+    def batches(loader):
+        """(batch on the device, its successor on the device or None): one batch of lookahead for the frozen tower."""
+        moved = lambda b: None if b is None else {k: b[k].to(device) for k in ("image", "input_ids", "attention_mask")}
+        it = iter(loader)
+        cur = moved(next(it, None))
+        while cur is not None:
+            nxt = moved(next(it, None))
+            yield cur, nxt
+            cur = nxt
+
     for epoch in range(1, num_epochs + 1):
         total_loss = torch.zeros((), dtype=torch.float32, device=device)
-        for step, batch in enumerate(train_loader):
-            images = batch["image"].to(device)
-            input_ids = batch["input_ids"].to(device)
-            mask = batch["attention_mask"].to(device)
-            loss = vlm_step_loss(vit_model, vlm_model, adapter, images, input_ids, mask, hf_vit_model)
+        for step, (batch, nxt) in enumerate(batches(train_loader)):
+            images, input_ids, mask = batch["image"], batch["input_ids"], batch["attention_mask"]
+            vit_hidden = None
+            if ahead is not None:
+                vit_hidden = ahead.take(images)  # computed under the previous step (or now, for the first batch of an epoch)
+                if nxt is not None:
+                    ahead.submit(nxt["image"])  # runs beside this step's decoder forward / backward
+            loss = vlm_step_loss(vit_model, vlm_model, adapter, images, input_ids, mask, hf_vit_model, vit_hidden=vit_hidden)
             if grad_sync is not None:
                 grad_sync.begin_step()
                 # ragged captions: weight this rank's mean by its share of the global batch's target tokens (ddp.py)
