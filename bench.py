@@ -136,25 +136,32 @@ def cpu_baseline(vit, ad, llm, seed, budget_s=240):
     }
 
 
+def _profile_json(name):
+    """A committed counter file from profiles/ -- only if it was measured on the kernel sources this process runs
+    (llm_quest_amd/fingerprint.py); a stale file yields None, never a number."""
+    from llm_quest_amd.fingerprint import kernel_sources_sha
+
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None, f"{name} not found"
+    if d.get("kernel_sources_sha") != kernel_sources_sha():
+        return None, f"{name} was measured on other kernel sources (its fingerprint {d.get('kernel_sources_sha')} != {kernel_sources_sha()}): re-collect it"
+    return d, None
+
+
 def pmc_traffic():
     """TCC counters of the dominant kernel, collected with rocprofv3 --pmc in separate passes and committed (PMC cannot be read
     from inside the timed process)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_tcc_gemm.json")
-    try:
-        with open(path) as f:
-            return json.load(f)["kernels"]
-    except (OSError, KeyError, ValueError):
-        return None
+    d, why = _profile_json("r02_pmc_tcc_gemm.json")
+    return (d["kernels"] if d else None), why
 
 
 def pmc_step_traffic():
-    """Whole-step TCC counters (profiles/r01_pmc_tcc_step.json), collected with rocprofv3 --pmc over this script."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_tcc_step.json")
-    try:
-        with open(path) as f:
-            return json.load(f)
-    except (OSError, ValueError):
-        return None
+    """Whole-step TCC counters (profiles/r02_pmc_tcc_step.json), collected with rocprofv3 --pmc over this script."""
+    return _profile_json("r02_pmc_tcc_step.json")
 
 
 def dominant_kernel_rate(batch, device):
@@ -339,7 +346,7 @@ def main():
             "roofline": {
                 "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                "traffic_note": "PMC bytes of the dominant kernel are in roofline.dominant_kernel (collected per kernel, profiles/r01_pmc_tcc_gemm.json)",
+                "traffic_note": "not collected",
                 "basis": "algorithmic 2.566 TFLOP/sample (SURVEY 8d) x per-GPU batch / step time; device-side (HIP events) "
                          f"{dev_ms / args.steps:.3f} ms/step",
             },
@@ -349,18 +356,23 @@ def main():
             line["with_optimizer_step"] = train_step
         if world == 1:
             line["roofline"]["dominant_kernel"] = {"name": "gemm_bf16_kernel", "hip_event_timing": dominant_kernel_rate(args.batch, device)}
-            pmc = pmc_traffic()
-            step_pmc = pmc_step_traffic()
-            if pmc is not None and args.batch == 64:  # the PMC passes were taken at this batch's shapes
-                line["roofline"]["traffic"] = step_pmc["per_step"]["total_bytes"] if step_pmc else pmc["NT"]["hbm_bytes"]
+            pmc, why_gemm = pmc_traffic()
+            step_pmc, why_step = pmc_step_traffic()
+            if args.batch != 64:  # the PMC passes were taken at this batch's shapes
+                line["roofline"]["traffic_note"] = "the committed counter passes were taken at per-GPU batch 64"
+            elif step_pmc is None:
+                line["roofline"]["traffic_note"] = "traffic withheld: " + why_step
+            else:
+                line["roofline"]["traffic"] = step_pmc["per_step"]["total_bytes"]
                 line["roofline"]["traffic_note"] = (
                     "memory-side bytes PER STEP (like `achieved`): 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE summed over every kernel of one step, separate "
-                    "rocprofv3 --pmc passes over this bench (profiles/r01_pmc_tcc_step.json, per-kernel table inside); Infinity-Cache hits are counted in "
-                    "FETCH_SIZE; the dominant kernel alone (gemm_bf16_kernel NT gate-up forward) moves "
-                    f"{pmc['NT']['hbm_bytes']} bytes per launch = {pmc['NT']['over_algorithmic']}x its algorithmic bytes (profiles/r01_pmc_tcc_gemm.json) and is MFMA-bound")
-                line["roofline"]["dominant_kernel"]["pmc_bytes_per_launch"] = {f: pmc[f]["hbm_bytes"] for f in ("NT", "NN", "TN")}
-                line["roofline"]["dominant_kernel"]["algorithmic_bytes_per_launch"] = {
-                    f: pmc[f]["algorithmic_read_bytes"] + pmc[f]["algorithmic_write_bytes"] for f in ("NT", "NN", "TN")}
+                    "rocprofv3 --pmc passes over this bench (profiles/r02_pmc_tcc_step.json, per-kernel table inside; fingerprint of the kernel sources checked); "
+                    "Infinity-Cache hits are counted in FETCH_SIZE")
+            if args.batch == 64 and pmc is not None:
+                line["roofline"]["dominant_kernel"]["pmc_bytes_per_launch"] = {f: pmc[f]["hbm_bytes"] for f in pmc}
+                line["roofline"]["dominant_kernel"]["over_algorithmic"] = {f: pmc[f]["over_algorithmic"] for f in pmc}
+            elif args.batch == 64:
+                line["roofline"]["dominant_kernel"]["pmc_note"] = "withheld: " + why_gemm
         if world == 1 and args.cpu_baseline == "auto":
             try:
                 line["cpu_baseline"] = cpu_baseline(vit, ad, llm, seed=123)

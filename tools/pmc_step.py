@@ -1,8 +1,10 @@
 """Whole-step memory-side traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, each with --kernel-trace) over
 `python3 bench.py --steps 1 --warmup 1 --cpu-baseline off`:  python tools/pmc_step.py <fetch_dir> <write_dir> <steps_in_trace> <out.json>
 Units and corrections as MI355X_MICROARCH.md prescribes: rocprofv3 reports KiB; on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, so it is doubled."""
-import csv, glob, json, re, sys
+import csv, glob, json, os, re, subprocess, sys
 from collections import defaultdict
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from llm_quest_amd.fingerprint import kernel_sources_sha
 
 
 def load(d, counter):
@@ -36,6 +38,8 @@ for name in set(fetch) | set(write):
 rows.sort(key=lambda r: -(r["fetch_bytes"] + r["write_bytes"]))
 tot_f, tot_w = sum(r["fetch_bytes"] for r in rows), sum(r["write_bytes"] for r in rows)
 out = {
+    "kernel_sources_sha": kernel_sources_sha(),
+    "git_sha": subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip(),
     "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, TCC slots) with --kernel-trace over `python3 bench.py --steps 1 --warmup 1 "
             "--cpu-baseline off` (per-GPU batch 64: 4 steps in each trace -- warm-up + timed, without and with the optimizer); figures are PER STEP = per-launch "
             "average x launches per step, so the bench's 13 stand-alone launches of each gate-up GEMM form drop out, and the optimizer's own kernels are left out (the headline step has none).  KiB units from rocprofv3; gfx950 correction: FETCH_SIZE doubled (128-byte requests "
