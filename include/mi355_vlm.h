@@ -141,6 +141,15 @@ int mi355_attn_bwd(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t 
                    const void* v, int64_t ldv, const void* o, int64_t ldo, const void* d_o, int64_t lddo,
                    const float* lse, float* delta, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv,
                    int64_t lddv, const uint8_t* key_mask, int causal, float scale, void* stream);
+/* The same backward with a caller-owned scratch matrix (16-byte aligned, mi355_attn_bwd_workspace_bytes(B,S,Hq,D) bytes; 0 = this
+ * shape has no such form and workspace may be NULL): the dK/dV pass leaves dS there in bf16 and dQ = scale * dS K is one product over
+ * it, instead of a pass that recomputes the scores.  Same results contract as mi355_attn_bwd; the scratch holds nothing afterwards. */
+int64_t mi355_attn_bwd_workspace_bytes(int B, int S, int Hq, int D);
+int mi355_attn_bwd_ws(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk,
+                      const void* v, int64_t ldv, const void* o, int64_t ldo, const void* d_o, int64_t lddo,
+                      const float* lse, float* delta, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv,
+                      int64_t lddv, const uint8_t* key_mask, int causal, float scale, void* workspace, int64_t workspace_bytes,
+                      void* stream);
 
 /* Row-wise cross entropy on bf16 logits with ignore_index=-100 (engine.py:45,60; vlm_engine.py:39).
  * logits [rows, V] ld=ldl.  loss_rows fp32 [rows] (0 for ignored).  If dlogits != NULL writes

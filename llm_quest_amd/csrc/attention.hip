@@ -238,12 +238,13 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 // owned tile (16 registers from owned offset OFF) += A x B, both operands in VGPRs.
-// s_nop 1: a B register written by the VALU instruction just before (v_cvt_pk -> MFMA operand).
-template <int OWNED, int OFF>
+// NOP (s_nop 1): for a B register written by the VALU instruction just before (v_cvt_pk -> MFMA operand); hipcc pads nothing inside asm.
+template <int OWNED, int OFF, bool NOP = true>
 __device__ __forceinline__ void mfma_owned(const bf16x8& a, const bf16x8& b) {
     static_assert(OFF % 16 == 0 && OFF + 16 <= OWNED, "tile outside the owned range");
     constexpr int R0 = 256 - OWNED + OFF;
-    OWNED_ASM(OWNED, "s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "i"(R0), "i"(R0 + 15));
+    if constexpr (NOP) OWNED_ASM(OWNED, "s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "i"(R0), "i"(R0 + 15));
+    else OWNED_ASM(OWNED, "v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "i"(R0), "i"(R0 + 15));
 }
 // compiler-allocated tile (16 VGPRs: the VALU reads it right after, no accvgpr copies) (+)= A x ownedB, where ownedB is the
 // 4-register B operand at owned offset OFF.  FIRST: start from zero (srcC = 0) instead of accumulating.
@@ -680,7 +681,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
                                                               bf16_t* __restrict__ dk, int64_t lddk, bf16_t* __restrict__ dv, int64_t lddv,
                                                               const uint8_t* __restrict__ key_mask, int causal, float scale, float scale_log2,
-                                                              int bpw) {
+                                                              int bpw, bf16_t* __restrict__ ds_out) {
+    // ds_out != nullptr: this pass also leaves dS / scale (bf16, the values its own dK^T product consumes) in a scratch buffer, so that
+    // dQ = scale * dS K becomes ONE product (attn_bwd_dq_spill_kernel) instead of the dQ pass's three (it recomputes S and dP):
+    // 5 products for the whole backward instead of 7.
     using C = Cfg<D>;
     constexpr int KS = C::KS, DT = C::DT;
     constexpr int NA = 2 * KS, NC = 4 * DT, NG = 2 * NA + 2 * NC;
@@ -747,6 +751,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
     const LaneOff<D> lo = lane_offsets<D>(lane);
     const unsigned lds0 = (unsigned)(unsigned long long)LDS_PTR(smem);
     int cstage = 0;
+    int st1 = 0, st2 = 0;  // dS stores issued by the previous trip and by the one before it
     for (int kb = kb_lo; kb < kb_hi; ++kb) {
         [[maybe_unused]] const unsigned long long t_pro = PROF_T();
         const int k0 = kb * 128;
@@ -768,7 +773,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
         for (int it = 0; it < nit; ++it) {
             // this wave's pieces of the tile have landed (a younger tile may stay in flight), then everybody's
             [[maybe_unused]] const unsigned long long t_w = PROF_T();
-            if (inflight >= 2) wait_vmcnt<PIECES + 1>(); else wait_vmcnt<0>();
+            // (gfx9 counts stores in vmcnt too, in issue order with the loads: the dS stores of the last two trips, 4 each, are younger than the tile awaited)
+            // order of issue behind the awaited tile: the stores of trip m-2, the next tile's pieces (+ its row constants), the stores of trip m-1
+            if (inflight >= 2) {
+                if (st1 + st2 == 8) wait_vmcnt<PIECES + 1 + 8>();
+                else if (st1 + st2 == 4) wait_vmcnt<PIECES + 1 + 4>();
+                else wait_vmcnt<PIECES + 1>();
+            } else wait_vmcnt<0>();
+            st2 = st1;
+            st1 = 0;
             PROF_ADD(1, t_w);
             [[maybe_unused]] const unsigned long long t_b = PROF_T();
             __builtin_amdgcn_s_barrier();
@@ -809,7 +822,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
                 TrHalves ft[RING] = {};
                 f32x16 sacc[2], pacc[2];
                 unsigned pw[2][8] = {}, dsw[2][8] = {};  // packed P / dS: words 4s..4s+3 of sub-tile st are the B operand of k-step s
-                float pv[16], dsv[16], l2r[16], dlr[16];
+                float lsr[2][16], dlr[2][16], tt[2][16], pv[2][16], dsv[2][16];
                 auto load = [&](auto gc) {
                     constexpr int g = gc.value;
                     if constexpr (ATTN_ABL & 1) return;
@@ -823,7 +836,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
                         if constexpr (!(ATTN_ABL & 32)) tr_issue<imm, imm + 8 * C::ROWB>(ft[g % RING], lds0 + va, lds0 + (UNI ? va ^ 0x20 : va));
                     }
                 };
-                // per-query constants of the 16 accumulator rows of sub-tile st: rows 8*g4 + 4*h + 0..3
+                // per-query constants of the 16 accumulator rows of sub-tile st: rows 8*g4 + 4*h + 0..3 (lse, then delta)
                 auto row_constants = [&](auto stc) {
                     constexpr int st = stc.value;
 #pragma unroll
@@ -831,25 +844,50 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
                         const f32x4 a = *reinterpret_cast<const f32x4*>(rc + st * 32 + 8 * g4);
                         const f32x4 c = *reinterpret_cast<const f32x4*>(rc + 64 + st * 32 + 8 * g4);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { l2r[4 * g4 + e] = a[e] * LOG2E; dlr[4 * g4 + e] = c[e]; }
+                        for (int e = 0; e < 4; ++e) { lsr[st][4 * g4 + e] = a[e]; dlr[st][4 * g4 + e] = c[e]; }
                     }
                 };
-                auto element = [&](auto stc, auto ec) {
-                    constexpr int st = stc.value, e = ec.value;
-                    if constexpr (ATTN_ABL & 2) return;
-                    float t = fmaf(sacc[st][e], scale_log2, -l2r[e]);
-                    if constexpr (BOUNDARY) {
-                        const int qq = qt * 64 + st * 32 + acc_row(e, lane);
-                        const bool masked = (causal && kg > qq) || !kreal || qq >= S;
-                        t = masked ? -INFINITY : t;  // exp2(-inf) = 0: no branch around the exp
+                // One element (accumulator register e of sub-tile st) in four stages.  A wave alone on its SIMD pays every dependent pair of
+                // vector instructions in full (tools/microbench/mfma_gap.hip: seven instructions of ONE element's chain beside an MFMA make the gap
+                // 62 cycles, three of them 33), so a gap never holds two stages of the same element: b_step(m) runs stage k of element m - k.
+                // The empty statements pin each stage's result where it is written (LLVM otherwise sinks a whole chain to its consumer).
+                auto stage = [&](auto stc, auto ec, auto kc) {
+                    constexpr int st = stc.value, e = ec.value, k = kc.value;
+                    if constexpr (e < 0 || e >= 16 || (ATTN_ABL & 2)) return;
+                    else if constexpr (k == 0) {
+                        lsr[st][e] *= LOG2E;
+                        asm volatile("" : "+v"(lsr[st][e]));
+                    } else if constexpr (k == 1) {
+                        float t = fmaf(sacc[st][e], scale_log2, -lsr[st][e]);
+                        if constexpr (BOUNDARY) {
+                            const int qq = qt * 64 + st * 32 + acc_row(e, lane);
+                            const bool masked = (causal && kg > qq) || !kreal || qq >= S;
+                            t = masked ? -INFINITY : t;  // exp2(-inf) = 0: no branch around the exp
+                        }
+                        tt[st][e] = t;
+                        asm volatile("" : "+v"(tt[st][e]));
+                    } else if constexpr (k == 2) {
+                        pv[st][e] = __builtin_amdgcn_exp2f(tt[st][e]);
+                        dsv[st][e] = pacc[st][e] - dlr[st][e];
+                        asm volatile("" : "+v"(pv[st][e]), "+v"(dsv[st][e]));
+                    } else {
+                        dsv[st][e] *= pv[st][e];  // dS / scale (the factor is applied to dK once)
+                        if constexpr (e % 2 == 1) {
+                            pw[st][e / 2] = pack_bf2(pv[st][e - 1], pv[st][e]);
+                            dsw[st][e / 2] = pack_bf2(dsv[st][e - 1], dsv[st][e]);
+                            asm volatile("" : "+v"(pw[st][e / 2]), "+v"(dsw[st][e / 2]));
+                        } else {
+                            asm volatile("" : "+v"(dsv[st][e]));
+                        }
                     }
-                    const float p = __builtin_amdgcn_exp2f(t);
-                    pv[e] = p;
-                    dsv[e] = p * (pacc[st][e] - dlr[e]);  // dS / scale (the factor is applied to dK once)
-                    if constexpr (e % 2 == 1) {
-                        pw[st][e / 2] = pack_bf2(pv[e - 1], pv[e]);
-                        dsw[st][e / 2] = pack_bf2(dsv[e - 1], dsv[e]);
-                    }
+                };
+                // virtual step m of the B phase of sub-tile st, PER elements entering per step: steps 0 .. 16 / PER + 2
+                auto b_step = [&](auto stc, auto mc, auto perc) {
+                    constexpr int m = mc.value, PER = perc.value;
+                    if constexpr (m >= 0 && m < 16 / PER + 3)
+                        static_for<4>([&](auto kc) {
+                            static_for<PER>([&](auto i) { stage(stc, std::integral_constant<int, (m - kc.value) * PER + i.value>{}, kc); });
+                        });
                 };
                 static_for<PD>([&](auto g) { load(g); });
                 [[maybe_unused]] unsigned long long t_seg = PROF_T();
@@ -871,42 +909,43 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
                         constexpr int h = g - 2 * NA, st = h / NC, sd = (h % NC) / (2 * DT), dt = (h % (2 * DT)) / 2, which = h % 2;
                         constexpr int younger = NG - 1 - g < PD ? NG - 1 - g : PD;
                         const bf16x8 fa = tr_wait<2 * younger>(ft[g % RING]);
-                        if constexpr (ATTN_ABL & 64) {  // profiling: same MFMA count into a VGPR tile with an AGPR B operand
-                            mfma_ownedB<OWNED, KF0, false>(sacc[(g / 2) % 2], fa);
-                        } else if constexpr (ATTN_ABL & 128) {  // profiling: owned accumulators but a fixed B operand
-                            if constexpr (ATTN_ABL & 256) {  // ... with the B phase kept alive
-                                const u32x4 w = {pw[st][4 * sd], dsw[st][4 * sd + 1], pw[st][4 * sd + 2], dsw[st][4 * sd + 3]};
-                                asm volatile("" ::"v"(w));
-                            }
-                            mfma_owned<OWNED, (which ? DK0 : 0) + 16 * dt>(fa, f[0]);
-                        } else if constexpr (which == 0) {
+                        if constexpr (which == 0) {
                             const u32x4 w = {pw[st][4 * sd], pw[st][4 * sd + 1], pw[st][4 * sd + 2], pw[st][4 * sd + 3]};
-                            mfma_owned<OWNED, 16 * dt>(fa, __builtin_bit_cast(bf16x8, w));
+                            mfma_owned<OWNED, 16 * dt, false>(fa, __builtin_bit_cast(bf16x8, w));
                         } else {
                             const u32x4 w = {dsw[st][4 * sd], dsw[st][4 * sd + 1], dsw[st][4 * sd + 2], dsw[st][4 * sd + 3]};
-                            mfma_owned<OWNED, DK0 + 16 * dt>(fa, __builtin_bit_cast(bf16x8, w));
+                            mfma_owned<OWNED, DK0 + 16 * dt, false>(fa, __builtin_bit_cast(bf16x8, w));
                         }
                     }
-                    // B(0) rides on the MFMAs of A(1), B(1) on those of C(0)
+                    // B(0) rides on the MFMAs of A(1) and the first three of C(0), B(1) on those of C(0) and the first three of C(1): the k-step
+                    // sd = 1 products that need the last elements start later than that in both C phases
                     if constexpr (g == NA) tiles_settle(sacc[0], pacc[0]);
                     if constexpr (g == 2 * NA) tiles_settle(sacc[1], pacc[1]);
-                    if constexpr (g >= NA && g < 2 * NA) {
-                        constexpr int m = g - NA, per = 16 / NA;
-                        static_for<per>([&](auto i) { element(std::integral_constant<int, 0>{}, std::integral_constant<int, m * per + i.value>{}); });
-                        if constexpr (g == 2 * NA - 1) row_constants(std::integral_constant<int, 1>{});
-                    } else if constexpr (g >= 2 * NA && g < 2 * NA + NC) {
-                        constexpr int m = g - 2 * NA, per = (16 + NC - 1) / NC;
-                        static_for<per>([&](auto i) {
-                            if constexpr (m * per + i.value < 16) element(std::integral_constant<int, 1>{}, std::integral_constant<int, m * per + i.value>{});
-                        });
-                    }
+                    static_assert(16 % NA == 0 && 16 % NC == 0 && 16 / (16 / NA) + 3 <= NA + NC / 2 && 16 / (16 / NC) + 3 <= NC + NC / 2, "B phase does not fit its gaps");
+                    b_step(std::integral_constant<int, 0>{}, std::integral_constant<int, g - NA>{}, std::integral_constant<int, 16 / NA>{});
+                    b_step(std::integral_constant<int, 1>{}, std::integral_constant<int, g - 2 * NA>{}, std::integral_constant<int, 16 / NC>{});
+                    if constexpr (g == 2 * NA - 1) row_constants(std::integral_constant<int, 1>{});
                     // keep this step's VALU where it is written: left alone, hipcc gathers a whole B phase into one MFMA gap
                     __builtin_amdgcn_sched_barrier(0);
                 });
                 PROF_ADD(11, t_seg);
+                if (ds_out) {
+                    // 16-byte units in the order the registers hold them: store (st, c2) = words 4 c2 .. 4 c2 + 3 of sub-tile st = this lane's key
+                    // against queries 32 st + 16 c2 + 4 (lane >> 5) + {0..3, 8..11}; unit index = lane, so every store is one contiguous KiB.
+                    // Blocks of 2 KiB: [b][hq][query tile][st][32-key group] -- what one wave of the dQ kernel streams through.
+                    const int hq_ = hkv * rep + it / per_head;
+                    const int nqb_ = (S + 127) / 128;
+                    char* blk = reinterpret_cast<char*>(ds_out) + ((((int64_t)b * Hq + hq_) * (2 * nqb_) + qt) * 2 * (4 * nqb_) + (kb * 4 + wave)) * 2048 + lane * 16;
+                    static_for<4>([&](auto i) {
+                        constexpr int st = i.value / 2, c2 = i.value % 2;
+                        const u32x4 w4 = {dsw[st][4 * c2], dsw[st][4 * c2 + 1], dsw[st][4 * c2 + 2], dsw[st][4 * c2 + 3]};
+                        *reinterpret_cast<u32x4*>(blk + (int64_t)st * (4 * nqb_) * 2048 + c2 * 1024) = w4;
+                    });
+                }
             };
             if (boundary) tile_body(std::true_type{});
             else tile_body(std::false_type{});
+            st1 = ds_out != nullptr ? 4 : 0;
         }
         [[maybe_unused]] const unsigned long long t_epi = PROF_T();
         owned_settle<OWNED>();
@@ -930,6 +969,106 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
     if (prof_on)
         for (int i = 0; i < 16; ++i) atomicAdd(&g_prof[i], prof_acc[i]);
 #endif
+}
+
+// ---- dQ from the spilled dS:  dQ^T[d x q] = scale * K^T[d x key] dS^T[key x q].  One workgroup = 128 queries of one (batch, head), a
+// wave = 32 of them = one (query tile, st) stream of the scratch buffer.  Per 64-key tile the K tile (transposed-read image, shared) and
+// each wave's own two 2-KiB dS blocks arrive by LDS-DMA, double-buffered; both MFMA operands are transposing reads in the same k order,
+// so the loop is 16 MFMAs and 40 LDS reads per tile and wave with no vector arithmetic at all.  The causal bound mirrors the dK/dV pass:
+// a (wave, 32-key group) is fetched iff that pass wrote it.
+// dS block in LDS: 2 pieces (c2) of 64 16-byte units; unit (h, key) sits in slot (32 h + key) ^ (h << 2) (the DMA lane for slot i fetches unit
+// i ^ ((i >> 5) << 2)), so the 16 lanes of a transposing read -- 4 keys x {h = 0, 1} x two 8-byte halves -- cover 16 distinct 8-byte bank slots.
+// Unit (c2, h, key) holds queries 16 c2 + 4 h + {0..3} and + {8..11}: query quad qd (of the wave's 8) is half (qd >> 1) & 1 of unit (c2 = qd >> 2, h = qd & 1).
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_spill_kernel(int B, int S, int Hq, int Hkv, const bf16_t* __restrict__ k, int64_t ldk,
+                                                                   const bf16_t* __restrict__ ds, bf16_t* __restrict__ dq, int64_t lddq,
+                                                                   int causal, float scale) {
+    using C = Cfg<D>;
+    constexpr int DT = C::DT, DSW = 4096, STAGE = C::TILE + 4 * DSW;  // a wave's dS bytes per 64-key tile: 2 key groups x 2 KiB
+    // Two stages and two workgroups per CU: one workgroup's LDS-DMA issue (~100 cycles per piece and wave when four waves issue together) runs under
+    // the other's MFMAs.  Four stages with one workgroup per CU were slower (249 us against 205 at the headline shape): the loop is bound by that issue
+    // cost and the LDS reads, not by the bytes in flight.
+    constexpr int NST = 2;
+    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nqb = (S + 127) / 128;
+    const int vid = xcd_chunked((int)blockIdx.x, (int)gridDim.x);
+    const int qb = nqb - 1 - (vid % nqb);  // heaviest (latest) query blocks first under the causal mask
+    const int bh = vid / nqb;
+    const int hq = bh % Hq, b = bh / Hq;
+    const int hkv = hq / (Hq / Hkv);
+    const int q0 = qb * 128;
+    const int qw = q0 + wave * 32;
+    const int qg = qw + (lane & 31);
+    const int ntiles_all = (S + 63) / 64;
+    const int ntiles = causal ? min(ntiles_all, (q0 + 127) / 64 + 1) : ntiles_all;
+    const bf16_t* kbase = k + (int64_t)b * S * ldk + (int64_t)hkv * D;
+    // this wave's stream: blocks [key group] of (b, hq, query tile 2 qb + wave / 2, st = wave % 2)
+    const char* sblk = reinterpret_cast<const char*>(ds) + (((((int64_t)b * Hq + hq) * (2 * nqb) + 2 * qb + (wave >> 1)) * 2 + (wave & 1)) * (4 * nqb)) * 2048;
+    auto srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(sblk), 0, 0x7fffffff, 0x00020000);
+    const unsigned unit = (unsigned)(lane ^ ((lane >> 5) << 2)) * 16;
+    auto fetched = [&](int kgrp) { return !(causal && kgrp * 32 > qw + 31) && kgrp * 32 < S; };
+    auto issue = [&](int kt) {
+        char* st_ = smem + (kt % NST) * STAGE;
+        dma_tile<D, IMG_TR>(kbase + (int64_t)kt * 64 * ldk, ldk, S - kt * 64, st_, wave, lane);
+        char* mine = st_ + C::TILE + wave * DSW;
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+            if (fetched(2 * kt + half)) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, LDS_PTR(mine + half * 2048), 16, (unsigned)((2 * kt + half) * 2048) + unit, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, LDS_PTR(mine + half * 2048 + 1024), 16, (unsigned)((2 * kt + half) * 2048 + 1024) + unit, 0, 0, 0);
+            }
+    };
+    const LaneOff<D> lok = lane_offsets<D>(lane);
+    const int g = lane >> 4, q4 = (lane >> 2) & 3, p = lane & 3;
+    const unsigned scol = (unsigned)((g & 1) * 1024 + ((((p & 1) * 32 + 4 * (g >> 1) + q4) ^ ((p & 1) << 2)) * 16) + (p >> 1) * 8) + C::TILE + wave * DSW;
+    const unsigned lds0 = (unsigned)(unsigned long long)LDS_PTR(smem);
+    f32x16 acc[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    for (int t = 0; t < NST - 1 && t < ntiles; ++t) issue(t);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        wait_vmcnt<0>();               // this wave's pieces of tile kt (the next tile is requested below) ...
+        __builtin_amdgcn_s_barrier();  // ... and everybody's K pieces; the stage refilled next was read one iteration ago
+        if (kt + NST - 1 < ntiles) issue(kt + NST - 1);
+        const unsigned kimg = lds0 + (kt % NST) * STAGE, simg = kimg + scol;
+        static_for<2>([&](auto hc) {
+            constexpr int half = hc.value;
+            if (!fetched(2 * kt + half)) return;
+            // the half's two 16-key k-steps: B = dS^T fragment of this wave's 32 queries, A = K^T fragments of the DT column groups;
+            // all reads from asm (a compiler-visible LDS read behind the DMA above would be guarded by vmcnt(0))
+            TrHalves bs[2], ak[2][DT];
+            static_for<2>([&](auto sc) {
+                constexpr int sd = sc.value, imm_s = half * 2048 + sd * 256, imm_k = (half * 32 + 16 * sd) * C::ROWB;
+                tr_issue<imm_s, imm_s + 128>(bs[sd], simg, simg);
+                static_for<DT>([&](auto dt) { tr_issue<imm_k, imm_k + 8 * C::ROWB>(ak[sd][dt.value], kimg + lok.col[dt.value], kimg + lok.col[dt.value]); });
+            });
+            static_for<2>([&](auto sc) {
+                constexpr int sd = sc.value;
+                // LDS reads issued after bs[sd]: its own DT K fragments and, for sd = 0, the whole second k-step: 2 (DT + (1 - sd) (1 + DT))
+                constexpr int after_b = 2 * DT + (sd == 0 ? 2 * (1 + DT) : 0);
+                const bf16x8 bf = tr_wait<(after_b < 15 ? after_b : 15)>(bs[sd]);
+                static_for<DT>([&](auto dt) {
+                    constexpr int after_a = 2 * (DT - 1 - dt.value) + (sd == 0 ? 2 * (1 + DT) : 0);
+                    acc[dt.value] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_wait<(after_a < 15 ? after_a : 15)>(ak[sd][dt.value]), bf, acc[dt.value], 0, 0, 0);
+                });
+            });
+        });
+    }
+    if (qg < S) {
+        bf16_t* row = dq + ((int64_t)b * S + qg) * lddq + (int64_t)hq * D;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = dt * 32 + 8 * g4 + 4 * (lane >> 5);
+                const u32x2 pk = {pack_bf2(acc[dt][4 * g4] * scale, acc[dt][4 * g4 + 1] * scale), pack_bf2(acc[dt][4 * g4 + 2] * scale, acc[dt][4 * g4 + 3] * scale)};
+                *reinterpret_cast<u32x2*>(row + d) = pk;
+            }
+    }
 }
 
 int check_common(const char* name, int B, int S, int Hq, int Hkv, int D) {
@@ -971,10 +1110,31 @@ extern "C" int mi355_attn_fwd(int B, int S, int Hq, int Hkv, int D, const void* 
     return 0;
 }
 
+extern "C" int64_t mi355_attn_bwd_workspace_bytes(int B, int S, int Hq, int D) {
+    if (D != 128 || B <= 0 || S <= 0 || Hq <= 0) return 0;  // the spilled form is built for head_dim 128
+    const int64_t nqb = (S + 127) / 128;
+    return (int64_t)B * Hq * nqb * nqb * 128 * 128 * 2;  // one bf16 per (query, key) of the padded square
+}
+
+extern "C" int mi355_attn_bwd_ws(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk,
+                                 const void* v, int64_t ldv, const void* o, int64_t ldo, const void* d_o, int64_t lddo,
+                                 const float* lse, float* delta, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv,
+                                 int64_t lddv, const uint8_t* key_mask, int causal, float scale, void* workspace, int64_t workspace_bytes,
+                                 void* stream);
+
 extern "C" int mi355_attn_bwd(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk,
                               const void* v, int64_t ldv, const void* o, int64_t ldo, const void* d_o, int64_t lddo,
                               const float* lse, float* delta, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv,
                               int64_t lddv, const uint8_t* key_mask, int causal, float scale, void* stream) {
+    return mi355_attn_bwd_ws(B, S, Hq, Hkv, D, q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo, lse, delta, dq, lddq, dk, lddk, dv, lddv, key_mask, causal, scale,
+                             nullptr, 0, stream);
+}
+
+extern "C" int mi355_attn_bwd_ws(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk,
+                                 const void* v, int64_t ldv, const void* o, int64_t ldo, const void* d_o, int64_t lddo,
+                                 const float* lse, float* delta, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv,
+                                 int64_t lddv, const uint8_t* key_mask, int causal, float scale, void* workspace, int64_t workspace_bytes,
+                                 void* stream) {
     if (check_common("mi355_attn_bwd", B, S, Hq, Hkv, D)) return 1;
     MI355_REQUIRE(q && k && v && o && d_o && lse && delta && dq && dk && dv, "mi355_attn_bwd: null pointer");
     MI355_REQUIRE(((ldq | ldk | ldv | ldo | lddo | lddq | lddk | lddv) & 7) == 0, "mi355_attn_bwd: leading dimensions must be multiples of 8");
@@ -991,14 +1151,26 @@ extern "C" int mi355_attn_bwd(int B, int S, int Hq, int Hkv, int D, const void* 
     const int64_t gq = (int64_t)B * Hq * ((nblk + bpw_q - 1) / bpw_q), gk = (int64_t)B * Hkv * ((nblk + bpw_k - 1) / bpw_k);
     MI355_REQUIRE(S <= 64 * ATTN_MAX_TILES, "mi355_attn_bwd: S must be <= %d", 64 * ATTN_MAX_TILES);
     MI355_REQUIRE(gq < 0x7fffffffLL, "mi355_attn_bwd: grid too large");
+    // workspace given (head_dim 128): the dK/dV pass spills dS and dQ is one product over it; otherwise the dQ pass recomputes S and dP
+    const bool spill = D == 128 && workspace != nullptr && !((causal >> 8) & 1024);  // ablation bit 10: the three-product dQ pass
+    if (spill) {
+        MI355_REQUIRE(workspace_bytes >= mi355_attn_bwd_workspace_bytes(B, S, Hq, D), "mi355_attn_bwd_ws: workspace of %lld bytes, %lld needed",
+                      (long long)workspace_bytes, (long long)mi355_attn_bwd_workspace_bytes(B, S, Hq, D));
+        MI355_REQUIRE(((uintptr_t)workspace & 15) == 0, "mi355_attn_bwd_ws: workspace must be 16-byte aligned");
+    }
+    bf16_t* ds_ws = spill ? (bf16_t*)workspace : nullptr;
 #define BWD_LAUNCH(DD)                                                                                                              \
     hipLaunchKernelGGL(attn_delta_kernel<DD>, dim3(dgrid), dim3(256), 0, s, B, S, Hq, (const bf16_t*)o, ldo, (const bf16_t*)d_o, lddo, delta); \
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<DD>, dim3((unsigned)gk), dim3(256), 0, s, B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, \
-                       (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, key_mask, causal, scale, sl2, bpw_k); \
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<DD>, dim3((unsigned)gq), dim3(256), 0, s, B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,  \
-                       (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dq, lddq, key_mask, causal, scale, sl2, bpw_q);
+                       (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, key_mask, causal, scale, sl2, bpw_k, ds_ws); \
+    if (!spill)                                                                                                                      \
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<DD>, dim3((unsigned)gq), dim3(256), 0, s, B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,  \
+                           (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dq, lddq, key_mask, causal, scale, sl2, bpw_q);
     if (D == 128) {
         BWD_LAUNCH(128)
+        if (spill)
+            hipLaunchKernelGGL(attn_bwd_dq_spill_kernel<128>, dim3((unsigned)((int64_t)B * Hq * nblk)), dim3(256), 0, s, B, S, Hq, Hkv, (const bf16_t*)k, ldk,
+                               (const bf16_t*)ds_ws, (bf16_t*)dq, lddq, causal & 0xff, scale);
     } else {
         BWD_LAUNCH(64)
     }

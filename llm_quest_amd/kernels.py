@@ -297,6 +297,22 @@ def _check_attn_operand(t, name, tokens, width):
 _ATTN_ABLATE = int(os.environ.get("MI355_ATTN_ABLATE", "0")) << 8  # profiling switches of attention.hip
 
 
+_ATTN_DS_SPILL = os.environ.get("MI355_ATTN_DS_SPILL", "1") != "0"  # 0: the dQ pass recomputes S and dP (no scratch)
+_ATTN_WS = {}
+
+
+def _attn_scratch(device, nbytes):
+    """dS scratch of the attention backward, one per (device, stream), grown to the largest request: every layer of a model reuses it
+    (a backward pass fills it and empties it again before the next one starts on the same stream)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _ATTN_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        _ATTN_WS.pop(key, None)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _ATTN_WS[key] = ws
+    return ws
+
+
 def attn_fwd(q, k, v, B, S, Hq, Hkv, D, key_mask=None, causal=True, scale=None):
     """q [B*S,Hq*D], k/v [B*S,Hkv*D] (row-strided views allowed).  Returns (o [B*S,Hq*D], lse fp32 [B,Hq,S])."""
     L.require_gpu(q, k, v, key_mask)
@@ -321,10 +337,13 @@ def attn_bwd(q, k, v, o, do, lse, B, S, Hq, Hkv, D, dq, dk, dv, key_mask=None, c
         raise ValueError("attention: lse must be contiguous fp32 [B,Hq,S]")
     delta = torch.empty_like(lse)
     scale = D ** -0.5 if scale is None else scale
+    ws, need = None, L.load().mi355_attn_bwd_workspace_bytes(B, S, Hq, D) if _ATTN_DS_SPILL else 0
+    if need:
+        ws = _attn_scratch(q.device, need)
     L.call(
-        "mi355_attn_bwd", B, S, Hq, Hkv, D, L.ptr(q), q.stride(0), L.ptr(k), k.stride(0), L.ptr(v), v.stride(0), L.ptr(o), o.stride(0),
+        "mi355_attn_bwd_ws", B, S, Hq, Hkv, D, L.ptr(q), q.stride(0), L.ptr(k), k.stride(0), L.ptr(v), v.stride(0), L.ptr(o), o.stride(0),
         L.ptr(do), do.stride(0), L.ptr(lse), L.ptr(delta), L.ptr(dq), dq.stride(0), L.ptr(dk), dk.stride(0), L.ptr(dv), dv.stride(0),
-        L.ptr(key_mask), int(causal) | _ATTN_ABLATE, scale,
+        L.ptr(key_mask), int(causal) | _ATTN_ABLATE, scale, L.ptr(ws), need,
     )
 
 

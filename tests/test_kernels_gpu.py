@@ -420,6 +420,43 @@ def test_attention_fwd_bwd(K, B, S, Hq, Hkv, D, causal, ragged):
         assert e < 8e-3, f"{name} rel l2 {e}"
 
 
+@pytest.mark.parametrize("B,S,Hq,Hkv,causal,ragged", [(2, 709, 4, 2, True, True), (1, 333, 2, 2, False, False), (3, 64, 4, 1, True, False), (1, 130, 2, 1, True, True)])
+def test_attention_backward_scratch_form_equals_recompute_form(K, B, S, Hq, Hkv, causal, ragged):
+    """mi355_attn_bwd_ws (the dK/dV pass leaves dS in a scratch buffer, dQ = scale * dS K is one product over it) against the form
+    without a workspace (the dQ pass recomputes S and dP): the same bf16 dS words meet the same K fragments in the same order, so
+    the three gradients are bit-identical; a scratch buffer that is too small is refused."""
+    D = 128
+    g = torch.Generator().manual_seed(S + Hq)
+    q, k, v, do = (dev(torch.randn(B * S, w * D, generator=g).to(BF16)) for w in (Hq, Hkv, Hkv, Hq))
+    km = None
+    if ragged:
+        km = torch.ones(B, S, dtype=torch.uint8)
+        km[0, S - S // 3 :] = 0
+        km = dev(km)
+    o, lse = K.attn_fwd(q, k, v, B, S, Hq, Hkv, D, key_mask=km, causal=causal)
+    outs = []
+    for spill in (False, True):
+        K._ATTN_DS_SPILL = spill
+        try:
+            dq, dk, dv = torch.full_like(q, float("nan")), torch.full_like(k, float("nan")), torch.full_like(v, float("nan"))
+            K.attn_bwd(q, k, v, o, do, lse, B, S, Hq, Hkv, D, dq, dk, dv, key_mask=km, causal=causal)
+            outs.append((dq, dk, dv))
+        finally:
+            K._ATTN_DS_SPILL = True
+    for a, b in zip(*outs):
+        assert torch.isfinite(b.float()).all() and torch.equal(a, b)
+    from llm_quest_amd import _lib as L
+
+    need = L.load().mi355_attn_bwd_workspace_bytes(B, S, Hq, D)
+    assert need == B * Hq * ((S + 127) // 128 * 128) ** 2 * 2 and L.load().mi355_attn_bwd_workspace_bytes(B, S, Hq, 64) == 0
+    ws = torch.empty(need - 16, dtype=torch.uint8, device="cuda")
+    delta = torch.empty_like(lse)
+    L.require_gpu(q, ws)
+    with pytest.raises(RuntimeError, match="workspace"):
+        L.call("mi355_attn_bwd_ws", B, S, Hq, Hkv, D, L.ptr(q), q.stride(0), L.ptr(k), k.stride(0), L.ptr(v), v.stride(0), L.ptr(o), o.stride(0), L.ptr(do), do.stride(0),
+               L.ptr(lse), L.ptr(delta), L.ptr(dq), dq.stride(0), L.ptr(dk), dk.stride(0), L.ptr(dv), dv.stride(0), L.ptr(km), int(causal), D ** -0.5, L.ptr(ws), need - 16)
+
+
 def test_attention_strided_views(K):
     """k/v read in place from the fused QKV projection buffer (row pitch = (Hq+2Hkv)*D)."""
     B, S, Hq, Hkv, D = 1, 100, 4, 2, 128
