@@ -334,9 +334,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int B, int S, int Hq, 
     load_rows_frag<D>(q + (int64_t)b * S * ldq + (int64_t)hq * D, ldq, qg, qvalid, lane, qf);
     // key-padding byte of this lane's key in the NEXT tile: loaded one tile ahead so its latency hides behind a whole tile
     uint8_t mk = (key_mask && lane < S) ? key_mask[(int64_t)b * S + lane] : (uint8_t)0;
+    [[maybe_unused]] const bool prof_on = threadIdx.x == 0;
+    [[maybe_unused]] unsigned long long prof_acc[16] = {};
+    [[maybe_unused]] const unsigned long long t_wg = PROF_T();
     for (int kt = 0; kt < ntiles; ++kt) {
+        [[maybe_unused]] const unsigned long long t_sync = PROF_T();
         __syncthreads();
+        PROF_ADD(1, t_sync);
+        [[maybe_unused]] const unsigned long long t_iss = PROF_T();
         if (kt + 1 < ntiles && !(abl & 1)) issue(kt + 1, (kt + 1) & 1);
+        PROF_ADD(2, t_iss);
+        [[maybe_unused]] unsigned long long t_seg = PROF_T();
+        if (prof_on) prof_acc[7] += 1;
         const int koff = (kt & 1) * 2 * C::TILE, voff = koff + C::TILE;
         // key-padding bits of this tile (1 = real token); keys beyond S read as padding here and are removed below
         unsigned long long kbits = ~0ull;
@@ -362,6 +371,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int B, int S, int Hq, 
                 for (int ks = 0; ks < C::KS; ++ks)
                     sacc[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(smem, vkx[ks], st * 32 * C::ROWB), qf[ks], sacc[st], 0, 0, 0);
             }
+#if ATTN_ABL & 16
+            asm volatile("" : "+v"(sacc[0]), "+v"(sacc[1]));
+            if (prof_on) { const unsigned long long now = __builtin_readcyclecounter(); prof_acc[3] += now - t_seg; t_seg = now; }
+#endif
             // masks are needed only on the diagonal / tail / padded tiles (wave-uniform test)
             const bool boundary = (kbits != ~0ull) || (kt * 64 + 64 > S) || (causal && kt * 64 + 63 > q0 + wave * 32);
             float mnew;
@@ -414,6 +427,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int B, int S, int Hq, 
                 m = mnew;
             }
             l += psum;
+#if ATTN_ABL & 16
+            asm volatile("" : "+v"(sacc[0]), "+v"(sacc[1]), "+v"(l));
+            if (prof_on) { const unsigned long long now = __builtin_readcyclecounter(); prof_acc[4] += now - t_seg; t_seg = now; }
+#endif
 #pragma unroll
             for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -424,6 +441,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int B, int S, int Hq, 
                         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr<D>(smem, vv[dt], (st * 32 + 16 * s) * C::ROWB), pf, oacc[dt], 0, 0, 0);
                 }
         }
+#if ATTN_ABL & 16
+        if (wave_active) { asm volatile("" : "+v"(oacc[0]), "+v"(oacc[1])); PROF_ADD(5, t_seg); if (prof_on) prof_acc[6] += 1; }
+#endif
         // reference semantics for rows whose visible keys are all padding: keep going over the causally hidden tiles
         if (key_mask && causal && kt + 1 == ntiles && ntiles < ntiles_all) {
             if (__syncthreads_or(m == MASK_T)) {
@@ -433,6 +453,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int B, int S, int Hq, 
         }
     }
 
+#if ATTN_ABL & 16
+    PROF_ADD(0, t_wg);
+    if (prof_on && (abl & 4096) && (blockIdx.x & 63) == 5)  // one workgroup in 64 reports: 16 contended atomics from each of 6 144 would be the whole run time
+        for (int i = 0; i < 16; ++i) atomicAdd(&g_prof[i], prof_acc[i]);
+#endif
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
     if (qvalid) {
