@@ -55,6 +55,9 @@ try:
 except (OSError, ValueError):
     allres = {"runs": []}
 allres["runs"] = [r for r in allres["runs"] if r["label"] != label] + [res]
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from llm_quest_amd.fingerprint import kernel_sources_sha
+allres["kernel_sources_sha"] = kernel_sources_sha()  # the sources the newest run was measured on (collect every label in one go)
 json.dump(allres, open(out_path, "w"), indent=1)
 for k, row in sorted(res["kernels"].items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[:12]:
     print(k[:70], {c: (round(v, 3) if v < 100 else int(v)) for c, v in row.items() if c.endswith(("pct", "GHz", "cycles", "mfma", "pmc"))})
