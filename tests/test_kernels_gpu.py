@@ -511,6 +511,35 @@ def test_cross_entropy_large_vocab(K):
     assert rel_l2(loss_rows, ref) < 1e-5
 
 
+@pytest.mark.parametrize("V", [1000, 8200, 32768, 32776, 151_936, 155_648, 155_656, 5003])
+@pytest.mark.parametrize("inplace", [True, False])
+def test_cross_entropy_forms_agree_with_fp32(K, V, inplace):
+    """Every dispatch of mi355_cross_entropy: the two-read kernel (V <= 8192, V > 155 648, V % 8 != 0) and the row-in-registers
+    kernel in both chunk counts (4 and 19 per thread); ignore_index rows, an out-of-range target, the target in the row's first
+    and last chunk, in place and out of place.  Loss rows to 1e-5 of the fp32 value, gradient to bf16 rounding (ref engine.py:45,60)."""
+    g = torch.Generator().manual_seed(V)
+    rows = 9
+    lg = (torch.randn(rows, V, generator=g) * 3).to(BF16)
+    tg = torch.randint(0, V, (rows,), generator=g)
+    tg[0], tg[1], tg[2], tg[3] = 0, V - 1, -100, V + 5  # first / last element, ignored, out of range
+    scale = torch.tensor([0.125], dtype=F32)
+    pitch = (V + 7) // 8 * 8  # rows are 16-byte aligned (the entry point refuses anything else): an odd vocabulary is a view into padded rows
+    x = torch.zeros(rows, pitch, dtype=BF16, device="cuda")[:, :V]
+    x.copy_(lg)
+    loss_rows, dl = K.cross_entropy(x, dev(tg), want_grad=True, grad_scale=dev(scale), inplace=inplace)
+    assert (dl.data_ptr() == x.data_ptr()) == inplace
+    ok = [r for r in range(rows) if r not in (2, 3)]
+    lref = lg.float().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lref[ok], tg[ok], reduction="none")
+    ref.sum().backward()
+    assert float((loss_rows.cpu()[ok] - ref.detach()).abs().max()) < 1e-5 * float(ref.detach().abs().max())
+    assert float(loss_rows[2]) == 0.0 and torch.isnan(loss_rows[3])
+    assert torch.count_nonzero(dl[[2, 3]]) == 0
+    assert rel_l2(dl.cpu()[ok], lref.grad[ok] * 0.125) < 4e-3
+    if not inplace:
+        assert torch.equal(x.cpu(), lg)  # the logits are untouched
+
+
 def test_embedding_and_scatter(K):
     g = torch.Generator().manual_seed(41)
     table = torch.randn(1000, 1024, generator=g).to(BF16)
