@@ -736,13 +736,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
     auto qt0_of = [&](int kb) { return causal ? kb * 2 : 0; };  // first query tile that can see any key of the block
 
     // ---- Q / dO tile stream over (key block, head, query tile), NST-deep
-    int ikb = kb_lo, iit = 0, istage = 0;
+    // (head and query tile advance as counters: a scalar division per tile was a tenth of the tile's time)
+    int ikb = kb_lo, ih = 0, iq = 0, istage = 0;  // next tile to request: key block, query head within the kv group, query tile counted from the block's first
     auto issue_next = [&]() -> bool {
-        while (ikb < kb_hi && iit >= (nqt_all - qt0_of(ikb)) * rep) { ++ikb; iit = 0; }
+        if (ikb < kb_hi && iq >= nqt_all - qt0_of(ikb)) { iq = 0; ++ih; }
+        if (ikb < kb_hi && ih >= rep) { ih = 0; ++ikb; }
         if (ikb >= kb_hi) return false;
-        const int per_head = nqt_all - qt0_of(ikb);
-        const int hq = hkv * rep + iit / per_head;
-        const int qt = qt0_of(ikb) + iit % per_head;
+        const int hq = hkv * rep + ih;
+        const int qt = qt0_of(ikb) + iq;
         char* st_ = smem + istage * STAGE;
         const bf16_t* qb_ = q + ((int64_t)b * S + (int64_t)qt * 64) * ldq + (int64_t)hq * D;
         const bf16_t* ob_ = d_o + ((int64_t)b * S + (int64_t)qt * 64) * lddo + (int64_t)hq * D;
@@ -762,7 +763,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
             const unsigned voff = qt * 64 + lane < S ? (unsigned)(lane * 4) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(rowc + istage * 512 + (wave & 1) * 256), 4, voff, 0, 0, 0);
         }
-        ++iit;
+        ++iq;
         istage = istage == NST - 1 ? 0 : istage + 1;
         return true;
     };
@@ -777,25 +778,31 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
     const unsigned lds0 = (unsigned)(unsigned long long)LDS_PTR(smem);
     int cstage = 0;
     int st1 = 0, st2 = 0;  // dS stores issued by the previous trip and by the one before it
+    // the K / V rows of a key block are requested while the PREVIOUS block's dK / dV are written out (the tile loop's registers are free there): their
+    // latency, 3-4k cycles per block in front of the first tile before, hides behind the epilogue's stores
+    bf16x8 tk[KS], tv[KS];
+    auto request_kv = [&](int kb_) {
+        const int kg_ = kb_ * 128 + wave * 32 + (lane & 31);
+        load_rows_frag<D>(k + (int64_t)b * S * ldk + (int64_t)hkv * D, ldk, kg_, kg_ < S, lane, tk);
+        load_rows_frag<D>(v + (int64_t)b * S * ldv + (int64_t)hkv * D, ldv, kg_, kg_ < S, lane, tv);
+    };
+    if (kb_lo < kb_hi) request_kv(kb_lo);
     for (int kb = kb_lo; kb < kb_hi; ++kb) {
         [[maybe_unused]] const unsigned long long t_pro = PROF_T();
         const int k0 = kb * 128;
         const int kg = k0 + wave * 32 + (lane & 31);
         const bool kvalid = kg < S;
         const bool kreal = kvalid && (key_mask == nullptr || key_mask[(int64_t)b * S + kg] != 0);
-        {
-            bf16x8 tk[KS], tv[KS];
-            load_rows_frag<D>(k + (int64_t)b * S * ldk + (int64_t)hkv * D, ldk, kg, kvalid, lane, tk);
-            load_rows_frag<D>(v + (int64_t)b * S * ldv + (int64_t)hkv * D, ldv, kg, kvalid, lane, tv);
-            owned_zero<OWNED, 0, 32 * DT>();
-            static_for<KS>([&](auto ks) { owned_write4<OWNED, KF0 + 4 * ks.value>(tk[ks.value]); });
-            static_for<KS>([&](auto ks) { owned_write4<OWNED, VF0 + 4 * ks.value>(tv[ks.value]); });
-        }
+        owned_zero<OWNED, 0, 32 * DT>();
+        static_for<KS>([&](auto ks) { owned_write4<OWNED, KF0 + 4 * ks.value>(tk[ks.value]); });
+        static_for<KS>([&](auto ks) { owned_write4<OWNED, VF0 + 4 * ks.value>(tv[ks.value]); });
         const int qt0 = qt0_of(kb);
         const int per_head = nqt_all - qt0;
         const int nit = per_head * rep;
         PROF_ADD(3, t_pro);
+        int ch = 0, cq = -1;  // the tile consumed: query head within the kv group, query tile counted from qt0
         for (int it = 0; it < nit; ++it) {
+            if (++cq == per_head) { cq = 0; ++ch; }
             // this wave's pieces of the tile have landed (a younger tile may stay in flight), then everybody's
             [[maybe_unused]] const unsigned long long t_w = PROF_T();
             // (gfx9 counts stores in vmcnt too, in issue order with the loads: the dS stores of the last two trips, 4 each, are younger than the tile awaited)
@@ -821,7 +828,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
                 __device__ ~BodyTimer() { if (on) { acc[2] += __builtin_readcyclecounter() - t0; acc[5] += 1; } }
             } body_timer{PROF_T(), prof_on, prof_acc};
 #endif
-            const int qt = qt0 + it % per_head;
+            const int qt = qt0 + cq;
             const int qroff = cstage * STAGE, qtoff = UNI ? qroff : qroff + C::TILE, oroff = qroff + OIMG, otoff = UNI ? oroff : oroff + C::TILE;
             const float* rc = reinterpret_cast<const float*>(rowc + cstage * 512) + 4 * (lane >> 5);
             cstage = cstage == NST - 1 ? 0 : cstage + 1;
@@ -958,7 +965,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
                     // 16-byte units in the order the registers hold them: store (st, c2) = words 4 c2 .. 4 c2 + 3 of sub-tile st = this lane's key
                     // against queries 32 st + 16 c2 + 4 (lane >> 5) + {0..3, 8..11}; unit index = lane, so every store is one contiguous KiB.
                     // Blocks of 2 KiB: [b][hq][query tile][st][32-key group] -- what one wave of the dQ kernel streams through.
-                    const int hq_ = hkv * rep + it / per_head;
+                    const int hq_ = hkv * rep + ch;
                     const int nqb_ = (S + 127) / 128;
                     char* blk = reinterpret_cast<char*>(ds_out) + ((((int64_t)b * Hq + hq_) * (2 * nqb_) + qt) * 2 * (4 * nqb_) + (kb * 4 + wave)) * 2048 + lane * 16;
                     static_for<4>([&](auto i) {
@@ -974,17 +981,24 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
         }
         [[maybe_unused]] const unsigned long long t_epi = PROF_T();
         owned_settle<OWNED>();
-        bf16_t* krow = dk + ((int64_t)b * S + kg) * lddk + (int64_t)hkv * D;
-        bf16_t* vrow = dv + ((int64_t)b * S + kg) * lddv + (int64_t)hkv * D;
-        static_for<DT * 4>([&](auto i) {
-            constexpr int dt = i.value / 4, g4 = i.value % 4, rv = 16 * dt + 4 * g4, rk = DK0 + rv;
-            const int d = dt * 32 + 8 * g4 + 4 * (lane >> 5);
-            const u32x2 a = {pack_bf2(owned_read<OWNED, rk>() * scale, owned_read<OWNED, rk + 1>() * scale),
-                             pack_bf2(owned_read<OWNED, rk + 2>() * scale, owned_read<OWNED, rk + 3>() * scale)};
-            const u32x2 c = {pack_bf2(owned_read<OWNED, rv>(), owned_read<OWNED, rv + 1>()), pack_bf2(owned_read<OWNED, rv + 2>(), owned_read<OWNED, rv + 3>())};
+        if (kb + 1 < kb_hi) request_kv(kb + 1);
+        // 16-byte stores: the two half-waves hold adjacent 8-byte pieces of a key's row (d = 8 g4 + 4 (lane >> 5) + 0..3); one v_permlane32_swap per word
+        // gives the lower half-wave both pieces of an even g4 and the upper half-wave both pieces of the odd one -- 8 stores per tensor instead of 16
+        // (the write-out is bound by what it costs to issue a store)
+        bf16_t* krow = dk + ((int64_t)b * S + kg) * lddk + (int64_t)hkv * D + 8 * (lane >> 5);
+        bf16_t* vrow = dv + ((int64_t)b * S + kg) * lddv + (int64_t)hkv * D + 8 * (lane >> 5);
+        static_for<DT * 2>([&](auto i) {
+            constexpr int dt = i.value / 2, gp = i.value % 2, rv = 16 * dt + 8 * gp, rk = DK0 + rv;
+            const unsigned ka0 = pack_bf2(owned_read<OWNED, rk>() * scale, owned_read<OWNED, rk + 1>() * scale), ka1 = pack_bf2(owned_read<OWNED, rk + 2>() * scale, owned_read<OWNED, rk + 3>() * scale);
+            const unsigned kb0 = pack_bf2(owned_read<OWNED, rk + 4>() * scale, owned_read<OWNED, rk + 5>() * scale), kb1 = pack_bf2(owned_read<OWNED, rk + 6>() * scale, owned_read<OWNED, rk + 7>() * scale);
+            const unsigned va0 = pack_bf2(owned_read<OWNED, rv>(), owned_read<OWNED, rv + 1>()), va1 = pack_bf2(owned_read<OWNED, rv + 2>(), owned_read<OWNED, rv + 3>());
+            const unsigned vb0 = pack_bf2(owned_read<OWNED, rv + 4>(), owned_read<OWNED, rv + 5>()), vb1 = pack_bf2(owned_read<OWNED, rv + 6>(), owned_read<OWNED, rv + 7>());
+            const auto k0s = __builtin_amdgcn_permlane32_swap(ka0, kb0, false, false), k1s = __builtin_amdgcn_permlane32_swap(ka1, kb1, false, false);
+            const auto v0s = __builtin_amdgcn_permlane32_swap(va0, vb0, false, false), v1s = __builtin_amdgcn_permlane32_swap(va1, vb1, false, false);
+            const u32x4 wk = {k0s[0], k1s[0], k0s[1], k1s[1]}, wv = {v0s[0], v1s[0], v0s[1], v1s[1]};
             if (kvalid && !(abl & 2)) {
-                *reinterpret_cast<u32x2*>(krow + d) = a;
-                *reinterpret_cast<u32x2*>(vrow + d) = c;
+                *reinterpret_cast<u32x4*>(krow + dt * 32 + 16 * gp) = wk;
+                *reinterpret_cast<u32x4*>(vrow + dt * 32 + 16 * gp) = wv;
             }
         });
         PROF_ADD(4, t_epi);
@@ -1163,7 +1177,8 @@ extern "C" int mi355_attn_bwd_ws(int B, int S, int Hq, int Hkv, int D, const voi
     if (check_common("mi355_attn_bwd", B, S, Hq, Hkv, D)) return 1;
     MI355_REQUIRE(q && k && v && o && d_o && lse && delta && dq && dk && dv, "mi355_attn_bwd: null pointer");
     MI355_REQUIRE(((ldq | ldk | ldv | ldo | lddo | lddq | lddk | lddv) & 7) == 0, "mi355_attn_bwd: leading dimensions must be multiples of 8");
-    MI355_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)d_o) & 15) == 0, "mi355_attn_bwd: operands must be 16-byte aligned");
+    MI355_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)d_o | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0,
+                  "mi355_attn_bwd: operands and gradients must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const float sl2 = scale * LOG2E;
     const int64_t items = (int64_t)B * S * ((Hq + 512 / D - 1) / (512 / D));
