@@ -35,7 +35,7 @@ struct Elem<float> {
 template <typename T, int V, bool TRANSPOSE>
 __global__ __launch_bounds__(256) void rope_apply_kernel(int64_t rows, int H, int S, int D, int R, const T* __restrict__ x, int64_t sb, int64_t sh,
                                                          int64_t ss, const float* __restrict__ cosr, const float* __restrict__ sinr,
-                                                         const int32_t* __restrict__ idx, T* __restrict__ out, int64_t ob, int64_t oh, int64_t os) {
+                                                         const int32_t* __restrict__ idx, int64_t table_rows, T* __restrict__ out, int64_t ob, int64_t oh, int64_t os) {
     const int half = R >> 1;
     const int cpr = half / V + (D - R) / V;  // chunks per row
     const int64_t total = rows * cpr;
@@ -54,7 +54,10 @@ __global__ __launch_bounds__(256) void rope_apply_kernel(int64_t rows, int H, in
             continue;
         }
         const int j = c * V;
-        const int64_t crow = idx ? (int64_t)idx[b * S + s] : (int64_t)s;
+        // a position outside the coefficient table (the reference would raise an index error) never reads out of bounds: its row comes out as NaN
+        int64_t crow = idx ? (int64_t)idx[b * S + s] : (int64_t)s;
+        const bool bad_row = crow < 0 || crow >= table_rows;
+        crow = bad_row ? 0 : crow;
         const float* cr = cosr + crow * R;
         const float* sr = sinr + crow * R;
         T o1[V], o2[V];
@@ -71,8 +74,8 @@ __global__ __launch_bounds__(256) void rope_apply_kernel(int64_t rows, int H, in
                 r1 = Elem<T>::rnd(Elem<T>::rnd(c1 * x1) + Elem<T>::rnd(s2 * x2));
                 r2 = Elem<T>::rnd(Elem<T>::rnd(c2 * x2) + (-Elem<T>::rnd(s1 * x1)));
             }
-            o1[e] = Elem<T>::st(r1);
-            o2[e] = Elem<T>::st(r2);
+            o1[e] = Elem<T>::st(bad_row ? __builtin_nanf("") : r1);
+            o2[e] = Elem<T>::st(bad_row ? __builtin_nanf("") : r2);
         }
 #pragma unroll
         for (int e = 0; e < V; ++e) {
@@ -121,7 +124,7 @@ extern "C" int mi355_rope_apply(int B, int H, int S, int D, int R, const void* x
     MI355_REQUIRE(B > 0 && H > 0 && S > 0 && D > 0 && x && cos_t && sin_t && out, "mi355_rope_apply: bad arguments");
     MI355_REQUIRE(R > 0 && R <= D && (R & 1) == 0, "mi355_rope_apply: rotation width %d must be even and <= head_dim %d", R, D);
     MI355_REQUIRE(dtype == MI355_DT_BF16 || dtype == MI355_DT_F32, "mi355_rope_apply: dtype must be bf16 or fp32");
-    MI355_REQUIRE(idx || table_rows >= S, "mi355_rope_apply: coefficient table has %lld rows, sequence length is %d", (long long)table_rows, S);
+    MI355_REQUIRE(table_rows > 0 && (idx || table_rows >= S), "mi355_rope_apply: coefficient table has %lld rows, sequence length is %d", (long long)table_rows, S);
     const int64_t rows = (int64_t)B * H * S;
     const int half = R / 2;
     const int vw = dtype == MI355_DT_BF16 ? 8 : 4;
@@ -130,7 +133,7 @@ extern "C" int mi355_rope_apply(int B, int H, int S, int D, int R, const void* x
     const int cpr = vec ? half / vw + (D - R) / vw : half + (D - R);
     const int grid = grid_for(rows * cpr, 256);
 #define RL(T, V, TR) \
-    hipLaunchKernelGGL((rope_apply_kernel<T, V, TR>), dim3(grid), dim3(256), 0, STREAM, rows, H, S, D, R, (const T*)x, sb, sh, ss, cos_t, sin_t, idx, (T*)out, ob, oh, os)
+    hipLaunchKernelGGL((rope_apply_kernel<T, V, TR>), dim3(grid), dim3(256), 0, STREAM, rows, H, S, D, R, (const T*)x, sb, sh, ss, cos_t, sin_t, idx, table_rows, (T*)out, ob, oh, os)
     if (dtype == MI355_DT_BF16) {
         if (vec) { if (transpose) RL(bf16_t, 8, true); else RL(bf16_t, 8, false); }
         else { if (transpose) RL(bf16_t, 1, true); else RL(bf16_t, 1, false); }

@@ -298,18 +298,42 @@ _ATTN_ABLATE = int(os.environ.get("MI355_ATTN_ABLATE", "0")) << 8  # profiling s
 
 
 _ATTN_DS_SPILL = os.environ.get("MI355_ATTN_DS_SPILL", "1") != "0"  # 0: the dQ pass recomputes S and dP (no scratch)
-_ATTN_WS = {}
+# The dS scratch grows with S^2 (2 bytes per (query, key) of the padded square per head): 1.2 GB at the headline shape, 17 GB at S = 8192, B = 8.
+# Above this cap -- or a quarter of the device's free memory, or when the allocation fails -- the backward takes the recompute form (three
+# products in the dQ pass, O(S) memory, bit-identical gradients): long-context training keeps working, only slower per layer.
+_ATTN_DS_SPILL_MAX = int(float(os.environ.get("MI355_ATTN_DS_SPILL_MAX_MB", "4096")) * (1 << 20))
+_ATTN_WS = {}  # (device, stream handle) -> uint8 buffer; at most _ATTN_WS_SLOTS entries (least recently used dropped: dead streams do not pin memory)
+_ATTN_WS_SLOTS = 4
+attn_bwd_form = {"spill": 0, "recompute": 0}  # how many backward calls took each form (tests, diagnostics)
+
+
+def release_attention_scratch():
+    """Drop every cached dS scratch buffer (they are re-created on demand)."""
+    _ATTN_WS.clear()
 
 
 def _attn_scratch(device, nbytes):
-    """dS scratch of the attention backward, one per (device, stream), grown to the largest request: every layer of a model reuses it
-    (a backward pass fills it and empties it again before the next one starts on the same stream)."""
+    """dS scratch of the attention backward, one per (device, stream): every layer of a model reuses it (a backward pass fills it and
+    empties it again before the next one starts on the same stream).  Returns None when the request is over the cap or cannot be
+    allocated -- the caller then runs the recompute form.  A buffer more than 4x the request is replaced by a fitting one."""
+    if nbytes > _ATTN_DS_SPILL_MAX:
+        return None
     key = (device, torch.cuda.current_stream(device).cuda_stream)
-    ws = _ATTN_WS.get(key)
-    if ws is None or ws.numel() < nbytes:
-        _ATTN_WS.pop(key, None)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _ATTN_WS[key] = ws
+    ws = _ATTN_WS.pop(key, None)
+    if ws is not None and (ws.numel() < nbytes or ws.numel() > 4 * nbytes):
+        ws = None
+    if ws is None:
+        free, _ = torch.cuda.mem_get_info(device)
+        cached = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+        if nbytes > (free + cached) // 4:
+            return None
+        try:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        except torch.OutOfMemoryError:
+            return None
+    _ATTN_WS[key] = ws  # re-inserted last: dict order is the LRU order
+    while len(_ATTN_WS) > _ATTN_WS_SLOTS:
+        _ATTN_WS.pop(next(iter(_ATTN_WS)))
     return ws
 
 
@@ -340,6 +364,9 @@ def attn_bwd(q, k, v, o, do, lse, B, S, Hq, Hkv, D, dq, dk, dv, key_mask=None, c
     ws, need = None, L.load().mi355_attn_bwd_workspace_bytes(B, S, Hq, D) if _ATTN_DS_SPILL else 0
     if need:
         ws = _attn_scratch(q.device, need)
+        if ws is None:
+            need = 0  # over the cap / no memory: the recompute form (mi355_attn_bwd_ws with a NULL workspace)
+    attn_bwd_form["spill" if need else "recompute"] += 1
     L.call(
         "mi355_attn_bwd_ws", B, S, Hq, Hkv, D, L.ptr(q), q.stride(0), L.ptr(k), k.stride(0), L.ptr(v), v.stride(0), L.ptr(o), o.stride(0),
         L.ptr(do), do.stride(0), L.ptr(lse), L.ptr(delta), L.ptr(dq), dq.stride(0), L.ptr(dk), dk.stride(0), L.ptr(dv), dv.stride(0),

@@ -36,14 +36,6 @@ def f32_cat_cached(module, tag, params):
     return val
 
 
-def refuse_training(module, what):
-    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
-        raise NotImplementedError(
-            f"{what}: the HIP ViT path is forward-only in this round (frozen / eval ViT as in the VLM step, "
-            "vlm_engine.py:80-83). Freeze the ViT (requires_grad=False) or run under torch.no_grad()."
-        )
-
-
 class ViTMultiHeadAttention(nn.Module):
     """Bidirectional MHA, separate q/k/v Linear layers with optional bias (reference: vit_attention.py:8-91)."""
 
@@ -80,13 +72,17 @@ class ViTMultiHeadAttention(nn.Module):
         return ctx
 
     def forward(self, x):
-        """x (b, s, d_in) fp32 or bf16 -> (b, s, d_out) in x.dtype."""
-        L.require_gpu(x)
-        refuse_training(self, "ViTMultiHeadAttention")
+        """x (b, s, d_in) fp32 or bf16 -> (b, s, d_out) in x.dtype.  An ordinary autograd module as upstream (vit_attention.py:44-91): one
+        node over the (forward, backward) pair of ``vit_train``; without grad mode the forward keeps nothing."""
+        from llm_quest_amd.multimodal.vision_transformer import vit_train as T
+
         B, S, _ = x.shape
-        h = x.reshape(B * S, -1)
-        h = K.cast(h.contiguous(), BF16) if h.dtype != BF16 else h.contiguous()
-        ctx = self.context(h, B, S)
-        wo = bf16_cached(self, "wo", [self.out_proj.weight])
-        y = K.gemm(L.GEMM_NT, ctx, wo, bias=self.out_proj.bias.detach(), out_dtype=x.dtype)
-        return y.view(B, S, self.d_out)
+
+        def fwd(t):
+            y, saved = T.att_forward(self, T.as_bf16_rows(t), B, S, self.training, out_dtype=F32)
+            return T.like(y, t, self.d_out), saved
+
+        def bwd(saved, dy):
+            return T.like(T.att_backward(self, saved, dy.reshape(B * S, self.d_out)), dy, x.shape[-1])
+
+        return T.run_piece(self, x, fwd, bwd)

@@ -5,7 +5,7 @@ import torch.nn as nn
 
 from llm_quest_amd import _lib as L
 from llm_quest_amd import kernels as K
-from llm_quest_amd.multimodal.vision_transformer.vit_attention import bf16_cached, refuse_training
+from llm_quest_amd.multimodal.vision_transformer.vit_attention import bf16_cached
 from llm_quest_amd.multimodal.vision_transformer.vit_transformer_block import LayerNorm, ViTTransformerBlock
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -38,11 +38,36 @@ class PatchEmbedding2D(nn.Module):
         return K.gemm(L.GEMM_NT, rows, w, bias=self.conv_proj.bias.detach(), out_dtype=F32)
 
     def forward(self, x):
-        L.require_gpu(x)
-        refuse_training(self, "PatchEmbedding2D")
-        b = x.shape[0]
-        proj = self.project(x).view(b, self.num_patches, -1)
-        return torch.cat([self.cls_token.detach().expand(b, -1, -1), proj], dim=1)
+        """(b, c, h, w) -> (b, num_patches + 1, emb) fp32, CLS row first (reference :68-89).  Autograd node: the backward writes the
+        projection's weight / bias gradients and the CLS token's; pixels receive no gradient."""
+        from llm_quest_amd.multimodal.vision_transformer import vit_train as T
+
+        b, emb = x.shape[0], self.cls_token.shape[-1]
+
+        def fwd(px):
+            assert px.shape[2] == self.img_width and px.shape[3] == self.img_height, (
+                f"Input image shape {px.shape} does not match expected shape {self.img_width}x{self.img_height}"
+            )
+            rows = K.patchify(px.contiguous().to(F32), self.patch_size, out_dtype=BF16)
+            w = bf16_cached(self, "wconv", [self.conv_proj.weight])
+            proj = K.gemm(L.GEMM_NT, rows, w, bias=self.conv_proj.bias.detach(), out_dtype=F32)
+            out = torch.empty((b, self.num_patches + 1, emb), dtype=F32, device=px.device)
+            flat = out.view(b, -1)
+            K.copy2d(self.cls_token.detach().reshape(1, emb).to(F32).expand(b, emb).contiguous(), flat[:, :emb])
+            K.copy2d(proj.view(b, -1), flat[:, emb:])
+            return out, (rows,)
+
+        def bwd(saved, dy):
+            g = T.as_f32_rows(dy).view(b, -1)
+            T._acc(self.cls_token, K.colsum(g[:, :emb]))
+            dproj = torch.empty((b, self.num_patches * emb), dtype=F32, device=g.device)
+            K.copy2d(g[:, emb:], dproj)
+            dproj_b = K.cast(dproj, BF16).view(b * self.num_patches, emb)
+            T._wgrad(self.conv_proj.weight, dproj_b, saved[0])
+            T._bgrad(self.conv_proj.bias, dproj_b)
+            return None
+
+        return T.run_piece(self, x, fwd, bwd)
 
 
 class ViTModel(nn.Module):

@@ -5,7 +5,7 @@ import torch.nn as nn
 
 from llm_quest_amd import _lib as L
 from llm_quest_amd import kernels as K
-from llm_quest_amd.multimodal.vision_transformer.vit_attention import ViTMultiHeadAttention, bf16_cached, refuse_training
+from llm_quest_amd.multimodal.vision_transformer.vit_attention import ViTMultiHeadAttention, bf16_cached
 
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -23,13 +23,21 @@ class LayerNorm(nn.Module):
         return K.layernorm_fwd(x2d_f32, self.scale.detach(), self.shift.detach(), out_dtype=out_dtype, eps=self.eps)
 
     def forward(self, x):
-        L.require_gpu(x)
-        refuse_training(self, "LayerNorm")
-        shp = x.shape
-        x2 = x.reshape(-1, shp[-1]).contiguous()
-        if x2.dtype != F32:
-            x2 = K.cast(x2, F32)
-        return self.normalize(x2, F32).view(shp)
+        """fp32 statistics whatever the input dtype; output in x.dtype.  Autograd node over ``layernorm_fwd`` / ``layernorm_bwd``."""
+        from llm_quest_amd.multimodal.vision_transformer import vit_train as T
+
+        def fwd(t):
+            x2 = T.as_f32_rows(t)
+            y, mean, rsig = K.layernorm_fwd(x2, self.scale.detach(), self.shift.detach(), out_dtype=F32, eps=self.eps, want_stats=True)
+            return T.like(y, t, t.shape[-1]), (x2, mean, rsig)
+
+        def bwd(saved, dy):
+            x2, mean, rsig = saved
+            g = dy.reshape(x2.shape)
+            g = g if g.dtype in (F32, BF16) else g.to(F32)
+            return T.like(T._ln_bwd(self, x2, mean, rsig, g, None), dy, dy.shape[-1])
+
+        return T.run_piece(self, x, fwd, bwd)
 
 
 class GELU(nn.Module):
@@ -39,12 +47,27 @@ class GELU(nn.Module):
         super().__init__()
 
     def forward(self, x):
-        L.require_gpu(x)
-        if torch.is_grad_enabled() and x.requires_grad:
-            raise NotImplementedError("stand-alone GELU backward is not wired; use ViTAdapter or eval mode")
-        xb = x.contiguous() if x.dtype == BF16 else K.cast(x.contiguous(), BF16)
-        y = K.gelu_fwd(xb)
-        return y if x.dtype == BF16 else K.cast(y, x.dtype)
+        from llm_quest_amd.multimodal.vision_transformer import vit_train as T
+
+        def fwd(t):
+            xb = t.contiguous() if t.dtype == BF16 else K.cast(t.contiguous(), BF16)
+            pad = (-xb.numel()) % 8  # the element-wise kernels move 16-byte words
+            if pad:
+                xb = torch.cat([xb.reshape(-1), xb.new_zeros(pad)])
+            y = K.gelu_fwd(xb)
+            y = y[: t.numel()].view(t.shape) if pad else y
+            return (y if t.dtype == BF16 else K.cast(y.contiguous(), t.dtype)), (xb, pad)
+
+        def bwd(saved, dy):
+            xb, pad = saved
+            g = dy.contiguous() if dy.dtype == BF16 else K.cast(dy.contiguous(), BF16)
+            if pad:
+                g = torch.cat([g.reshape(-1), g.new_zeros(pad)])
+            dx = K.gelu_bwd(xb, g.view(xb.shape))
+            dx = dx[: dy.numel()].view(dy.shape) if pad else dx.view(dy.shape)
+            return dx if dy.dtype == BF16 else K.cast(dx.contiguous(), dy.dtype)
+
+        return T.run_piece(self, x, fwd, bwd)
 
 
 class FFN(nn.Module):
@@ -60,14 +83,18 @@ class FFN(nn.Module):
         return K.gemm(L.GEMM_NT, h_bf16, w1, bias=self.layers[0].bias.detach(), gelu=True)
 
     def forward(self, x):
-        L.require_gpu(x)
-        refuse_training(self, "ViT FFN")
-        shp = x.shape
-        h = x.reshape(-1, shp[-1]).contiguous()
-        h = h if h.dtype == BF16 else K.cast(h, BF16)
-        f = self.hidden(h)
-        w2 = bf16_cached(self, "w2", [self.layers[2].weight])
-        return K.gemm(L.GEMM_NT, f, w2, bias=self.layers[2].bias.detach(), out_dtype=x.dtype).view(shp)
+        from llm_quest_amd.multimodal.vision_transformer import vit_train as T
+
+        d = x.shape[-1]
+
+        def fwd(t):
+            y, saved = T.ffn_forward(self, T.as_bf16_rows(t), out_dtype=F32)
+            return T.like(y, t, d), saved
+
+        def bwd(saved, dy):
+            return T.like(T.ffn_backward(self, saved, dy.reshape(-1, d)), dy, d)
+
+        return T.run_piece(self, x, fwd, bwd)
 
 
 class ViTTransformerBlock(nn.Module):
@@ -102,9 +129,17 @@ class ViTTransformerBlock(nn.Module):
         return K.gemm(L.GEMM_NT, f, w2, bias=self.ffn.layers[2].bias.detach(), residual=x2, out_dtype=F32)
 
     def forward(self, x):
-        L.require_gpu(x)
-        refuse_training(self, "ViTTransformerBlock")
+        """(b, s, d) -> (b, s, d) in x.dtype; trains stand-alone (one autograd node over ``vit_train.block_forward`` / ``block_backward``,
+        dropout as configured), as the reference's module does (vit_transformer_block.py:106-127)."""
+        from llm_quest_amd.multimodal.vision_transformer import vit_train as T
+
         B, S, d = x.shape
-        x2 = x.reshape(B * S, d).contiguous()
-        x2 = x2 if x2.dtype == F32 else K.cast(x2, F32)
-        return self.run(x2, B, S).view(B, S, d)
+
+        def fwd(t):
+            y, saved = T.block_forward(self, T.as_f32_rows(t), B, S, self.training)
+            return T.like(y, t, d), saved
+
+        def bwd(saved, dy):
+            return T.like(T.block_backward(self, saved, T.as_f32_rows(dy), B, S), dy, d)
+
+        return T.run_piece(self, x, fwd, bwd)

@@ -71,6 +71,71 @@ def kv_append_dev(k_rows, v_rows, kc, vc, write_pos_dev):
            kc.shape[1], L.ptr(write_pos_dev))
 
 
+def _lin(decode):
+    return gemv if decode else (lambda a, w, residual=None: K.gemm(L.GEMM_NT, a, w, residual=residual))
+
+
+def cached_positions(kv_cache, B, S, device, position_ids=None, reference_default=False):
+    """int32 [B*S] rotary positions of the new tokens.  ``reference_default``: with ``position_ids=None`` RoPE.apply rotates by
+    0..S-1 whatever the cache holds (common/rope.py:229-232) -- the stand-alone modules keep that; ``Qwen3Model`` continues at ``start_pos``."""
+    if position_ids is not None:
+        return position_ids.to(device=device, dtype=torch.int32).expand(B, S).reshape(-1).contiguous()
+    start = 0 if reference_default else kv_cache.start_pos
+    return (start + torch.arange(S, dtype=torch.int32, device=device)).repeat(B)
+
+
+def cached_key_mask(attn_mask, kv_cache, B, S, device):
+    if attn_mask is None:
+        return None
+    km = attn_mask.to(device=device, dtype=torch.uint8).contiguous()
+    if km.shape[0] != B or km.shape[1] < kv_cache.start_pos + S:
+        raise ValueError(f"attn_mask must cover the cached sequence: (b, >= {kv_cache.start_pos + S}), got {tuple(km.shape)}")
+    return km
+
+
+@torch.no_grad()
+def attention_cached(att, h1, B, S, cos, sin, pos, km, kv_cache, dev_state=None, residual=None):
+    """``GroupedQueryAttention.forward(..., kv_cache=...)`` (reference qwen3_attention.py:91-148) on rows h1 bf16 [B*S, d_in]: fused QKV
+    projection, QK-norm + RoPE, cache append, attention over the cache (prefill: flash attention over the prompt; decode: one query row per
+    head), output projection (+ residual)."""
+    arena = ops.arena_for(att)
+    Hq, Hkv, D = att.num_heads, att.num_kv_groups, att.head_dim
+    decode = kv_cache.start_pos > 0
+    if decode and S != 1:
+        raise NotImplementedError("with a filled KV cache one new token per sequence is decoded (q_seq_len 1, generate.py:139-148)")
+    lin = _lin(decode)
+    qkv = lin(h1, arena.fused(att.w_queries.weight, att.w_values.weight))
+    q, k, _ = K.qknorm_rope_fwd(qkv, att.q_norm.weight, att.k_norm.weight, cos, sin, pos, Hq, Hkv, D)
+    v = qkv[:, (Hq + Hkv) * D :]
+    if dev_state is not None:  # graph replay: position and length are read on the device, the cache object is advanced by the caller
+        _, write_pos, len_dev = dev_state
+        kc, vc = kv_cache.keys_cache[att.layer_idx], kv_cache.values_cache[att.layer_idx]
+        kv_append_dev(k, v, kc, vc, write_pos)
+        ctx = attn_decode(q, kc, vc, kc.shape[1], Hq, Hkv, D, key_mask=km, scale=att.att_scaling, len_dev=len_dev)
+    elif decode:
+        kc, vc, end = kv_cache.append_rows(k, v, att.layer_idx, B, S)
+        ctx = attn_decode(q, kc, vc, end, Hq, Hkv, D, key_mask=km, scale=att.att_scaling)
+    else:
+        kv_cache.append_rows(k, v, att.layer_idx, B, S)
+        ctx, _ = K.attn_fwd(q, k, v, B, S, Hq, Hkv, D, key_mask=None if km is None else km[:, :S].contiguous(), causal=True, scale=att.att_scaling)
+    return lin(ctx, att.out_proj.weight, residual=residual)
+
+
+@torch.no_grad()
+def block_cached(blk, h, B, S, cos, sin, pos, km, kv_cache, dev_state=None):
+    """``TransformerBlock.forward(..., kv_cache=...)`` (reference qwen3_transformer_block.py:91-112) on the bf16 residual rows h [B*S, d]."""
+    arena = ops.arena_for(blk)
+    ffn = blk.ffn
+    decode = kv_cache.start_pos > 0
+    lin = _lin(decode)
+    h1, _ = K.rmsnorm_fwd(h, blk.norm1.weight, want_rstd=False)
+    h = attention_cached(blk.att, h1, B, S, cos, sin, pos, km, kv_cache, dev_state, residual=h)
+    h2, _ = K.rmsnorm_fwd(h, blk.norm2.weight, want_rstd=False)
+    gu = lin(h2, arena.fused(ffn.lin1.weight, ffn.lin_gate.weight))
+    return lin(K.swiglu_fwd(gu, ffn.lin1.weight.shape[0]), ffn.lin2.weight, residual=h)
+
+
+
 @torch.no_grad()
 def qwen3_forward_cached(model, x, kv_cache, attn_mask=None, position_ids=None, input_embedded=False, dev_state=None):
     """Logits (b, s, vocab) of ``Qwen3Model`` with ``kv_cache`` updated in place (reference: qwen3_model.py:60-94).
@@ -104,29 +169,9 @@ def qwen3_forward_cached(model, x, kv_cache, attn_mask=None, position_ids=None, 
         km = attn_mask.to(device=h.device, dtype=torch.uint8).contiguous()
         if km.shape[0] != B or km.shape[1] < start + S:
             raise ValueError(f"attn_mask must cover the cached sequence: (b, >= {start + S}), got {tuple(km.shape)}")
-    lin = gemv if decode else (lambda a, w, residual=None: K.gemm(L.GEMM_NT, a, w, residual=residual))
     for blk in model.trf_blocks:
-        arena = ops.arena_for(blk)
-        att, ffn = blk.att, blk.ffn
-        Hq, Hkv, D = att.num_heads, att.num_kv_groups, att.head_dim
-        h1, _ = K.rmsnorm_fwd(h, blk.norm1.weight, want_rstd=False)
-        qkv = lin(h1, arena.fused(att.w_queries.weight, att.w_values.weight))
-        q, k, _ = K.qknorm_rope_fwd(qkv, att.q_norm.weight, att.k_norm.weight, model.cos, model.sin, pos, Hq, Hkv, D)
-        v = qkv[:, (Hq + Hkv) * D :]
-        if dev_state is not None:  # graph replay: position and length are read on the device, the cache object is advanced by the caller
-            kc, vc = kv_cache.keys_cache[att.layer_idx], kv_cache.values_cache[att.layer_idx]
-            kv_append_dev(k, v, kc, vc, write_pos)
-            ctx = attn_decode(q, kc, vc, kc.shape[1], Hq, Hkv, D, key_mask=km, scale=att.att_scaling, len_dev=len_dev)
-        elif decode:
-            kc, vc, end = kv_cache.append_rows(k, v, att.layer_idx, B, S)
-            ctx = attn_decode(q, kc, vc, end, Hq, Hkv, D, key_mask=km, scale=att.att_scaling)
-        else:
-            kv_cache.append_rows(k, v, att.layer_idx, B, S)
-            ctx, _ = K.attn_fwd(q, k, v, B, S, Hq, Hkv, D, key_mask=None if km is None else km[:, :S].contiguous(), causal=True, scale=att.att_scaling)
-        h = lin(ctx, att.out_proj.weight, residual=h)
-        h2, _ = K.rmsnorm_fwd(h, blk.norm2.weight, want_rstd=False)
-        gu = lin(h2, arena.fused(ffn.lin1.weight, ffn.lin_gate.weight))
-        h = lin(K.swiglu_fwd(gu, ffn.lin1.weight.shape[0]), ffn.lin2.weight, residual=h)
+        h = block_cached(blk, h, B, S, model.cos, model.sin, pos, km, kv_cache, dev_state)
+    lin = _lin(decode)
     hn, _ = K.rmsnorm_fwd(h, model.final_norm.weight, want_rstd=False)
     return lin(hn, model.out_head.weight).view(B, S, -1)
 

@@ -75,10 +75,17 @@ class GroupedQueryAttention(nn.Module):
 
     def forward(self, x, mask, cos, sin, attn_mask=None, kv_cache=None, position_ids=None):
         """x (b, s, d_in); ``mask`` (the dense causal buffer) is accepted for API parity and never read."""
-        if kv_cache is not None:
-            raise NotImplementedError("KV-cache decoding is outside the training hot path (SURVEY.md section 8f)")
         L.require_gpu(x)
         B, S, _ = x.shape
+        if kv_cache is not None:  # inference (reference :117-118): prefill / one-token decode through utils.KVCache, no autograd
+            from llm_quest_amd import ops_decode as OD
+
+            h1 = x.reshape(B * S, -1)
+            h1 = (h1 if h1.dtype == torch.bfloat16 else K.cast(h1.contiguous(), torch.bfloat16)).contiguous()
+            pos = OD.cached_positions(kv_cache, B, S, x.device, position_ids, reference_default=True)
+            km = OD.cached_key_mask(attn_mask, kv_cache, B, S, x.device)
+            y = OD.attention_cached(self, h1, B, S, cos, sin, pos, km, kv_cache)
+            return (y if y.dtype == x.dtype else K.cast(y, x.dtype)).view(B, S, -1)
         rt = ops.make_runtime(B, S, x.device, cos, sin, attn_mask, position_ids)
         if not hasattr(self, "_param_list"):
             object.__setattr__(self, "_param_list", list(self.parameters()))

@@ -73,8 +73,16 @@ class TransformerBlock(nn.Module):
         self.ffn = FFN(cfg)
 
     def forward(self, x, mask, cos, sin, attn_mask=None, kv_cache=None, position_ids=None, _runtime=None):
-        if kv_cache is not None:
-            raise NotImplementedError("KV-cache decoding is outside the training hot path (SURVEY.md section 8f)")
         B, S, _ = x.shape
+        if kv_cache is not None:  # inference (reference qwen3_transformer_block.py:99-100 -> qwen3_attention.py:117-118), no autograd
+            from llm_quest_amd import ops_decode as OD
+
+            L.require_gpu(x)
+            h = x.reshape(B * S, -1)
+            h = (h if h.dtype == torch.bfloat16 else K.cast(h.contiguous(), torch.bfloat16)).contiguous()
+            pos = OD.cached_positions(kv_cache, B, S, x.device, position_ids, reference_default=True)
+            km = OD.cached_key_mask(attn_mask, kv_cache, B, S, x.device)
+            y = OD.block_cached(self, h, B, S, cos, sin, pos, km, kv_cache)
+            return (y if y.dtype == x.dtype else K.cast(y, x.dtype)).view(B, S, -1)
         rt = _runtime if _runtime is not None else ops.make_runtime(B, S, x.device, cos, sin, attn_mask, position_ids)
         return ops.run_block(self, x, rt)

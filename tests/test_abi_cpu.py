@@ -91,3 +91,39 @@ def test_attention_backward_owned_agprs_are_untouched_by_the_compiler(tmp_path):
     bad, seen = mod.audit(str(out))
     assert not bad, bad[:5]
     assert set(seen) == set(mod.OWNED), seen
+
+
+def test_integration_md_stubs_match_the_binding_table():
+    """Every `_lib.<name>.argtypes = [...]` line of INTEGRATION.md (the stubs a reference maintainer would copy) must list exactly the
+    argument types of `_lib.SIGNATURES` -- the doc cannot drift from the header again (round 2: a 16-argument stub of a 17-argument call)."""
+    import ctypes
+
+    from llm_quest_amd import _lib
+
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    letters = {"P": ctypes.c_void_p, "I": ctypes.c_int, "L": ctypes.c_int64, "F": ctypes.c_float,
+               "ctypes.c_uint64": ctypes.c_uint64, "U": ctypes.c_uint64}
+    stubs = re.findall(r"_lib\.(mi355_\w+)\.argtypes\s*=\s*\[(.*?)\]", text)
+    assert len(stubs) >= 4, "INTEGRATION.md lost its ctypes stubs"
+    for name, body in stubs:
+        assert name in _lib.SIGNATURES, f"INTEGRATION.md binds {name}, which the library does not declare"
+        doc = [letters[a.strip()] for a in body.split(",") if a.strip()]
+        assert doc == list(_lib.SIGNATURES[name]), f"INTEGRATION.md stub of {name}: {len(doc)} args vs {len(_lib.SIGNATURES[name])} in the binding table"
+    # call sites in the doc pass as many arguments as the stub declares
+    for name, body in stubs:
+        m = re.search(r"_lib\." + name + r"\((.*?)\)\)", text, flags=re.S)
+        if not m:
+            continue
+        depth, nargs, cur = 0, 0, ""
+        for ch in m.group(1):
+            if ch in "([":
+                depth += 1
+            elif ch in ")]":
+                depth -= 1
+            if ch == "," and depth == 0:
+                nargs += 1
+                cur = ""
+            else:
+                cur += ch
+        nargs += 1 if cur.strip() else 0
+        assert nargs == len(_lib.SIGNATURES[name]), f"INTEGRATION.md calls {name} with {nargs} arguments, the ABI takes {len(_lib.SIGNATURES[name])}"

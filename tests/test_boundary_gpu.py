@@ -139,3 +139,122 @@ def test_vision_attention_and_ffn_forward_alone(golden):
     # bf16 input gives a bf16 result, eval / no_grad works
     with torch.no_grad():
         assert blk.ffn(x.detach().to(BF16)).dtype == BF16
+
+
+# ------------------------------------------------------------------------------------------- ViT sub-modules, stand-alone (row b)
+def _vit(golden):
+    from llm_quest_amd.multimodal.vision_transformer.vit_model import ViTModel
+    from oracle.gen_golden import TINY_VIT
+
+    t = golden("vit_tiny")
+    m = ViTModel(dict(TINY_VIT))
+    m.load_state_dict(sub_dict(t, "sd."))
+    return t, m.cuda().train(), TINY_VIT
+
+
+def test_vit_submodule_forwards_compose_to_the_reference_gradients(golden):
+    """PatchEmbedding2D.forward -> + pos_embedding -> ViTTransformerBlock.forward x L -> LayerNorm.forward -> classifier, each module called
+    through its OWN forward (reference vit_model.py:68-89, vit_transformer_block.py:22-31,106-127) as ordinary autograd modules: the
+    composition reproduces the reference model's logits, loss and every parameter gradient of the ``vit_tiny`` fixture."""
+    t, m, cfg = _vit(golden)
+    img, y = t["in.image"].cuda(), t["in.labels"].cuda()
+    h = m.patch_embedding(img)
+    assert h.requires_grad and h.shape == (img.shape[0], m.patch_embedding.num_patches + 1, cfg["emb_dim"])
+    h = h + m.pos_embedding
+    for blk in m.transformer_blocks:
+        h = blk(h)
+        assert h.requires_grad and h.dtype == F32
+    hn = m.final_ln(h)
+    assert rel_l2(hn, t["out.hidden"]) < 1e-2
+    logits = torch.nn.functional.linear(hn[:, 0], m.classifier.weight, m.classifier.bias)  # 10 x 64: the test's own glue, not the product path
+    assert rel_l2(logits, t["out.logits"]) < 2e-2
+    loss = torch.nn.functional.cross_entropy(logits.float(), y)
+    assert abs(float(loss) - float(t["out.loss"])) / float(t["out.loss"]) < 5e-3
+    loss.backward()
+    ref = sub_dict(t, "grad.")
+    for name, p in m.named_parameters():
+        assert p.grad is not None, name
+        err = float((p.grad.double().cpu() - ref[name].double()).norm())
+        assert err <= 3e-2 * float(ref[name].double().norm()) + 2e-4, f"{name}: |err| {err:.3e}, |ref| {float(ref[name].norm()):.3e}"
+
+
+def test_vit_attention_ffn_layernorm_gelu_train_stand_alone(golden):
+    """ViTMultiHeadAttention / FFN / LayerNorm / GELU on their own (vit_attention.py:44-91, vit_transformer_block.py:22-67): forward, input
+    gradient and every parameter gradient against the oracle's fp32 restatement on the same weights (3e-2 = bf16 MFMA operands)."""
+    from oracle import models, ops
+
+    t, m, cfg = _vit(golden)
+    blk = m.transformer_blocks[1]
+    sd = {k: v.detach().float().cpu().requires_grad_(True) for k, v in blk.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 17, cfg["emb_dim"], generator=g)
+    gy = torch.randn(3, 17, cfg["emb_dim"], generator=g)
+
+    def check(mod, pfx, out, xg, ref_out, xr):
+        assert rel_l2(out, ref_out) < 2e-2, pfx
+        assert rel_l2(xg, xr.grad) < 3e-2, pfx + " dx"
+        # w_keys.bias has a mathematically ZERO gradient (softmax ignores a constant key offset): absolute slack on the scale of the module's
+        # other gradients (bf16 rounding of dS), relative tolerance elsewhere
+        scale = max(float(sd[pfx + n].grad.double().norm()) for n, _ in mod.named_parameters())
+        for name, p in mod.named_parameters():
+            r = sd[pfx + name].grad
+            err = float((p.grad.double().cpu() - r.double()).norm())
+            assert err <= 3e-2 * float(r.double().norm()) + 2e-3 * scale, f"{pfx}{name}: {err:.3e} vs {float(r.norm()):.3e}"
+
+    # attention
+    xa = x.cuda().requires_grad_(True)
+    out = blk.att(xa)
+    assert out.requires_grad and out.shape == x.shape
+    out.backward(gy.cuda())
+    xr = x.clone().requires_grad_(True)
+    ro = models.vit_attention(sd, "att.", xr, cfg["n_heads"])
+    ro.backward(gy)
+    check(blk.att, "att.", out, xa.grad, ro, xr)
+    # FFN
+    xa = x.cuda().requires_grad_(True)
+    out = blk.ffn(xa)
+    out.backward(gy.cuda())
+    xr = x.clone().requires_grad_(True)
+    ro = torch.nn.functional.linear(ops.gelu_erf(torch.nn.functional.linear(xr, sd["ffn.layers.0.weight"], sd["ffn.layers.0.bias"])),
+                                    sd["ffn.layers.2.weight"], sd["ffn.layers.2.bias"])
+    ro.backward(gy)
+    check(blk.ffn, "ffn.", out, xa.grad, ro, xr)
+    # LayerNorm (sigma + eps)
+    xa = x.cuda().requires_grad_(True)
+    out = blk.ln_1(xa)
+    out.backward(gy.cuda())
+    xr = x.clone().requires_grad_(True)
+    ro = ops.layernorm_sigma_eps(xr, sd["ln_1.scale"], sd["ln_1.shift"])
+    ro.backward(gy)
+    assert rel_l2(out, ro) < 1e-5 and rel_l2(xa.grad, xr.grad) < 1e-4
+    assert rel_l2(blk.ln_1.scale.grad, sd["ln_1.scale"].grad) < 1e-4 and rel_l2(blk.ln_1.shift.grad, sd["ln_1.shift"].grad) < 1e-4
+    # GELU (bf16 arithmetic in the kernel), an odd element count takes the padded path
+    from llm_quest_amd.multimodal.vision_transformer.vit_transformer_block import GELU
+
+    xo = torch.randn(5, 7, generator=g)
+    xa = xo.cuda().requires_grad_(True)
+    out = GELU()(xa)
+    out.backward(torch.ones_like(out))
+    xr = xo.to(BF16).float().requires_grad_(True)
+    ro = ops.gelu_erf(xr)
+    ro.backward(torch.ones_like(ro))
+    assert out.dtype == F32 and rel_l2(out, ro) < 6e-3 and rel_l2(xa.grad, xr.grad) < 6e-3
+    # eval / no-grad: nothing is kept, nothing requires grad
+    with torch.no_grad():
+        assert not blk(x.cuda()).requires_grad
+
+
+def test_rope_apply_positions_outside_the_table_do_not_read_out_of_bounds():
+    """A position >= ctx_len (or negative) is an index error upstream (common/rope.py:225-227).  The kernel has no host sync to raise from, so
+    such a row comes out as NaN -- loudly wrong -- and nothing outside the coefficient table is read; rows with valid positions are untouched."""
+    from llm_quest_amd.common.rope import RoPE
+
+    cos, sin = RoPE.compute_angles(10_000, 16, 8)
+    x = torch.randn(2, 3, 4, 16).to(BF16)
+    pid = torch.tensor([[0, 3, 7, 2], [1, 8, -1, 5]])
+    y = RoPE.apply(x.cuda(), cos.cuda(), sin.cuda(), pid.cuda()).float().cpu()
+    ok = torch.ones(2, 4, dtype=torch.bool)
+    ok[1, 1] = ok[1, 2] = False
+    assert torch.isnan(y[1, :, 1]).all() and torch.isnan(y[1, :, 2]).all()
+    good = RoPE.apply(x, cos, sin, pid.clamp(0, 7)).float()
+    assert torch.equal(y.permute(0, 2, 1, 3)[ok], good.permute(0, 2, 1, 3)[ok])

@@ -25,3 +25,27 @@ def test_multipliers_are_reproducible_and_shaped():
     m = OD.attention_multiplier(2, 2, 9, 0.5, 1, 0)
     assert m.shape == (2, 2, 9, 9) and 0.3 < float((m > 0).float().mean()) < 0.7
     assert OD.threshold(0.0) == 0 and OD.threshold(0.5) == 1 << 31
+
+
+def test_dropout_stream_follows_torch_generator_state():
+    """``nn.Dropout`` restarts its masks when the SAME seed is set again and resumes them from ``set_rng_state``; the (seed, offset) pairs
+    of the HIP dropout sites must do the same (llm_quest_amd/rng.py)."""
+    import torch
+
+    from llm_quest_amd import rng
+
+    rng.follow_torch()
+    torch.manual_seed(1234)
+    a = [rng.draw() for _ in range(4)]
+    torch.manual_seed(1234)
+    b = [rng.draw() for _ in range(4)]
+    assert a == b and len({o for _, o in a}) == 4 and all(s == 1234 for s, _ in a)
+    state = torch.get_rng_state()
+    c = [rng.draw() for _ in range(2)]
+    torch.set_rng_state(state)
+    assert [rng.draw() for _ in range(2)] == c
+    torch.manual_seed(1235)
+    assert rng.draw() != a[0]
+    rng.manual(7, 5)
+    assert [rng.draw(), rng.draw()] == [(7, 5), (7, 6)]
+    rng.follow_torch()

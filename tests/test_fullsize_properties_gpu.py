@@ -239,6 +239,93 @@ def test_full_size_step_matches_the_cpu_oracle():
         assert err <= 1.5 * floor + 2e-3, f"{name}: vs fp32 oracle {err:.3e}, bf16 oracle floor {floor:.3e}"
 
 
+def _oracle_compare(mine, l_mine, oracle_run):
+    """Loss within 1e-3 of the oracle's fp32-evaluated loss; every picked gradient within 1.5x the oracle's own bf16-vs-fp32 distance."""
+    l_low, g_low = oracle_run(True)
+    l_fp32, g_fp32 = oracle_run(False)
+    assert abs(l_mine - l_fp32) / l_fp32 < 1e-3, (l_mine, l_fp32, l_low)
+    for name, twin in g_fp32.items():
+        floor = float((g_low[name].double() - twin.double()).norm() / twin.double().norm())
+        err = float((mine[name].double() - twin.double()).norm() / twin.double().norm())
+        assert err <= 1.5 * floor + 2e-3, f"{name}: vs fp32 oracle {err:.3e}, low-precision oracle floor {floor:.3e}"
+
+
+def test_full_size_qwen3_text_step_matches_the_cpu_oracle():
+    """BASELINE configs[2] at FULL size against the CPU oracle: Qwen3-0.6B, S = 1024, B = 1, ``global_loss`` on the shifted ids (engine.py:50-72).
+    The tiny fixtures never reach 16 heads x 28 layers, S = 1024 or V = 151 936; a deterministic but wrong kernel at these shapes would pass the
+    property tests below -- not this one.  Picks: first / last block ``w_queries``, a ``lin2``, the tied embedding / head matrix."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import bench
+    from llm_quest_amd.config import qwen3_config_creator
+    from llm_quest_amd.engine import global_loss
+    from llm_quest_amd.qwen.qwen3.qwen3_model import Qwen3Model
+    from oracle import models, ops
+
+    torch.set_num_threads(min(16, bench.usable_cores()))
+    cfg = dict(qwen3_config_creator("0.6B"), context_length=1024)
+    torch.manual_seed(5)
+    with torch.device("cuda"):
+        m = Qwen3Model(cfg).train()
+    g = torch.Generator().manual_seed(21)
+    ids = torch.randint(0, V, (1, 1024), generator=g)
+    tgt = torch.roll(ids, -1, 1)
+    loss = global_loss(m(ids.cuda()), tgt.cuda(), m)
+    loss.backward()
+    picks = ["trf_blocks.0.att.w_queries.weight", "trf_blocks.27.att.w_queries.weight", "trf_blocks.13.ffn.lin2.weight", "emb_dict.weight"]
+    named = dict(m.named_parameters())
+    mine = {n: named[n].grad.float().cpu() for n in picks}
+    skip = ("mask", "cos", "sin", "out_head.weight")
+
+    def oracle_run(low):
+        dtype = BF16 if low else F32
+        sd = {k: v.detach().cpu().to(dtype).requires_grad_(True) for k, v in m.state_dict().items() if k not in skip}
+        sd["out_head.weight"] = sd["emb_dict.weight"]
+        logits = models.qwen3_forward(sd, dict(cfg, dtype=dtype), ids)
+        l32 = ops.lm_loss(logits.float(), tgt)
+        l32.backward()
+        return float(l32), {n: sd[n].grad.float() for n in picks}
+
+    _oracle_compare(mine, float(loss), oracle_run)
+
+
+def test_full_size_vit_base_step_matches_the_cpu_oracle():
+    """BASELINE configs[1] at FULL size against the CPU oracle: ViT-Base/16, 224 x 224, B = 2, ``drop_rate`` 0, class head + CE.  The oracle's low
+    precision run is the reference under ``torch.autocast(bf16)`` (what this path's dtype flow reproduces), its twin plain fp32.
+    Picks: every third block's ``w_keys``, the patch projection, the classifier."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import bench
+    from llm_quest_amd.config import VIT_BASE_CONFIG
+    from llm_quest_amd.engine import _cross_entropy
+    from llm_quest_amd.multimodal.vision_transformer.vit_model import ViTModel
+    from oracle import models
+
+    torch.set_num_threads(min(16, bench.usable_cores()))
+    cfg = dict(VIT_BASE_CONFIG, drop_rate=0.0)
+    torch.manual_seed(6)
+    with torch.device("cuda"):
+        m = ViTModel(cfg).train()
+    g = torch.Generator().manual_seed(22)
+    img = torch.randn(2, 3, 224, 224, generator=g)
+    y = torch.randint(0, cfg["num_classes"], (2,), generator=g)
+    loss = _cross_entropy(m(img.cuda()), y.cuda())
+    loss.backward()
+    picks = [f"transformer_blocks.{i}.att.w_keys.weight" for i in range(0, cfg["n_layers"], 3)] + ["patch_embedding.conv_proj.weight", "classifier.weight"]
+    named = dict(m.named_parameters())
+    mine = {n: named[n].grad.float().cpu() for n in picks}
+
+    def oracle_run(low):
+        sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+        with torch.autocast("cpu", dtype=BF16, enabled=low):
+            logits = models.vit_forward(sd, cfg, img)
+        l32 = torch.nn.functional.cross_entropy(logits.float(), y)
+        l32.backward()
+        return float(l32), {n: sd[n].grad.float() for n in picks}
+
+    _oracle_compare(mine, float(loss), oracle_run)
+
+
 def test_baseline_size_properties_config2_vit_base():
     """BASELINE configs[1]: ViT-Base/16 224x224 fwd+bwd at B = 64 (full size): loss ~ ln(100) at init, finite gradients, bit-identical
     repeat (no atomics anywhere on this path)."""

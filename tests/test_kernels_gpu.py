@@ -375,11 +375,11 @@ def _attn_ref(q, k, v, B, S, Hq, Hkv, D, key_mask, causal):
     k4 = k.double().view(B, S, Hkv, D).transpose(1, 2).repeat_interleave(Hq // Hkv, dim=1)
     v4 = v.double().view(B, S, Hkv, D).transpose(1, 2).repeat_interleave(Hq // Hkv, dim=1)
     s = (q4 @ k4.mT) * D ** -0.5
-    blocked = torch.zeros(B, 1, S, S, dtype=torch.bool)
+    blocked = torch.zeros(B, 1, S, S, dtype=torch.bool, device=q.device)
     if causal:
-        blocked = blocked | torch.triu(torch.ones(S, S, dtype=torch.bool), 1)
+        blocked = blocked | torch.triu(torch.ones(S, S, dtype=torch.bool, device=q.device), 1)
     if key_mask is not None:
-        blocked = blocked | ~key_mask.bool()[:, None, None, :]
+        blocked = blocked | ~key_mask.bool().to(q.device)[:, None, None, :]
     s = s.masked_fill(blocked, float(torch.finfo(torch.bfloat16).min) / 2)
     p = torch.softmax(s, dim=-1)
     return (p @ v4).transpose(1, 2).reshape(B * S, Hq * D), p
@@ -455,6 +455,47 @@ def test_attention_backward_scratch_form_equals_recompute_form(K, B, S, Hq, Hkv,
     with pytest.raises(RuntimeError, match="workspace"):
         L.call("mi355_attn_bwd_ws", B, S, Hq, Hkv, D, L.ptr(q), q.stride(0), L.ptr(k), k.stride(0), L.ptr(v), v.stride(0), L.ptr(o), o.stride(0), L.ptr(do), do.stride(0),
                L.ptr(lse), L.ptr(delta), L.ptr(dq), dq.stride(0), L.ptr(dk), dk.stride(0), L.ptr(dv), dv.stride(0), L.ptr(km), int(causal), D ** -0.5, L.ptr(ws), need - 16)
+
+
+def test_attention_backward_scratch_is_capped_and_falls_back_to_the_recompute_form(K, monkeypatch):
+    """The dS scratch grows with S^2; above the cap (MI355_ATTN_DS_SPILL_MAX_MB) -- or without memory for it -- ``attn_bwd`` must take the
+    O(S)-memory recompute form instead of allocating: S = 4096, B = 4 with the cap lowered under the 1 GiB this shape asks for.  Checked against
+    fp64 (evaluated on the GPU by torch: 1 GiB of scores per tensor) and against the scratch form, bit for bit."""
+    B, S, Hq, Hkv, D = 4, 4096, 2, 1, 128
+    g = torch.Generator().manual_seed(11)
+    q, k, v, do = (dev(torch.randn(B * S, w * D, generator=g).to(BF16)) for w in (Hq, Hkv, Hkv, Hq))
+    o, lse = K.attn_fwd(q, k, v, B, S, Hq, Hkv, D, causal=True)
+    from llm_quest_amd import _lib as L
+
+    need = L.load().mi355_attn_bwd_workspace_bytes(B, S, Hq, D)
+    assert need == B * Hq * S * S * 2
+    K.release_attention_scratch()
+    monkeypatch.setattr(K, "_ATTN_DS_SPILL_MAX", need - 1)
+    before = dict(K.attn_bwd_form)
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    torch.cuda.reset_peak_memory_stats()
+    dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+    K.attn_bwd(q, k, v, o, do, lse, B, S, Hq, Hkv, D, dq, dk, dv, causal=True)
+    torch.cuda.synchronize()
+    assert K.attn_bwd_form["recompute"] == before["recompute"] + 1 and K.attn_bwd_form["spill"] == before["spill"]
+    assert torch.cuda.max_memory_allocated() - base < need // 4 and not K._ATTN_WS  # nothing of the scratch's size was allocated or cached
+    monkeypatch.setattr(K, "_ATTN_DS_SPILL_MAX", need)
+    dq2, dk2, dv2 = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+    K.attn_bwd(q, k, v, o, do, lse, B, S, Hq, Hkv, D, dq2, dk2, dv2, causal=True)
+    assert K.attn_bwd_form["spill"] == before["spill"] + 1 and len(K._ATTN_WS) == 1
+    assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)
+    # a much smaller request on the same stream replaces the big buffer instead of pinning it
+    K.attn_bwd(q[: 2 * 128], k[: 2 * 128], v[: 2 * 128], o[: 2 * 128], do[: 2 * 128], lse[:2, :, :128].contiguous(), 2, 128, Hq, Hkv, D,
+               dq2[: 2 * 128], dk2[: 2 * 128], dv2[: 2 * 128], causal=True)
+    assert max(w.numel() for w in K._ATTN_WS.values()) < need // 4
+    K.release_attention_scratch()
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q, k, v))
+    o_ref, _ = _attn_ref(qr, kr, vr, B, S, Hq, Hkv, D, None, True)
+    o_ref.backward(do.double())
+    assert rel_l2(o, o_ref) < 4e-3
+    for name, got, ref in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
+        assert rel_l2(got, ref) < 8e-3, name
 
 
 def test_attention_strided_views(K):

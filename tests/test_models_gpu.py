@@ -513,3 +513,52 @@ def test_cross_entropy_rejects_out_of_range_targets_loudly():
     a, _ = K.cross_entropy(logits.clone(), good, want_grad=True, grad_scale=torch.ones(1, device="cuda"), inplace=True)
     b, _ = K.cross_entropy(logits.clone(), good, want_grad=True, grad_scale=torch.ones(1, device="cuda"), inplace=False)
     assert torch.equal(a, b)
+
+
+def test_hf_checkpoint_loads_into_a_model_already_on_the_gpu(golden, tmp_path):
+    """Row f2 on the device (reference qwen3_weight_loading.py:70-103): an HF-named ``.safetensors`` written from the ``qwen3_tiny`` fixture's
+    state dict is loaded by ``load_qwen3_weights`` into a model that ALREADY lives on cuda (its parameters are views of the per-block arenas the
+    fused QKV / gate-up GEMMs read; ``load_state_dict`` has to land in them), and the loaded model must reproduce the fixture's logits.  A run
+    before the load (random init) and a second load over the first prove the arenas really change."""
+    from safetensors.torch import save_file
+
+    from llm_quest_amd.qwen.qwen3.qwen3_model import Qwen3Model
+    from llm_quest_amd.qwen.qwen3.qwen3_weight_loading import get_remapping_rules, load_qwen3_weights
+
+    t = golden("qwen3_tiny")
+    cfg = dict(TINY_QWEN)
+    sd = sub_dict(t, "sd.")
+    inverse = [(ours, hf) for hf, ours in get_remapping_rules(cfg)]
+    hf = {}
+    for name, w in sd.items():
+        if name in ("mask", "cos", "sin", "out_head.weight"):
+            continue
+        hf_name = name
+        for ours, theirs in inverse:
+            hf_name = hf_name.replace(ours, theirs)
+        hf[hf_name] = w.detach().clone().contiguous()
+    assert "model.layers.1.self_attn.q_proj.weight" in hf and "model.embed_tokens.weight" in hf
+    path = tmp_path / "model.safetensors"
+    save_file(hf, str(path))
+    torch.manual_seed(99)
+    m = Qwen3Model(cfg).cuda().eval()
+    ids, km = t["in.ids"].cuda(), t["in.key_mask"].bool().cuda()
+    with torch.no_grad():
+        before = m(ids, attn_mask=km)  # builds the arenas on the device with the random init
+        assert rel_l2(before, t["out.logits"]) > 0.5
+        load_qwen3_weights(m, cfg, source=str(path), verbose=False)
+        assert all(p.is_cuda for p in m.parameters()) and m.out_head.weight is m.emb_dict.weight
+        logits = m(ids, attn_mask=km)
+    floor = rel_l2(t["out.logits"], t["twin.logits"])
+    mine = rel_l2(logits, t["twin.logits"])
+    assert mine <= 1.5 * floor + 1e-3, f"logits after the HF import vs fp32 twin {mine:.3e}, reference floor {floor:.3e}"
+    for name, p in m.named_parameters():
+        assert torch.equal(p.detach().cpu(), sd[name]), name
+    # and it trains from there: the loaded parameters are the ones the kernels see
+    m.train()
+    from llm_quest_amd.engine import global_loss
+
+    loss = global_loss(m(ids, attn_mask=km), t["in.targets"].cuda(), model=m)
+    loss.backward()
+    e = rel_l2(m.trf_blocks[0].att.w_queries.weight.grad, t["grad.trf_blocks.0.att.w_queries.weight"])
+    assert e < 6e-2, e
