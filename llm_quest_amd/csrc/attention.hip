@@ -11,282 +11,9 @@
 // Masking follows the reference (qwen3_attention.py:130-142): masked scores take a FINITE fill value, so a row
 // whose visible keys are all masked degenerates to uniform attention over all S keys exactly as upstream; keys
 // beyond S do not exist and get -inf.  Scores stay in fp32 (the reference rounds them to bf16 twice).
-#include <type_traits>
-
-#include "common.h"
+#include "attn_common.h"
 
 namespace {
-
-constexpr float MASK_T = -2.0e38f;  // finite "masked" score in the log2 domain
-constexpr float LOG2E = 1.4426950408889634f;
-constexpr float LN2 = 0.6931471805599453f;
-constexpr unsigned OOB = 0x80000000u;
-constexpr int ATTN_MAX_TILES = 512;  // key-mask words kept in LDS by the backward dQ pass: S <= 64 * 512
-
-template <int D>
-struct Cfg {
-    static constexpr int ROWB = D * 2;            // bytes per tile row
-    static constexpr int CH = ROWB / 16;          // 16-byte chunks per row
-    static constexpr int KS = D / 16;             // k-steps of the QK^T product
-    static constexpr int DT = D / 32;             // 32-row tiles of O^T
-    static constexpr int TILE = 64 * ROWB;        // bytes of one 64-key tile
-    static constexpr int RPP = 1024 / ROWB;       // rows per 1-KiB DMA piece
-    static constexpr int PPW = TILE / 1024 / 4;   // pieces per wave per tile
-    // D = 128: ONE image serves both the row reads and the transposing reads of the backward kernels (half the LDS-DMA)
-    static constexpr bool UNI = (D == 128);
-};
-
-// swizzles (chunk index XOR) -- row-read image (32x32 A-operand pattern) and transposed-read image
-template <int D> __device__ __forceinline__ int swz_row(int chunk, int row) { return D == 128 ? chunk ^ (row & 15) : chunk ^ ((row >> 1) & 7); }
-template <int D> __device__ __forceinline__ int swz_tr(int chunk, int row) { return D == 128 ? chunk ^ ((row & 3) << 2) : chunk ^ (((row >> 1) & 1) << 2); }
-
-// unified image (256-byte rows = one bank row, 16 chunks): chunk ^ f(row) with f = the two 2-bit fields of row&15 swapped.
-// f is a bijection over any 16 aligned rows (ds_read_b128 of 16 lanes = 16 rows at one chunk: 16 distinct slots), and its
-// high field follows row&3 (a transposing read's 16 lanes = 4 consecutive rows x 2 adjacent chunks x 2 halves: 8 distinct slots).
-__device__ __forceinline__ int swz_uni(int chunk, int row) { return chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)); }
-constexpr int IMG_ROW = 0, IMG_TR = 1, IMG_UNI = 2;
-
-// DMA one 64-row tile (rows = tokens tok0.., D contiguous elements at column col0) into LDS; IMG picks the swizzle
-template <int D, int IMG>
-__device__ __forceinline__ void dma_tile(const bf16_t* base, int64_t ld, int rows_valid, char* lds, int wave, int lane) {
-    using C = Cfg<D>;
-    auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base), 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-    for (int j = 0; j < C::PPW; ++j) {
-        const int pi = wave * C::PPW + j;
-        const int row = pi * C::RPP + lane / C::CH;
-        const int pos = lane % C::CH;
-        const int c = IMG == IMG_UNI ? swz_uni(pos, row) : IMG == IMG_TR ? swz_tr<D>(pos, row) : swz_row<D>(pos, row);
-        const unsigned voff = row < rows_valid ? (unsigned)(row * ld * 2 + c * 16) : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds + pi * 1024), 16, voff, 0, 0, 0);
-    }
-}
-
-// A-operand fragment (32 rows x 16 k) of a row image: row = r0 + (lane&31), k-step ks
-template <int D>
-__device__ __forceinline__ bf16x8 frag_rows(const char* img, int r0, int ks, int lane) {
-    const int row = r0 + (lane & 31);
-    const int chunk = 2 * ks + (lane >> 5);
-    return *reinterpret_cast<const bf16x8*>(img + row * Cfg<D>::ROWB + (swz_row<D>(chunk, row) << 4));
-}
-
-// A-operand fragment of the TRANSPOSE of a tr image: rows of A = 32 columns c0.. of the image, k = image rows in the
-// order the accumulator-as-operand trick needs: element j <-> image row  k0 + 8*(j>>2) + 4*(lane>>5) + (j&3).
-template <int D>
-__device__ __forceinline__ bf16x8 frag_cols(const char* img, int c0, int k0, int lane) {
-    const int g = lane >> 4, q4 = (lane >> 2) & 3, p = lane & 3, h = g >> 1;
-    const int row = k0 + 4 * h + q4;
-    const int col = c0 + 16 * (g & 1) + 4 * p;
-    const char* a = img + row * Cfg<D>::ROWB + (swz_tr<D>(col >> 3, row) << 4) + (p & 1) * 8;
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a));
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a + 8 * Cfg<D>::ROWB));
-    bf16x8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
-}
-
-// ---- precomputed per-lane LDS offsets -----------------------------------------------------------------------------
-// The XOR swizzles above defeat the compiler's immediate-offset folding (it re-derives ~6-10 VALU ops per LDS read, and
-// the attention loops were VALU-bound at 18 VALU per MFMA).  Both fragment addresses factor into
-//     row image:  tile_base + r0*ROWB + ( lane_row ^ (ks << 5) )               lane_row = r*ROWB + ((h ^ swz(r)) << 4)
-//     tr  image:  tile_base + k0*ROWB + lane_col[dt]   (+ 8*ROWB second half)   lane_col[dt] = lane part + ((dt ^ x) << 6)
-// with tile_base / r0 / k0 multiples of 4 KiB resp. ROWB (they never touch bits 4..7, so they commute with the XOR).
-template <int D>
-struct LaneOff {
-    int row;
-    int col[Cfg<D>::DT];
-    int rowu;               // unified image (D = 128 only)
-    int colu[Cfg<D>::DT];
-};
-template <int D>
-__device__ __forceinline__ LaneOff<D> lane_offsets(int lane) {
-    using C = Cfg<D>;
-    LaneOff<D> o;
-    const int r = lane & 31, h = lane >> 5;
-    const int sw = D == 128 ? (r & 15) : ((r >> 1) & 7);
-    o.row = r * C::ROWB + ((h ^ sw) << 4);
-    const int g = lane >> 4, q4 = (lane >> 2) & 3, p = lane & 3;
-    const int x = D == 128 ? q4 : ((q4 >> 1) & 1);
-    const int base = (4 * (g >> 1) + q4) * C::ROWB + ((2 * (g & 1) + (p >> 1)) << 4) + (p & 1) * 8;
-#pragma unroll
-    for (int dt = 0; dt < C::DT; ++dt) o.col[dt] = base + ((dt ^ x) << 6);
-    // unified image: row r -> chunk ^ ((r&3)<<2 | (r>>2)&3); a transposing read touches rows 4*(g>>1) + q4 (+8: low field ^ 2)
-    o.rowu = r * C::ROWB + ((h ^ (((r & 3) << 2) | ((r >> 2) & 3))) << 4);
-    const int baseu = (4 * (g >> 1) + q4) * C::ROWB + (((2 * (g & 1) + (p >> 1)) ^ (g >> 1)) << 4) + (p & 1) * 8;
-#pragma unroll
-    for (int dt = 0; dt < C::DT; ++dt) o.colu[dt] = baseu + ((dt ^ q4) << 6);
-    return o;
-}
-// row-image fragment: vx = (lane_row + image_offset) ^ (ks << 5), imm = r0 * ROWB
-__device__ __forceinline__ bf16x8 lds_frag(const char* smem, int vx, int imm) { return *reinterpret_cast<const bf16x8*>(smem + vx + imm); }
-// tr-image fragment: v = lane_col[dt] + image_offset, imm = k0 * ROWB
-template <int D>
-__device__ __forceinline__ bf16x8 lds_frag_tr(const char* smem, int v, int imm) {
-    const char* a = smem + v + imm;
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a));
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a + 8 * Cfg<D>::ROWB));
-    bf16x8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
-}
-
-// unified-image transposed fragment: v = lane_colu[dt] + image_offset, imm = k0 * ROWB (k0 a multiple of 16); the rows of
-// the second read are 8 further down, where the low swizzle field differs by 2 (byte bit 5)
-template <int D>
-__device__ __forceinline__ bf16x8 lds_frag_tr_uni(const char* smem, int v, int imm) {
-    const char* a = smem + v + imm;
-    const char* a2 = smem + (v ^ 0x20) + imm + 8 * Cfg<D>::ROWB;
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a));
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a2));
-    bf16x8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
-}
-// Transposed fragment read from an asm statement.  hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of the first
-// ds_read_tr16_b64 INTRINSIC that follows an LDS-DMA (it cannot tell the read from the DMA's destination; plain ds_read_b128
-// loads are not affected): with one wave per SIMD that exposes the whole latency of the tile just requested, every trip.
-// An asm read is invisible to that logic -- and to the compiler's lgkmcnt bookkeeping: the two halves stay separate 64-bit
-// values until `tr_wait<N>` (the statement that carries the counted s_waitcnt and names both halves) has run.  LDS returns
-// data in issue order, so N = the LDS operations issued after this fragment's reads (compiler-issued reads in between only
-// make the wait stricter).
-struct TrHalves {
-    bf16x4 lo, hi;
-};
-template <int IMM0, int IMM1>
-__device__ __forceinline__ void tr_issue(TrHalves& f, unsigned a0, unsigned a1) {
-    static_assert(IMM0 >= 0 && IMM1 < 65536, "ds offset field is 16 bits");
-    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%c4\n\tds_read_b64_tr_b16 %1, %3 offset:%c5" : "=&v"(f.lo), "=&v"(f.hi) : "v"(a0), "v"(a1), "i"(IMM0), "i"(IMM1));
-}
-template <int N>
-__device__ __forceinline__ bf16x8 tr_wait(TrHalves& f) {
-    static_assert(N >= 0 && N <= 15, "lgkmcnt field is 4 bits");
-    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.lo), "+v"(f.hi) : "n"(N) : "memory");
-    return __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-// pack accumulator registers 8s..8s+7 to a bf16 B-operand fragment
-__device__ __forceinline__ bf16x8 pack_frag(const f32x16& x, int s) {
-    u32x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = pack_bf2(x[8 * s + 2 * e], x[8 * s + 2 * e + 1]);
-    return __builtin_bit_cast(bf16x8, o);
-}
-
-// B-operand fragments of a [32 rows][D] row-major global matrix (rows on the lane): row = r0 + (lane&31)
-template <int D>
-__device__ __forceinline__ void load_rows_frag(const bf16_t* base, int64_t ld, int row, bool valid, int lane, bf16x8 (&f)[Cfg<D>::KS]) {
-#pragma unroll
-    for (int ks = 0; ks < Cfg<D>::KS; ++ks) {
-        u32x4 v = {0, 0, 0, 0};
-        if (valid) v = *reinterpret_cast<const u32x4*>(base + (int64_t)row * ld + 16 * ks + 8 * (lane >> 5));
-        f[ks] = __builtin_bit_cast(bf16x8, v);
-    }
-}
-
-// ---- registers owned by name in the accumulator file -----------------------------------------------------------------
-// The backward kernels need > 256 registers per lane.  Two things hipcc (ROCm 7.2) does with that were the whole cost of the
-// first version of these kernels: (1) it homes loop-carried MFMA accumulators in VGPRs and copies all 16 registers of a tile
-// into and out of the AGPRs around every MFMA (840 v_accvgpr_* per loop trip of the dK/dV pass); (2) it issues each LDS
-// fragment read immediately in front of the MFMA that consumes it, so with one wave per SIMD every MFMA waits a full LDS
-// latency (~10k cycles per trip for 2k cycles of MFMA).  So here:
-//   * dK^T / dV^T / dQ^T tiles and the register-resident B operands (K, V resp. Q, dO rows) are literal AGPRs at the TOP of
-//     the accumulator file, a[256-OWNED ...], touched only by the statements below.  Every statement lists the whole owned
-//     range as clobbered: that reserves it in the kernel descriptor and keeps compiler values that live across a statement
-//     out of it; hipcc allocates AGPRs for its own purposes from a0 upward and stays below (tools/audit_agpr.py, run by
-//     tests/test_abi_cpu.py, fails the build if a compiler instruction names a register of an owned range).
-//   * every MFMA is a volatile statement with a "memory" clobber, so LDS reads keep their source order relative to the
-//     MFMAs: the kernels issue fragment reads PD MFMAs ahead into a ring of R register slots, and the compiler only adds
-//     the counted lgkmcnt waits.
-#define AGPR_CL_64 "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
-#define AGPR_CL_96 AGPR_CL_64, "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191"
-#define AGPR_CL_128 AGPR_CL_96, "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159"
-#define AGPR_CL_192 AGPR_CL_128, "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"
-#ifndef ATTN_RING
-#define ATTN_RING 8   // fragment-ring slots of the backward kernels
-#define ATTN_PD 6     // fragments requested ahead of the MFMA that consumes them (2 * PD <= 15: lgkmcnt is 4 bits)
-#endif
-#ifndef ATTN_ABL
-#define ATTN_ABL 0  // profiling builds only: 1 = no fragment reads, 2 = no B phase, 4 = no C MFMAs, 8 = no A MFMAs
-#endif
-#define OWNED_ASM(OWNED, ...)                                                     \
-    do {                                                                          \
-        static_assert((OWNED) == 64 || (OWNED) == 96 || (OWNED) == 128 || (OWNED) == 192, "no clobber list of this size"); \
-        if constexpr ((OWNED) == 64) asm volatile(__VA_ARGS__ : AGPR_CL_64, "memory");        \
-        else if constexpr ((OWNED) == 96) asm volatile(__VA_ARGS__ : AGPR_CL_96, "memory");   \
-        else if constexpr ((OWNED) == 128) asm volatile(__VA_ARGS__ : AGPR_CL_128, "memory"); \
-        else asm volatile(__VA_ARGS__ : AGPR_CL_192, "memory");                               \
-    } while (0)
-
-#if ATTN_ABL & 16
-__device__ unsigned long long g_prof[16];
-#define PROF_T() (prof_on ? __builtin_readcyclecounter() : 0ull)
-#define PROF_ADD(i, t0) do { if (prof_on) prof_acc[i] += __builtin_readcyclecounter() - (t0); } while (0)
-#else
-#define PROF_T() 0ull
-#define PROF_ADD(i, t0) do { (void)(t0); } while (0)
-#endif
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (N > 0) {
-        static_for<N - 1>(f);
-        f(std::integral_constant<int, N - 1>{});
-    }
-}
-// owned tile (16 registers from owned offset OFF) += A x B, both operands in VGPRs.
-// NOP (s_nop 1): for a B register written by the VALU instruction just before (v_cvt_pk -> MFMA operand); hipcc pads nothing inside asm.
-template <int OWNED, int OFF, bool NOP = true>
-__device__ __forceinline__ void mfma_owned(const bf16x8& a, const bf16x8& b) {
-    static_assert(OFF % 16 == 0 && OFF + 16 <= OWNED, "tile outside the owned range");
-    constexpr int R0 = 256 - OWNED + OFF;
-    if constexpr (NOP) OWNED_ASM(OWNED, "s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "i"(R0), "i"(R0 + 15));
-    else OWNED_ASM(OWNED, "v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "i"(R0), "i"(R0 + 15));
-}
-// compiler-allocated tile (16 VGPRs: the VALU reads it right after, no accvgpr copies) (+)= A x ownedB, where ownedB is the
-// 4-register B operand at owned offset OFF.  FIRST: start from zero (srcC = 0) instead of accumulating.
-template <int OWNED, int OFF, bool FIRST>
-__device__ __forceinline__ void mfma_ownedB(f32x16& acc, const bf16x8& a) {
-    static_assert(OFF % 4 == 0 && OFF + 4 <= OWNED, "operand outside the owned range");
-    constexpr int R0 = 256 - OWNED + OFF;
-    if constexpr (FIRST) OWNED_ASM(OWNED, "v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(acc) : "v"(a), "i"(R0), "i"(R0 + 3));
-    else OWNED_ASM(OWNED, "v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(acc) : "v"(a), "i"(R0), "i"(R0 + 3));
-}
-// wait states between the last MFMA into a compiler-allocated tile and its first VALU read (16-pass XDL -> read: 18)
-__device__ __forceinline__ void tiles_settle(f32x16& x, f32x16& y) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(x), "+v"(y)); }
-template <int OWNED, int OFF, int COUNT>
-__device__ __forceinline__ void owned_zero() {
-    static_for<COUNT>([&](auto r) { OWNED_ASM(OWNED, "v_accvgpr_write_b32 a[%c0], 0" ::"i"(256 - OWNED + OFF + r.value)); });
-}
-// a 4-register operand (8 bf16) into owned offset OFF
-template <int OWNED, int OFF>
-__device__ __forceinline__ void owned_write4(const bf16x8& v) {
-    const u32x4 w = __builtin_bit_cast(u32x4, v);
-    OWNED_ASM(OWNED, "v_accvgpr_write_b32 a[%c4], %0\n\tv_accvgpr_write_b32 a[%c5], %1\n\tv_accvgpr_write_b32 a[%c6], %2\n\tv_accvgpr_write_b32 a[%c7], %3"
-              ::"v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "i"(256 - OWNED + OFF), "i"(256 - OWNED + OFF + 1), "i"(256 - OWNED + OFF + 2), "i"(256 - OWNED + OFF + 3));
-}
-template <int OWNED>
-__device__ __forceinline__ void owned_settle() { OWNED_ASM(OWNED, "s_nop 15\n\ts_nop 3" ::); }
-template <int OWNED, int R>
-__device__ __forceinline__ float owned_read() {
-    float x;
-    asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(x) : "i"(256 - OWNED + R));
-    return x;
-}
-
-__device__ __forceinline__ int acc_row(int e, int lane) { return (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); }
-
-// ================================================================================================ forward
-// position b of a round-robin-over-XCDs numbering -> position in a numbering where each XCD owns one contiguous chunk: workgroups
-// with adjacent VIRTUAL ids (the query blocks of one head, the two query heads of one kv head) then share an XCD and its L2, so
-// that K / V of a (batch, kv head) come over the fabric once per XCD instead of once per workgroup (FETCH_SIZE, profiles/).
-__device__ __forceinline__ int xcd_chunked(int b, int n) {
-    const int xcd = b & 7, q = n >> 3, r = n & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-}
 
 template <int D>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int B, int S, int Hq, int Hkv, const bf16_t* __restrict__ q, int64_t ldq,
@@ -475,6 +202,237 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int B, int S, int Hq, 
     }
 }
 
+// ================================================================================================ forward, lean softmax
+// The kernel above spends 10.4 vector instructions per MFMA (profiles/r02_pmc_sq_counters.json) and is bound by what its two waves per SIMD can
+// ISSUE, not by the matrix pipe.  This one keeps its shape (4 waves x 32 queries of one head, K / V tiles by LDS-DMA, two workgroups per CU so
+// that one wave's vector work runs under the other's MFMAs) and cuts the softmax to exp2 + add + half a pack + half a max3 per score:
+//   * the scale log2(e) / sqrt(d) is folded into the Q rows once (bf16(q * c): one more rounding of a bf16 operand; the reference rounds the
+//     scores themselves to bf16, twice);
+//   * a row's reference m is the INITIAL ACCUMULATOR of its score products (a 16-register tile holding -m): the MFMA chain delivers s * c - m;
+//   * the reference moves only when a row's scores outgrow it by 2^8 (before anything is accumulated: in either direction); O, l, the tile at
+//     hand and the initial-accumulator tile are then re-based by one factor -- rare, data-dependent, forced explicitly by a test;
+//   * maxima with v_max3 from asm (hipcc canonicalises both operands of every fmaxf on MFMA outputs: three instructions per maximum);
+//   * masks are a 32-bit word per lane and tile applied with v_bfe_i32 + v_bfi_b32, on boundary tiles only;
+//   * rows whose visible keys are ALL padding (reference semantics: uniform attention over all S keys) are known before the first tile -- under the
+//     causal mask they are the queries in front of the first real key of a left-padded batch row -- and get score 0 for every existing key; their
+//     batch rows walk every tile.
+// (An experiment with ONE wave per SIMD, both heads of a kv pair per wave and a hand-placed schedule -- csrc/attention_fwd2.hip -- is kept behind
+// ablation bit 13: its MFMAs hide completely, but a lone wave pays ~10 cycles for every dependent vector instruction and nothing covers its
+// per-block prologue / epilogue: 322 us against this kernel's time at the headline shape)
+constexpr float LEAN_THR = 8.0f;
+constexpr unsigned LEAN_FILL = __builtin_bit_cast(unsigned, MASK_T);
+__device__ __forceinline__ float lean_max3(float m, float x, float y) {
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(x), "v"(y));
+    return m;
+}
+__device__ __forceinline__ float lean_set_if(float x, unsigned word, int e, unsigned fill_bits) {
+    const unsigned sel = (unsigned)__builtin_amdgcn_sbfe((int)word, (unsigned)e, 1u);  // 0 or ~0
+    return __uint_as_float((__float_as_uint(x) & ~sel) | (fill_bits & sel));
+}
+// the 16 accumulator rows of a lane (bits 0-3, 8-11, 16-19, 24-27 of a 32-key word already shifted by 4 * half-wave) gathered into 16 bits
+__device__ __forceinline__ unsigned lean_gather16(unsigned w) { return (w & 0xFu) | ((w >> 4) & 0xF0u) | ((w >> 8) & 0xF00u) | ((w >> 12) & 0xF000u); }
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_fwd_lean_kernel(int B, int S, int Hq, int Hkv, const bf16_t* __restrict__ q, int64_t ldq,
+                                                               const bf16_t* __restrict__ k, int64_t ldk, const bf16_t* __restrict__ v,
+                                                               int64_t ldv, bf16_t* __restrict__ o, int64_t ldo, float* __restrict__ lse,
+                                                               const uint8_t* __restrict__ key_mask, int causal, float scale_log2) {
+    using C = Cfg<D>;
+    causal &= 0xff;
+    __shared__ __attribute__((aligned(16))) char smem[4 * C::TILE];  // 2 stages x (K row image, V tr image)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nqb = (S + 127) / 128;
+    const int vid = xcd_chunked((int)blockIdx.x, (int)gridDim.x);
+    const int qb = nqb - 1 - (vid % nqb);  // heaviest (latest) query blocks first under the causal mask
+    const int bh = vid / nqb;
+    const int hq = bh % Hq, b = bh / Hq;
+    const int hkv = hq / (Hq / Hkv);
+    const int q0 = qb * 128;
+    const int qw = q0 + wave * 32;
+    const int qg = qw + (lane & 31);
+    const bool qvalid = qg < S;
+    const bf16_t* kbase = k + (int64_t)b * S * ldk + (int64_t)hkv * D;
+    const bf16_t* vbase = v + (int64_t)b * S * ldv + (int64_t)hkv * D;
+    const int ntiles_all = (S + 63) / 64;
+
+    // a batch row whose key 0 is padding may hold rows with no visible real key: find its first real key (S: none) and walk every tile
+    bool allt = false;
+    int first_real = 0;
+    if (key_mask) {
+        allt = __builtin_amdgcn_readfirstlane((int)key_mask[(int64_t)b * S]) == 0;
+        if (allt) {
+            first_real = S;
+            for (int t = 0; t < ntiles_all; ++t) {
+                const int kgl = t * 64 + lane;
+                const unsigned long long bits = __ballot(kgl < S && key_mask[(int64_t)b * S + kgl] != 0);
+                if (bits) {
+                    first_real = t * 64 + (int)__builtin_ctzll(bits);
+                    break;
+                }
+            }
+        }
+    }
+    const bool qrow = allt && (causal ? qg < first_real : first_real >= S);
+    const int ntiles = (causal && !allt) ? min(ntiles_all, (q0 + 127) / 64 + 1) : ntiles_all;
+
+    auto issue = [&](int kt, int stage) {
+        char* ks_ = smem + stage * 2 * C::TILE;
+        dma_tile<D, IMG_ROW>(kbase + (int64_t)kt * 64 * ldk, ldk, S - kt * 64, ks_, wave, lane);
+        dma_tile<D, IMG_TR>(vbase + (int64_t)kt * 64 * ldv, ldv, S - kt * 64, ks_ + C::TILE, wave, lane);
+    };
+    const LaneOff<D> lo = lane_offsets<D>(lane);
+    issue(0, 0);  // first tile first, then the query rows: their latencies overlap
+    bf16x8 qf[C::KS];
+    load_rows_frag<D>(q + (int64_t)b * S * ldq + (int64_t)hq * D, ldq, qg, qvalid, lane, qf);
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {  // q * log2(e) / sqrt(d), rounded to bf16 again
+        u32x4 w = __builtin_bit_cast(u32x4, qf[ks]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = pack_bf2(__uint_as_float(w[e] << 16) * scale_log2, __uint_as_float(w[e] & 0xffff0000u) * scale_log2);
+        qf[ks] = __builtin_bit_cast(bf16x8, w);
+    }
+    // key-padding byte of this lane's key in the NEXT tile: loaded one tile ahead so its latency hides behind a whole tile
+    uint8_t mk = (key_mask && lane < S) ? key_mask[(int64_t)b * S + lane] : (uint8_t)0;
+    unsigned tri16 = 0;  // causal mask of a diagonal 32 x 32 sub-tile: bit ee set <=> key row acc_row(ee) lies behind this lane's query
+#pragma unroll
+    for (int ee = 0; ee < 16; ++ee) tri16 |= (acc_row(ee, lane) > (lane & 31) ? 1u : 0u) << ee;
+
+    f32x16 oacc[C::DT], ninit;
+#pragma unroll
+    for (int i = 0; i < C::DT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[i][e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) ninit[e] = 0.f;
+    float mref = 0.f, l = 0.f;
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();
+        if (kt + 1 < ntiles) issue(kt + 1, (kt + 1) & 1);
+        const int koff = (kt & 1) * 2 * C::TILE, voff = koff + C::TILE;
+        // bit per key of this tile: 1 = a real token that exists
+        const int nv = S - kt * 64;
+        unsigned long long kbits = nv >= 64 ? ~0ull : ((1ull << nv) - 1ull);
+        if (key_mask) {
+            kbits &= __ballot(mk != 0);
+            const int kn = (kt + 1) * 64 + lane;
+            mk = kn < S ? key_mask[(int64_t)b * S + kn] : (uint8_t)0;
+        }
+        // a wave whose 32 queries all precede this tile has nothing visible here
+        if (causal && !allt && kt * 64 > qw + 31) continue;
+        int vkx[C::KS], vv[C::DT];
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) vkx[ks] = (lo.row + koff) ^ (ks << 5);
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) vv[dt] = lo.col[dt] + voff;
+        f32x16 sacc[2];
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            sacc[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(smem, vkx[0], st * 32 * C::ROWB), qf[0], ninit, 0, 0, 0);
+#pragma unroll
+            for (int ks = 1; ks < C::KS; ++ks)
+                sacc[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(smem, vkx[ks], st * 32 * C::ROWB), qf[ks], sacc[st], 0, 0, 0);
+        }
+        // masks only on the diagonal / tail / padded tiles (wave-uniform test)
+        if ((kbits != ~0ull) || allt || (causal && kt * 64 + 63 > qw)) {
+            const unsigned long long exist = nv >= 64 ? ~0ull : ((1ull << nv) - 1ull);
+            unsigned m16[2], x16[2];
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const unsigned sh = 4u * (unsigned)(lane >> 5);
+                const unsigned vis = lean_gather16((st ? (unsigned)(kbits >> 32) : (unsigned)kbits) >> sh);
+                x16[st] = lean_gather16((st ? (unsigned)(exist >> 32) : (unsigned)exist) >> sh);
+                const int x = qw - kt * 64 - st * 32;  // the wave's first query against the sub-tile's first key (a multiple of 32): 0 = diagonal
+                const unsigned cz = (!causal || x >= 32) ? 0u : (x == 0 ? tri16 : 0xFFFFu);
+                m16[st] = (~vis & 0xFFFFu) | cz;
+            }
+            const unsigned mall = m16[0] | (m16[1] << 16), eall = x16[0] | (x16[1] << 16);
+            const unsigned mset = qrow ? ~eall : mall;  // -> the fill value
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int ee = 0; ee < 16; ++ee) sacc[st][ee] = lean_set_if(sacc[st][ee], mset, 16 * st + ee, LEAN_FILL);
+            if (allt) {  // rows whose visible keys are all padding: every existing key counts alike
+                const unsigned zset = qrow ? eall : 0u;
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int ee = 0; ee < 16; ++ee) sacc[st][ee] = lean_set_if(sacc[st][ee], zset, 16 * st + ee, 0u);
+            }
+        }
+        // row maxima of the tile (the two half-waves hold the two halves of a query's keys)
+        float t0 = lean_max3(sacc[0][0], sacc[0][1], sacc[0][2]), t1 = lean_max3(sacc[1][0], sacc[1][1], sacc[1][2]);
+#pragma unroll
+        for (int e = 3; e < 15; e += 2) {
+            t0 = lean_max3(t0, sacc[0][e], sacc[0][e + 1]);
+            t1 = lean_max3(t1, sacc[1][e], sacc[1][e + 1]);
+        }
+        float t = lean_max3(t0, t1, sacc[0][15]);
+        t = lean_max3(t, sacc[1][15], __shfl_xor(lean_max3(t, sacc[1][15], sacc[1][15]), 32, 64));
+        // up: always.  Down: only while nothing is accumulated, and never onto the fill value
+        const bool want = t > LEAN_THR || (l == 0.f && t < -LEAN_THR && t > 0.5f * MASK_T);
+        if (__builtin_expect(__any(want), 0)) {
+            const float delta = want ? t : 0.f;
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+            mref += delta;
+            l *= alpha;
+#pragma unroll
+            for (int i = 0; i < C::DT; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float x = sacc[st][e];  // a masked score stays AT the fill value
+                    sacc[st][e] = x < 0.5f * MASK_T ? x : x - delta;
+                }
+            const float nm = -mref;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ninit[e] = nm;
+        }
+        float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                sacc[st][e] = __builtin_amdgcn_exp2f(sacc[st][e]);
+                sacc[st][e + 1] = __builtin_amdgcn_exp2f(sacc[st][e + 1]);
+                ps0 += sacc[st][e];
+                ps1 += sacc[st][e + 1];
+            }
+        l += ps0 + ps1;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 pf = pack_frag(sacc[st], s);
+#pragma unroll
+                for (int dt = 0; dt < C::DT; ++dt)
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr<D>(smem, vv[dt], (st * 32 + 16 * s) * C::ROWB), pf, oacc[dt], 0, 0, 0);
+            }
+    }
+
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    // whole 16-byte pieces: one v_permlane32_swap per word pairs the half-waves' 8-byte pieces of a row
+    bf16_t* orow = o + ((int64_t)b * S + qg) * ldo + (int64_t)hq * D + 8 * (lane >> 5);
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+            const int r0 = 8 * gp;
+            const unsigned a0 = pack_bf2(oacc[dt][r0] * inv, oacc[dt][r0 + 1] * inv), a1 = pack_bf2(oacc[dt][r0 + 2] * inv, oacc[dt][r0 + 3] * inv);
+            const unsigned b0 = pack_bf2(oacc[dt][r0 + 4] * inv, oacc[dt][r0 + 5] * inv), b1 = pack_bf2(oacc[dt][r0 + 6] * inv, oacc[dt][r0 + 7] * inv);
+            const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false), s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+            const u32x4 w = {s0[0], s1[0], s0[1], s1[1]};
+            if (qvalid) *reinterpret_cast<u32x4*>(orow + dt * 32 + 16 * gp) = w;
+        }
+    // a row whose visible keys are all padding reports the fill value as its maximum, as the first-generation kernel does
+    if (qvalid && lane < 32) lse[((int64_t)b * Hq + hq) * S + qg] = ((qrow ? MASK_T : mref) + __builtin_amdgcn_logf(l)) * LN2;
+}
+
 // ================================================================================================ backward
 // delta[b,h,q] = sum_d dO[q,d] * O[q,d].  HBM-bound: 16-byte loads, D/8 lanes per (token, head) row, so one wave covers
 // 512/D adjacent heads of a token (contiguous in the token-major operands) per 1-KiB load instruction.
@@ -603,7 +561,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(int B, int S, int H
             unsigned long long kbits = ~0ull;
             if (key_mask) {
                 const unsigned long long w = kmw[kt];
-                kbits = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(w >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)w);
+                kbits = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(w >> 32)) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)w);
             }
             const bool wave_active = !causal || (kt * 64 <= q0 + wave * 32 + 31);
             if (!wave_active) continue;
@@ -1130,6 +1088,9 @@ extern "C" int mi355_debug_prof(unsigned long long* out, int reset) {
 }
 #endif
 
+int mi355_attn_fwd2_launch(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                           void* o, int64_t ldo, float* lse, const uint8_t* key_mask, int causal, float scale_log2, hipStream_t s);  // attention_fwd2.hip
+
 extern "C" int mi355_attn_fwd(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk,
                               const void* v, int64_t ldv, void* o, int64_t ldo, float* lse, const uint8_t* key_mask,
                               int causal, float scale, void* stream) {
@@ -1141,6 +1102,19 @@ extern "C" int mi355_attn_fwd(int B, int S, int Hq, int Hkv, int D, const void* 
     MI355_REQUIRE(grid < 0x7fffffffLL, "mi355_attn_fwd: grid too large");
     hipStream_t s = (hipStream_t)stream;
     const float sl2 = scale * LOG2E;
+    // ablation bit 13: the one-wave-per-SIMD experiment (attention_fwd2.hip; head_dim 128, an even number of query heads per kv head)
+    if (((causal >> 8) & 8192) && mi355_attn_fwd2_launch(B, S, Hq, Hkv, D, q, ldq, k, ldk, v, ldv, o, ldo, lse, key_mask, causal & 0xff, sl2, s) == 0) {
+        MI355_LAUNCH_CHECK("mi355_attn_fwd");
+        return 0;
+    }
+    if (!((causal >> 8) & 2048)) {  // the lean-softmax kernel; ablation bit 11 keeps the first-generation one
+        if (D == 128)
+            hipLaunchKernelGGL(attn_fwd_lean_kernel<128>, dim3((unsigned)grid), dim3(256), 0, s, B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, key_mask, causal, sl2);
+        else
+            hipLaunchKernelGGL(attn_fwd_lean_kernel<64>, dim3((unsigned)grid), dim3(256), 0, s, B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, key_mask, causal, sl2);
+        MI355_LAUNCH_CHECK("mi355_attn_fwd");
+        return 0;
+    }
     if (D == 128)
         hipLaunchKernelGGL(attn_fwd_kernel<128>, dim3((unsigned)grid), dim3(256), 0, s, B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, key_mask, causal, sl2);
     else

@@ -393,6 +393,8 @@ ATTN_CASES = [
     (2, 197, 3, 3, 64, False, False),
     (1, 130, 2, 2, 64, True, True),
     (1, 33, 2, 1, 128, False, False),
+    (2, 200, 4, 2, 128, True, "holes"),   # every fifth key padded: mask words with zeros in both halves (a sign-extension bug hid here)
+    (2, 200, 2, 2, 128, False, "holes"),
 ]
 
 
@@ -406,7 +408,10 @@ def test_attention_fwd_bwd(K, B, S, Hq, Hkv, D, causal, ragged):
     km = None
     if ragged:
         km = torch.ones(B, S, dtype=torch.uint8)
-        km[0, S - S // 3 :] = 0
+        if ragged == "holes":
+            km[:, 2::5] = 0
+        else:
+            km[0, S - S // 3 :] = 0
     qr, kr, vr = (t.double().requires_grad_(True) for t in (q, k, v))
     o_ref, _ = _attn_ref(qr, kr, vr, B, S, Hq, Hkv, D, km, causal)
     o_ref.backward(do.double())
@@ -420,7 +425,8 @@ def test_attention_fwd_bwd(K, B, S, Hq, Hkv, D, causal, ragged):
         assert e < 8e-3, f"{name} rel l2 {e}"
 
 
-@pytest.mark.parametrize("B,S,Hq,Hkv,causal,ragged", [(2, 709, 4, 2, True, True), (1, 333, 2, 2, False, False), (3, 64, 4, 1, True, False), (1, 130, 2, 1, True, True)])
+@pytest.mark.parametrize("B,S,Hq,Hkv,causal,ragged", [(2, 709, 4, 2, True, True), (1, 333, 2, 2, False, False), (3, 64, 4, 1, True, False), (1, 130, 2, 1, True, True),
+                                                      (2, 200, 4, 2, True, "holes")])
 def test_attention_backward_scratch_form_equals_recompute_form(K, B, S, Hq, Hkv, causal, ragged):
     """mi355_attn_bwd_ws (the dK/dV pass leaves dS in a scratch buffer, dQ = scale * dS K is one product over it) against the form
     without a workspace (the dQ pass recomputes S and dP): the same bf16 dS words meet the same K fragments in the same order, so
@@ -431,7 +437,10 @@ def test_attention_backward_scratch_form_equals_recompute_form(K, B, S, Hq, Hkv,
     km = None
     if ragged:
         km = torch.ones(B, S, dtype=torch.uint8)
-        km[0, S - S // 3 :] = 0
+        if ragged == "holes":
+            km[:, 2::5] = 0
+        else:
+            km[0, S - S // 3 :] = 0
         km = dev(km)
     o, lse = K.attn_fwd(q, k, v, B, S, Hq, Hkv, D, key_mask=km, causal=causal)
     outs = []
@@ -523,6 +532,120 @@ def test_attention_fully_masked_rows_follow_reference(K):
     o_ref, _ = _attn_ref(q, k, v, B, S, Hq, Hkv, D, km, True)
     o, _ = K.attn_fwd(dev(q), dev(k), dev(v), B, S, Hq, Hkv, D, key_mask=dev(km), causal=True)
     assert rel_l2(o, o_ref) < 4e-3
+
+
+# ---- the lean-softmax forward (csrc/attention.hip, the default) and the one-wave-per-SIMD experiment (csrc/attention_fwd2.hip, ablation bit 13)
+def _forward_kernel(K, bit):
+    """Context manager: ablation bit 11 (2048) keeps the first-generation forward kernel, bit 13 (8192) selects the one-wave-per-SIMD experiment."""
+    import contextlib
+
+    @contextlib.contextmanager
+    def cm():
+        keep = K._ATTN_ABLATE
+        K._ATTN_ABLATE = keep | (bit << 8)
+        try:
+            yield
+        finally:
+            K._ATTN_ABLATE = keep
+
+    return cm()
+
+
+def _old_forward(K):
+    return _forward_kernel(K, 2048)
+
+
+FWD2_CASES = [
+    # B, S, Hq, Hkv, causal, mask ("none" | "right" = padded tail | "left" = padded head: fully masked rows | "holes")
+    (3, 709, 4, 2, True, "none"),
+    (2, 1024, 8, 2, True, "none"),     # four query heads per kv head = two pairs
+    (2, 300, 2, 1, False, "none"),
+    (1, 129, 2, 1, True, "right"),
+    (2, 709, 4, 2, True, "left"),
+    (2, 450, 2, 2, True, "none"),      # one query head per kv head: not this kernel's shape, the first-generation kernel runs
+    (5, 64, 2, 1, True, "none"),
+    (1, 1, 2, 1, True, "none"),
+    (2, 63, 4, 2, False, "holes"),
+    (40, 200, 16, 8, True, "right"),   # 160 head pairs x 2 blocks = 320 items on 256 workgroups: the tile stream crosses item boundaries
+]
+
+
+@pytest.mark.parametrize("kernel", ["lean", "one_wave"])
+@pytest.mark.parametrize("B,S,Hq,Hkv,causal,mask", FWD2_CASES)
+def test_attention_forward_second_generation_matches_fp64(K, B, S, Hq, Hkv, causal, mask, kernel):
+    """Output and log-sum-exp against fp64 softmax with the reference's finite mask fill (qwen3_attention.py:130-142), over shapes that walk
+    one and several blocks per item, both tile-count parities, padded tails, padded heads (rows whose visible keys are all masked) and holes."""
+    D = 128
+    g = torch.Generator().manual_seed(S * 7 + Hq)
+    q = torch.randn(B * S, Hq * D, generator=g).to(BF16)
+    k = torch.randn(B * S, Hkv * D, generator=g).to(BF16)
+    v = torch.randn(B * S, Hkv * D, generator=g).to(BF16)
+    km = None
+    if mask != "none":
+        km = torch.ones(B, S, dtype=torch.uint8)
+        if mask == "right":
+            km[0, S - S // 3 :] = 0
+        elif mask == "left":
+            km[0, :70] = 0
+            km[1, :1] = 0
+        else:
+            km[:, ::5] = 0
+            km[1, 0] = 1
+    big = B * Hq * S * S > 3e7  # keep the fp64 reference on the device when the score tensor is large
+    rd = (lambda t: t.cuda()) if big else (lambda t: t)
+    o_ref, p_ref = _attn_ref(rd(q), rd(k), rd(v), B, S, Hq, Hkv, D, None if km is None else rd(km), causal)
+    with _forward_kernel(K, 8192 if kernel == "one_wave" else 0):
+        o, lse = K.attn_fwd(dev(q), dev(k), dev(v), B, S, Hq, Hkv, D, key_mask=None if km is None else dev(km), causal=causal)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    assert rel_l2(o, o_ref) < 4e-3, rel_l2(o, o_ref)
+    # lse = log sum exp of the masked scaled scores (the backward recomputes P from it)
+    q4 = rd(q).double().view(B, S, Hq, D).transpose(1, 2)
+    k4 = rd(k).double().view(B, S, Hkv, D).transpose(1, 2).repeat_interleave(Hq // Hkv, dim=1)
+    sc = (q4 @ k4.mT) * D ** -0.5
+    blocked = torch.zeros(B, 1, S, S, dtype=torch.bool, device=sc.device)
+    if causal:
+        blocked = blocked | torch.triu(torch.ones(S, S, dtype=torch.bool, device=sc.device), 1)
+    if km is not None:
+        blocked = blocked | ~rd(km).bool()[:, None, None, :]
+    fill = -2.0e38 * 0.6931471805599453  # the kernel's finite fill in natural-log units
+    lse_ref = torch.logsumexp(sc.masked_fill(blocked, fill), dim=-1)
+    live = ~blocked.expand(B, Hq, S, S).all(dim=-1)  # rows with at least one visible key (the others sit at the fill value)
+    # (the scale is folded into the bf16 query rows: one more rounding of an operand, ~1e-3 on a score)
+    assert float((lse.double().cpu() - lse_ref.cpu())[live.cpu()].abs().max()) < 6e-3
+    with _old_forward(K):
+        o1, lse1 = K.attn_fwd(dev(q), dev(k), dev(v), B, S, Hq, Hkv, D, key_mask=None if km is None else dev(km), causal=causal)
+    assert rel_l2(o, o1) < 5e-3 and float((lse - lse1)[live.to(lse.device)].abs().max()) < 6e-3
+
+
+@pytest.mark.parametrize("kernel", ["lean", "one_wave"])
+def test_attention_forward_lazy_rescale_branch_is_exercised(K, kernel):
+    """The forward rescales O only when a row maximum outgrows its running reference by 2^8 -- a rare, data-dependent branch
+    that bounded random data never takes.  Keys aligned with chosen queries make the maximum jump by ~30 log2 units at chosen tiles (first
+    tile, an interior tile, the block's last tile, for either head of the pair); every output row is checked against fp64."""
+    B, S, Hq, Hkv, D = 2, 709, 4, 2, 128
+    g = torch.Generator().manual_seed(77)
+    q = torch.randn(B * S, Hq * D, generator=g).to(BF16)
+    k = torch.randn(B * S, Hkv * D, generator=g).to(BF16)
+    v = torch.randn(B * S, Hkv * D, generator=g).to(BF16)
+    q4, k4 = q.view(B, S, Hq, D), k.view(B, S, Hkv, D)
+    for b, row, key, hq in ((0, 600, 400, 0), (0, 100, 70, 1), (1, 700, 690, 2), (1, 330, 5, 3), (0, 640, 639, 0), (1, 64, 63, 1)):
+        k4[b, key, hq // 2] = (2.0 * q4[b, row, hq].float()).to(BF16)
+    o_ref, p_ref = _attn_ref(q, k, v, B, S, Hq, Hkv, D, None, True)
+    assert float(p_ref.view(B, Hq, S, S)[0, 0, 600, 400]) > 0.99  # the spike really dominates its row
+    with _forward_kernel(K, 8192 if kernel == "one_wave" else 0):
+        o, lse = K.attn_fwd(dev(q), dev(k), dev(v), B, S, Hq, Hkv, D, causal=True)
+    assert rel_l2(o, o_ref) < 4e-3
+    err = (o.float().cpu() - o_ref.float()).view(B, S, Hq * D).norm(dim=-1) / o_ref.float().view(B, S, Hq * D).norm(dim=-1)
+    assert float(err.max()) < 2e-2, (float(err.max()), int(err.argmax()))
+    # and the backward, which recomputes P from this forward's lse, still matches
+    do = torch.randn(B * S, Hq * D, generator=g).to(BF16)
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q, k, v))
+    o_r, _ = _attn_ref(qr, kr, vr, B, S, Hq, Hkv, D, None, True)
+    o_r.backward(do.double())
+    dq, dk, dv = (torch.zeros_like(dev(t)) for t in (q, k, v))
+    K.attn_bwd(dev(q), dev(k), dev(v), o, dev(do), lse, B, S, Hq, Hkv, D, dq, dk, dv, causal=True)
+    for name, got, ref in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
+        assert rel_l2(got, ref) < 8e-3, name
 
 
 # ----------------------------------------------------------------------------------------------- CE / embedding / gathers

@@ -3,9 +3,10 @@ an accumulator register of the range its statements own (the top `owned` AGPRs).
 import re, sys
 
 OWNED = {"attn_bwd_dkv_kernelILi128E": 192, "attn_bwd_dq_kernelILi128E": 128, "attn_bwd_dkv_kernelILi64E": 96, "attn_bwd_dq_kernelILi64E": 64}
+OWNED_FWD2 = {"attn_fwd2_kernelILi128E": 192}  # attention_fwd2.hip
 
 
-def audit(path):
+def audit(path, OWNED=OWNED):
     name, inasm, bad, seen = None, False, [], {}
     for ln, l in enumerate(open(path), 1):
         m = re.match(r"^(_Z\S+):", l)
@@ -36,8 +37,9 @@ def audit(path):
 
 
 if __name__ == "__main__":
-    bad, seen = audit(sys.argv[1])
+    table = OWNED_FWD2 if "fwd2" in sys.argv[1] else OWNED
+    bad, seen = audit(sys.argv[1], table)
     print("owned-range MFMA statements per kernel:", seen)
     for b in bad[:20]:
         print("VIOLATION", b)
-    sys.exit(1 if bad or len(seen) != len(OWNED) else 0)
+    sys.exit(1 if bad or len(seen) != len(table) else 0)
