@@ -238,6 +238,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lean_kernel(int B, int S, int
                                                                int64_t ldv, bf16_t* __restrict__ o, int64_t ldo, float* __restrict__ lse,
                                                                const uint8_t* __restrict__ key_mask, int causal, float scale_log2) {
     using C = Cfg<D>;
+    [[maybe_unused]] const int abl = causal >> 8;
     causal &= 0xff;
     __shared__ __attribute__((aligned(16))) char smem[4 * C::TILE];  // 2 stages x (K row image, V tr image)
     const int lane = threadIdx.x & 63;
@@ -276,10 +277,35 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lean_kernel(int B, int S, int
     const bool qrow = allt && (causal ? qg < first_real : first_real >= S);
     const int ntiles = (causal && !allt) ? min(ntiles_all, (q0 + 127) / 64 + 1) : ntiles_all;
 
+    // per-lane parts of the DMA source offsets.  A wave's piece j of an image covers rows RPP (PPW wave + j) + lane / CH, chunk lane % CH; the chunk
+    // swizzle of the K row image depends on the row's low bits and so on j (an XOR on the chunk), that of the V image does not -- a whole tile
+    // (no row beyond S) then needs one XOR + one add per K piece, nothing per V piece (the rows of piece j go into the scalar offset)
+    constexpr int RPW = C::RPP * C::PPW;  // rows per wave
+    const int prow = lane / C::CH, pch = lane % C::CH;
+    const unsigned dk_row = (unsigned)((wave * RPW + prow) * (int)ldk * 2), dv_row = (unsigned)((wave * RPW + prow) * (int)ldv * 2);
     auto issue = [&](int kt, int stage) {
         char* ks_ = smem + stage * 2 * C::TILE;
-        dma_tile<D, IMG_ROW>(kbase + (int64_t)kt * 64 * ldk, ldk, S - kt * 64, ks_, wave, lane);
-        dma_tile<D, IMG_TR>(vbase + (int64_t)kt * 64 * ldv, ldv, S - kt * 64, ks_ + C::TILE, wave, lane);
+        const bf16_t* kp = kbase + (int64_t)kt * 64 * ldk;
+        const bf16_t* vp = vbase + (int64_t)kt * 64 * ldv;
+        if (S - kt * 64 >= 64) {
+            auto kr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kp), 0, 0x7fffffff, 0x00020000);
+            auto vr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vp), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < C::PPW; ++j) {
+                const int row = (wave * C::PPW + j) * C::RPP + prow;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(kr, LDS_PTR(ks_ + (wave * C::PPW + j) * 1024), 16, dk_row + (unsigned)(swz_row<D>(pch, row) << 4),
+                                                         (int)(j * C::RPP * ldk * 2), 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < C::PPW; ++j) {
+                const int row = (wave * C::PPW + j) * C::RPP + prow;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(vr, LDS_PTR(ks_ + C::TILE + (wave * C::PPW + j) * 1024), 16, dv_row + (unsigned)(swz_tr<D>(pch, row) << 4),
+                                                         (int)(j * C::RPP * ldv * 2), 0, 0);
+            }
+        } else {
+            dma_tile<D, IMG_ROW>(kp, ldk, S - kt * 64, ks_, wave, lane);
+            dma_tile<D, IMG_TR>(vp, ldv, S - kt * 64, ks_ + C::TILE, wave, lane);
+        }
     };
     const LaneOff<D> lo = lane_offsets<D>(lane);
     issue(0, 0);  // first tile first, then the query rows: their latencies overlap
@@ -306,10 +332,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lean_kernel(int B, int S, int
 #pragma unroll
     for (int e = 0; e < 16; ++e) ninit[e] = 0.f;
     float mref = 0.f, l = 0.f;
+    [[maybe_unused]] const bool prof_on = threadIdx.x == 0;
+    [[maybe_unused]] unsigned long long prof_acc[16] = {};
+    [[maybe_unused]] const unsigned long long t_wg = PROF_T();
 
     for (int kt = 0; kt < ntiles; ++kt) {
+        [[maybe_unused]] const unsigned long long t_sync = PROF_T();
         __syncthreads();
+        PROF_ADD(1, t_sync);
+        [[maybe_unused]] const unsigned long long t_iss = PROF_T();
         if (kt + 1 < ntiles) issue(kt + 1, (kt + 1) & 1);
+        PROF_ADD(2, t_iss);
+        [[maybe_unused]] unsigned long long t_seg = PROF_T();
+        if (prof_on) prof_acc[7] += 1;
         const int koff = (kt & 1) * 2 * C::TILE, voff = koff + C::TILE;
         // bit per key of this tile: 1 = a real token that exists
         const int nv = S - kt * 64;
@@ -334,6 +369,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lean_kernel(int B, int S, int
             for (int ks = 1; ks < C::KS; ++ks)
                 sacc[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(smem, vkx[ks], st * 32 * C::ROWB), qf[ks], sacc[st], 0, 0, 0);
         }
+#if ATTN_ABL & 16
+        asm volatile("" : "+v"(sacc[0]), "+v"(sacc[1]));
+        if (prof_on) { const unsigned long long now = __builtin_readcyclecounter(); prof_acc[3] += now - t_seg; t_seg = now; }
+#endif
         // masks only on the diagonal / tail / padded tiles (wave-uniform test)
         if ((kbits != ~0ull) || allt || (causal && kt * 64 + 63 > qw)) {
             const unsigned long long exist = nv >= 64 ? ~0ull : ((1ull << nv) - 1ull);
@@ -403,6 +442,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lean_kernel(int B, int S, int
                 ps1 += sacc[st][e + 1];
             }
         l += ps0 + ps1;
+#if ATTN_ABL & 16
+        asm volatile("" : "+v"(sacc[0]), "+v"(sacc[1]), "+v"(l));
+        if (prof_on) { const unsigned long long now = __builtin_readcyclecounter(); prof_acc[4] += now - t_seg; t_seg = now; }
+#endif
 #pragma unroll
         for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -412,7 +455,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lean_kernel(int B, int S, int
                 for (int dt = 0; dt < C::DT; ++dt)
                     oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr<D>(smem, vv[dt], (st * 32 + 16 * s) * C::ROWB), pf, oacc[dt], 0, 0, 0);
             }
+#if ATTN_ABL & 16
+        asm volatile("" : "+v"(oacc[0]), "+v"(oacc[1]));
+        PROF_ADD(5, t_seg);
+        if (prof_on) prof_acc[6] += 1;
+#endif
     }
+#if ATTN_ABL & 16
+    PROF_ADD(0, t_wg);
+    if (prof_on && (abl & 4096) && (blockIdx.x & 63) == 5)  // one workgroup in 64 reports
+        for (int i = 0; i < 16; ++i) atomicAdd(&g_prof[i], prof_acc[i]);
+#endif
 
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;

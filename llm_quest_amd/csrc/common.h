@@ -43,6 +43,17 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- SwiGLU: one definition for the elementwise kernels and the GEMM epilogues, so fused == separate bit for bit.  sigmoid through v_exp + v_rcp
+// (1 ulp each; an IEEE division costs ten instructions per element, and the epilogues are bound by what their lanes issue); operands and results
+// are rounded to bf16 where the reference's bf16 tensors are (silu(g) is a bf16 tensor before it multiplies u, qwen3_transformer_block.py:48-53).
+__device__ __forceinline__ float sigmoid_fast(float g) { return __builtin_amdgcn_rcpf(1.0f + __expf(-g)); }
+__device__ __forceinline__ float swiglu_act(float u, float g) { return u * bf2f(f2bf(g * sigmoid_fast(g))); }
+__device__ __forceinline__ void swiglu_grads(float d, float u, float g, float& du, float& dg) {
+    const float sg = sigmoid_fast(g);
+    du = d * g * sg;
+    dg = d * u * sg * (1.0f + g * (1.0f - sg));
+}
+
 // ---- GELU: KIND 0 exact erf (nn.GELU()), KIND 1 tanh approximation; one definition for the elementwise kernels and the GEMM epilogues
 template <int KIND>
 __device__ __forceinline__ float gelu_val(float x) {

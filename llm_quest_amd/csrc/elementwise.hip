@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(int64_t tokens, int F, 
         unpack8(*reinterpret_cast<const u32x4*>(gu + t * 2 * F + c), u);
         unpack8(*reinterpret_cast<const u32x4*>(gu + t * 2 * F + F + c), g);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = u[e] * rbf(g[e] / (1.0f + __expf(-g[e])));
+        for (int e = 0; e < 8; ++e) o[e] = swiglu_act(u[e], g[e]);
         *reinterpret_cast<u32x4*>(a + t * F + c) = pack8(o);
     }
 }
@@ -67,11 +67,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(int64_t tokens, int F, 
         unpack8(*reinterpret_cast<const u32x4*>(gu + t * 2 * F + F + c), g);
         unpack8(*reinterpret_cast<const u32x4*>(da + t * F + c), d);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float sg = 1.0f / (1.0f + __expf(-g[e]));
-            du[e] = d[e] * g[e] * sg;
-            dg[e] = d[e] * u[e] * sg * (1.0f + g[e] * (1.0f - sg));
-        }
+        for (int e = 0; e < 8; ++e) swiglu_grads(d[e], u[e], g[e], du[e], dg[e]);
         *reinterpret_cast<u32x4*>(dgu + t * 2 * F + c) = pack8(du);
         *reinterpret_cast<u32x4*>(dgu + t * 2 * F + F + c) = pack8(dg);
     }

@@ -816,7 +816,9 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
                                 }
                                 if (KIND == MI355_EPI_SWIGLU_FWD) {
                                     // this wave's 64 staging columns = [u (32) | g (32)] of hidden units hid0..hid0+31 (see the DMA plan): lanes 0-3 of each
-                                    // row group write u into C[:, hid] and a = u * silu(g) into R[:, hid], lanes 4-7 write g into C[:, N/2 + hid];
+                                    // row group write their 8 u into C[:, hid], lanes 4-7 their 8 g into C[:, N/2 + hid]; EVERY lane then computes four of
+                                    // the group's 32 activations a = u * silu(g) (its own operand half from registers, the partner's from the staging row)
+                                    // and writes them into R[:, hid] -- with the gate lanes idle the pass was bound by what the value lanes had to issue.
                                     // u, g are rounded to bf16 first, so a equals mi355_swiglu_fwd on the stored gate-up output bit for bit.
                                     const int l8 = lane & 7;
                                     const int64_t nh = p.N >> 1;
@@ -826,25 +828,20 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
                                     u32x4 own;
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) own[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
-                                    if (l8 >= 4) {
-                                        *reinterpret_cast<u32x4*>(gu_row + nh + hid) = own;
-                                        continue;
-                                    }
-                                    *reinterpret_cast<u32x4*>(gu_row + hid) = own;
-                                    const float* gp_ = stg + row * EPI_LD + 32 + l8 * 8;
-                                    u32x4 av;
+                                    const int hi4 = l8 >> 2;  // value lanes take units 0-3 of their eight, gate lanes units 4-7
+                                    *reinterpret_cast<u32x4*>(gu_row + (hi4 ? nh : 0) + hid) = own;
+                                    // partner operand of my four units: staging columns (other half) + (l8 & 3) * 8 + 4 * hi4
+                                    const f32x4 pv = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + (hi4 ? 0 : 32) + (l8 & 3) * 8 + 4 * hi4);
+                                    float a4[4];
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) {
-                                        float a2[2];
-#pragma unroll
-                                        for (int hlf = 0; hlf < 2; ++hlf) {
-                                            const float u_ = hlf ? __uint_as_float(own[e] & 0xffff0000u) : __uint_as_float(own[e] << 16);
-                                            const float g_ = bf2f(f2bf(gp_[2 * e + hlf]));
-                                            a2[hlf] = u_ * bf2f(f2bf(g_ / (1.0f + __expf(-g_))));
-                                        }
-                                        av[e] = pack_bf2(a2[0], a2[1]);
+                                        const unsigned w = own[2 * hi4 + (e >> 1)];
+                                        const float mine = (e & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16);
+                                        const float other = bf2f(f2bf(pv[e]));
+                                        a4[e] = hi4 ? swiglu_act(other, mine) : swiglu_act(mine, other);
                                     }
-                                    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(const_cast<void*>(p.R)) + gm * p.ldr + hid) = av;
+                                    const u32x2 av = {pack_bf2(a4[0], a4[1]), pack_bf2(a4[2], a4[3])};
+                                    *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(const_cast<void*>(p.R)) + gm * p.ldr + hid + 4 * hi4) = av;
                                     continue;
                                 }
                                 if (KIND == MI355_EPI_SWIGLU_BWD) {
@@ -866,10 +863,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
                                         for (int hlf = 0; hlf < 2; ++hlf) {
                                             const float u_ = hlf ? __uint_as_float(uv[e] & 0xffff0000u) : __uint_as_float(uv[e] << 16);
                                             const float g_ = hlf ? __uint_as_float(gv[e] & 0xffff0000u) : __uint_as_float(gv[e] << 16);
-                                            const float d_ = bf2f(f2bf(v[2 * e + hlf]));
-                                            const float sg = 1.0f / (1.0f + __expf(-g_));
-                                            du[2 * e + hlf] = d_ * g_ * sg;
-                                            dg[2 * e + hlf] = d_ * u_ * sg * (1.0f + g_ * (1.0f - sg));
+                                            swiglu_grads(bf2f(f2bf(v[2 * e + hlf])), u_, g_, du[2 * e + hlf], dg[2 * e + hlf]);
                                         }
                                     }
                                     u32x4 o0, o1;

@@ -4,7 +4,7 @@ os.environ["MI355_ATTN_ABLATE"] = "4096"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from llm_quest_amd import kernels as K, _lib as L
-B, S, Hq, Hkv, D = 64, 708, 16, 8, 128
+B, S, Hq, Hkv, D = 64, 709, 16, 8, 128
 r = lambda *s: torch.randn(*s, device="cuda").to(torch.bfloat16)
 q, k, v = r(B * S, Hq * D), r(B * S, Hkv * D), r(B * S, Hkv * D)
 lib = L.load()
