@@ -166,6 +166,14 @@ int mi355_embedding_fwd(int64_t tokens, int width, int64_t vocab, const int64_t*
 int mi355_embedding_bwd(int64_t tokens, int width, int64_t vocab, const int64_t* ids, const void* dout, int64_t ldd,
                         float* dtable_f32, void* stream);
 
+/* The same gradient without atomics, bit-reproducible for any ids (torch's scatter-add into nn.Embedding.weight.grad is not; the reference step
+ * qwen3_model.py:69 -> its autograd backward).  sorted_ids: the ids sorted STABLY, perm: the permutation that sorted them (sorted_ids[j] =
+ * ids[perm[j]]); dout bf16 [tokens, width] indexed by perm; table bf16 [vocab, width], row pitch ldt: every vocabulary row that occurs becomes
+ * (accumulate ? row : 0) + scale * sum of its tokens' rows (summed in token order, fp32); rows that do not occur are left untouched.
+ * Ids outside [0, vocab) are skipped.  width, ldd, ldt multiples of 8. */
+int mi355_embedding_bwd_sorted(int64_t tokens, int width, int64_t vocab, const int64_t* sorted_ids, const int64_t* perm, const void* dout,
+                               int64_t ldd, float scale, void* table, int64_t ldt, int accumulate, void* stream);
+
 /* y[c][r] = x[r][c], bf16, pitches in elements.  rows, cols, ldx, ldy multiples of 8; pointers 16-byte aligned.  The backward of a Linear
  * (reference: every nn.Linear on the path, e.g. llm_quest/qwen/qwen3/qwen3_transformer_block.py:7-53) uses it once per weight so that the
  * dgrad GEMM dX = dY W reads W^T in the K-contiguous NT form.                                                                              */

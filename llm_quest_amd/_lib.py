@@ -42,6 +42,7 @@ SIGNATURES = {
     "mi355_ce_finalize": [_L, _P, _P, _P, _P],
     "mi355_embedding_fwd": [_L, _I, _L, _P, _P, _P, _L, _P],
     "mi355_embedding_bwd": [_L, _I, _L, _P, _P, _L, _P, _P],
+    "mi355_embedding_bwd_sorted": [_L, _I, _L, _P, _P, _P, _L, _F, _P, _L, _I, _P],
     "mi355_copy2d": [_L, _L, _P, _L, _P, _L, _P],
     "mi355_transpose_bf16": [_L, _L, _P, _L, _P, _L, _P],
     "mi355_patchify": [_I, _I, _I, _I, _I, _P, _P, _I, _P],

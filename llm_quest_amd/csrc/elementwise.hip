@@ -379,6 +379,45 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(int64_t tokens, int 
     }
 }
 
+// Deterministic form: the ids arrive SORTED (stably: equal ids keep the order of their token positions) together with the permutation that
+// sorted them.  One wave per sorted position; the first position of each run of equal ids owns the run, sums its rows in run order in fp32
+// registers and updates that vocabulary row once: no atomics, the same bits every time whatever the ids repeat, and only the touched rows move
+// (the atomic form walks a dense fp32 copy of the table).  scale: 1 / world under data parallelism (the runs then hold every rank's tokens).
+__global__ __launch_bounds__(256) void embedding_bwd_sorted_kernel(int64_t tokens, int width, int64_t vocab, const int64_t* __restrict__ sid,
+                                                                   const int64_t* __restrict__ perm, const bf16_t* __restrict__ dout, int64_t ldd,
+                                                                   float scale, bf16_t* __restrict__ table, int64_t ldt, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); j < tokens; j += (int64_t)gridDim.x * 4) {
+        const int64_t id = sid[j];
+        if (id < 0 || id >= vocab) continue;
+        if (j > 0 && sid[j - 1] == id) continue;  // not the head of its run
+        for (int c0 = 0; c0 < width; c0 += 512) {  // 8 columns per lane and sweep
+            const int c = c0 + lane * 8;
+            if (c >= width) continue;
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int64_t jj = j; jj < tokens && sid[jj] == id; ++jj) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(dout + perm[jj] * ldd + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[2 * e] += __uint_as_float(v[e] << 16);
+                    acc[2 * e + 1] += __uint_as_float(v[e] & 0xffff0000u);
+                }
+            }
+            bf16_t* row = table + id * ldt + c;
+            u32x4 o;
+            if (accumulate) {
+                const u32x4 old = *reinterpret_cast<const u32x4*>(row);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = pack_bf2(__uint_as_float(old[e] << 16) + acc[2 * e] * scale, __uint_as_float(old[e] & 0xffff0000u) + acc[2 * e + 1] * scale);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = pack_bf2(acc[2 * e] * scale, acc[2 * e + 1] * scale);
+            }
+            *reinterpret_cast<u32x4*>(row) = o;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------- strided copy
 // y[c][r] = x[r][c] for a bf16 matrix, 64x64 tiles through LDS: 16-byte loads along x's rows, 16-byte stores along y's rows.
 // Used once per weight and backward pass: dgrad GEMMs then read W^T with K contiguous (NT form) instead of the K-strided NN form.
@@ -660,6 +699,17 @@ extern "C" int mi355_embedding_bwd(int64_t tokens, int width, int64_t vocab, con
     MI355_REQUIRE(tokens > 0 && width > 0 && ids && dout && dtable_f32, "mi355_embedding_bwd: bad arguments");
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3(grid_for(tokens, 4)), dim3(256), 0, STREAM, tokens, width, vocab, ids, (const bf16_t*)dout, ldd, dtable_f32);
     MI355_LAUNCH_CHECK("mi355_embedding_bwd");
+    return 0;
+}
+
+extern "C" int mi355_embedding_bwd_sorted(int64_t tokens, int width, int64_t vocab, const int64_t* sorted_ids, const int64_t* perm, const void* dout,
+                                          int64_t ldd, float scale, void* table, int64_t ldt, int accumulate, void* stream) {
+    MI355_REQUIRE(tokens > 0 && width > 0 && vocab > 0 && sorted_ids && perm && dout && table, "mi355_embedding_bwd_sorted: bad arguments");
+    MI355_REQUIRE((width & 7) == 0 && (ldd & 7) == 0 && (ldt & 7) == 0 && (((uintptr_t)dout | (uintptr_t)table) & 15) == 0,
+                  "mi355_embedding_bwd_sorted: width and both row pitches must be multiples of 8 elements, pointers 16-byte aligned");
+    hipLaunchKernelGGL(embedding_bwd_sorted_kernel, dim3(grid_for(tokens, 4)), dim3(256), 0, STREAM, tokens, width, vocab, sorted_ids, perm, (const bf16_t*)dout, ldd,
+                       scale, (bf16_t*)table, ldt, accumulate);
+    MI355_LAUNCH_CHECK("mi355_embedding_bwd_sorted");
     return 0;
 }
 

@@ -19,6 +19,13 @@ mask).  For ragged masks multiply the loss by ``sync.loss_weight(n_target_tokens
 ``n_r * world / sum_r n_r`` (one 1-element all-reduce of the counts, no host sync), so the AVG all-reduce of the buckets
 returns ``sum_r grad(sum-loss_r) / sum_r n_r`` -- the gradient of the global-batch mean.
 
+The tied embedding / LM-head matrix (311 MB, the largest bucket) receives the head's weight gradient FIRST in the backward and the embedding's
+scatter LAST, so as one bucket it could only be exchanged after the backward, fully exposed (~1.8 ms on xGMI).  It is split instead
+(``early_tail``): the dense part -- head gradient + final norm -- is all-reduced as soon as the last transformer block's backward has finished,
+under the 27 blocks still to come; the embedding's part is sparse (one row per token), so at the end the ranks all-gather their token ids and
+token-gradient rows (67 MB per rank at 64 x 512 tokens, direct xGMI links) and every rank runs the same deterministic segmented sum
+(``mi355_embedding_bwd_sorted``) over all ranks' tokens with scale 1 / world -- identical bits on every rank, nothing dense left to exchange.
+
 Gradient accumulation: wrap every micro-step but the last in ``with sync.no_sync():`` -- the hooks then leave the buckets
 alone (they keep accumulating locally) and ``finish_step`` is a no-op; the last micro-step exchanges the sums.
 """
@@ -29,6 +36,13 @@ import os
 
 import torch
 import torch.distributed as dist
+
+
+_ACTIVE = None  # the GradSync between begin_step() and finish_step(): autograd nodes that split their bucket ask it (ops.EmbeddingFn)
+
+
+def active():
+    return _ACTIVE
 
 
 def init_from_env(backend=None):
@@ -57,7 +71,7 @@ class GradSync:
     (Qwen3 TransformerBlocks, ViTAdapter); ``tail_arenas`` are reduced in ``finish_step`` (embedding / LM-head arena).
     """
 
-    def __init__(self, owners, tail_arenas=(), group=None, tail_params=()):
+    def __init__(self, owners, tail_arenas=(), group=None, tail_params=(), early_tail=None):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.group = group
         self.owners = list(owners)
@@ -73,6 +87,9 @@ class GradSync:
             object.__setattr__(m, "_grad_ready", self._on_ready)
         self.enabled = self.world > 1
         self._sync_on = True
+        # (trigger owner, arena): the arena is complete -- except for sparse embedding rows that travel separately -- once the trigger's backward ran
+        self.early_tail = early_tail
+        self._events = {}
 
     # ---------------------------------------------------------------- loss weighting / accumulation
     def loss_weight(self, n_tokens):
@@ -117,7 +134,9 @@ class GradSync:
         if buf.is_cuda:
             if self.comm_stream is None:
                 self.comm_stream = torch.cuda.Stream(device=buf.device)
-            ev = torch.cuda.Event()
+            ev = self._events.get(id(arena))  # one event per bucket, reused every step
+            if ev is None:
+                ev = self._events[id(arena)] = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(buf.device))
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
@@ -134,6 +153,12 @@ class GradSync:
     def _on_ready(self, module):
         if not self.enabled or not self._sync_on:
             return
+        if self.early_tail is not None and module is self.early_tail[0]:
+            top = self.early_tail[1]
+            if id(top) not in self._done and top.trainable():
+                self._done.add(id(top))
+                top.untouched_to_zero()
+                self._reduce(top)
         ar = self._arena(module)
         if id(ar) in self._done:
             return
@@ -141,9 +166,31 @@ class GradSync:
         ar.untouched_to_zero()
         self._reduce(ar)
 
+    # ---------------------------------------------------------------- the embedding's sparse part of a split bucket
+    def splits(self, arena):
+        """True while this step exchanges ``arena`` in two parts: its dense part has been (or is being) all-reduced, embedding rows go through
+        ``gather_embedding``."""
+        return self.enabled and self._sync_on and self.early_tail is not None and arena is self.early_tail[1] and id(arena) in self._done
+
+    def gather_embedding(self, ids, rows):
+        """Every rank's token ids [T] and token-gradient rows [T, width], concatenated in rank order, and the factor 1 / world: what the
+        deterministic embedding backward sums on every rank alike.  The dense all-reduce of the split bucket runs on the communication stream;
+        the rows are added to that bucket afterwards, so the current stream waits for it here.  All ranks must hold equally many tokens."""
+        flat = ids.reshape(-1).contiguous()
+        rows = rows.contiguous()
+        ids_all = torch.empty(self.world * flat.numel(), dtype=flat.dtype, device=flat.device)
+        rows_all = torch.empty((self.world * rows.shape[0], rows.shape[1]), dtype=rows.dtype, device=rows.device)
+        dist.all_gather_into_tensor(ids_all, flat, group=self.group)
+        dist.all_gather_into_tensor(rows_all, rows, group=self.group)
+        if self.comm_stream is not None:
+            torch.cuda.current_stream(rows.device).wait_stream(self.comm_stream)
+        return ids_all, rows_all, 1.0 / self.world
+
     # ---------------------------------------------------------------- step protocol
     def begin_step(self):
+        global _ACTIVE
         self._done.clear()
+        _ACTIVE = self
 
     def finish_step(self):
         """Reduce buckets not yet sent, then order the compute stream after the communication stream."""
@@ -163,6 +210,8 @@ class GradSync:
         self._reduce_tail_params()
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        global _ACTIVE
+        _ACTIVE = None
 
     def _reduce_tail_params(self):
         ps = self.tail_params
@@ -217,7 +266,8 @@ def sync_for_vlm(vlm_model, adapter):
     """GradSync wired for the early-fusion step: Qwen3 blocks (last -> first), adapter, then the embedding/head arena."""
     vlm_model._build_arenas()
     owners = list(reversed(list(vlm_model.trf_blocks))) + [adapter]
-    return GradSync(owners, tail_arenas=[vlm_model._top_arena])
+    # the head / embedding arena is complete, but for the embedding's token rows, when the last block's backward has run
+    return GradSync(owners, tail_arenas=[vlm_model._top_arena], early_tail=(owners[0], vlm_model._top_arena))
 
 
 def sync_for_qwen35(vlm):

@@ -418,6 +418,22 @@ def embedding_bwd(ids, dout, dtable_f32):
     L.call("mi355_embedding_bwd", flat.numel(), dout.shape[1], dtable_f32.shape[0], L.ptr(flat), L.ptr(dout), dout.stride(0), L.ptr(dtable_f32))
 
 
+def embedding_bwd_sorted(ids, dout, table, accumulate, scale=1.0):
+    """table[id] = (accumulate ? table[id] : 0) + scale * sum of dout rows whose id it is -- deterministic (no atomics): the ids are sorted
+    stably first (index preparation, one device-side sort), then one wave per run of equal ids sums that run's rows in token order.
+    Rows of ``table`` (bf16 [vocab, width], row-strided views allowed) that no id names are left untouched."""
+    L.require_gpu(ids, dout, table)
+    flat = ids.reshape(-1).contiguous()
+    _rowmajor(dout, "dout")
+    _rowmajor(table, "table")
+    if dout.dtype != BF16 or table.dtype != BF16 or dout.shape[0] != flat.numel() or dout.shape[1] != table.shape[1] or flat.dtype != torch.int64:
+        raise ValueError("embedding_bwd_sorted: int64 ids, bf16 dout [tokens, width] and bf16 table [vocab, width]")
+    sid, perm = torch.sort(flat, stable=True)
+    L.call("mi355_embedding_bwd_sorted", flat.numel(), dout.shape[1], table.shape[0], L.ptr(sid), L.ptr(perm), L.ptr(dout), dout.stride(0), float(scale),
+           L.ptr(table), table.stride(0), int(bool(accumulate)))
+    return table
+
+
 def transpose(x, out=None):
     """out[c, r] = x[r, c] for a bf16 matrix (row-strided views allowed; rows, cols and pitches multiples of 8)."""
     L.require_gpu(x, out)

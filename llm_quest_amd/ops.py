@@ -291,10 +291,24 @@ class EmbeddingFn(torch.autograd.Function):
         if w.requires_grad:
             dy2 = dy.reshape(-1, w.shape[1])
             dy2 = dy2 if dy2.stride(1) == 1 else dy2.contiguous()
-            acc = torch.zeros(w.shape, dtype=F32, device=w.device)
-            K.embedding_bwd(ctx.ids, dy2, acc)
-            view, accum = arena_for(ctx.owner).grad_target(w)
-            K.add_f32_to_bf16(acc, view if accum else None, view)
+            arena = arena_for(ctx.owner)
+            view, accum = arena.grad_target(w)
+            if w.dtype == BF16 and dy2.dtype == BF16 and w.shape[1] % 8 == 0:
+                # deterministic: sorted ids, one wave per run of equal ids, no atomics, only the touched rows move.  Under data parallelism with a
+                # split head / embedding bucket (ddp.GradSync.early_tail) every rank sums ALL ranks' token rows, scaled by 1 / world.
+                from . import ddp
+
+                ids, rows, scale = ctx.ids, dy2, 1.0
+                sync = ddp.active()
+                if sync is not None and sync.splits(arena):
+                    ids, rows, scale = sync.gather_embedding(ctx.ids, dy2)
+                if not accum:
+                    view.zero_()
+                K.embedding_bwd_sorted(ids, rows, view, True, scale)
+            else:  # fp32 tables: the dense accumulator with fp32 atomics
+                acc = torch.zeros(w.shape, dtype=F32, device=w.device)
+                K.embedding_bwd(ctx.ids, dy2, acc)
+                K.add_f32_to_bf16(acc, view if accum else None, view)
         return None, None, None
 
 

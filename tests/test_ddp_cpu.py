@@ -183,3 +183,87 @@ def test_token_weighted_exchange_and_no_sync_world2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(results) == [(0, True), (1, True)]
+
+
+def _split_worker(rank, world, port, out):
+    """The tied head / embedding bucket in two parts (ddp.GradSync.early_tail): the dense part is exchanged when the trigger owner's backward has
+    run, the embedding's token rows are all-gathered and summed by every rank alike."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from llm_quest_amd import ddp
+    from llm_quest_amd.ops import arena_for
+
+    ddp.init_from_env(backend="gloo")
+    V, W, T = 12, 4, 6
+    owners = [_Owner(7 + i) for i in range(2)]
+
+    class _Top(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.emb = torch.nn.Parameter(torch.zeros(V, W))
+            self.norm = torch.nn.Parameter(torch.zeros(W))
+
+    top = _Top()
+    sync = ddp.GradSync(owners, tail_arenas=[arena_for(top)], early_tail=(owners[0], arena_for(top)))
+    g = torch.Generator().manual_seed(40 + rank)
+    head_grad = torch.randn(V, W, generator=g)          # this rank's LM-head weight gradient
+    norm_grad = torch.randn(W, generator=g)
+    ids = torch.randint(0, V, (T,), generator=g)        # this rank's tokens (ids repeat across and inside ranks)
+    rows = torch.randn(T, W, generator=g)
+
+    def step(exchange):
+        for p in list(top.parameters()) + [q for m in owners for q in m.parameters()]:
+            p.grad = None
+        sync.begin_step()
+        ar = arena_for(top)
+        ar.grad_target(top.emb)[0].copy_(head_grad)     # first gradient of the backward
+        ar.grad_target(top.norm)[0].copy_(norm_grad)
+        assert not sync.splits(ar)
+        for m in owners:                                 # blocks, last to first: owners[0] is the trigger
+            for p in m.parameters():
+                arena_for(m).grad_target(p)[0].fill_(float(rank + 1))
+            m._grad_ready(m)
+        # the embedding backward, last of all
+        view, _ = ar.grad_target(top.emb)
+        if sync.splits(ar):
+            assert exchange
+            ids_all, rows_all, scale = sync.gather_embedding(ids, rows)
+            view.index_add_(0, ids_all, rows_all * scale)  # what mi355_embedding_bwd_sorted does on the device
+        else:
+            assert not exchange
+            view.index_add_(0, ids, rows)
+        sync.finish_step()
+        return top.emb.grad.clone(), top.norm.grad.clone(), owners[0].a.grad.clone()
+
+    emb, norm, blk = step(True)
+    # expectation: the mean over ranks of (head gradient + scatter of the rank's rows)
+    parts = []
+    for rk in range(world):
+        gg = torch.Generator().manual_seed(40 + rk)
+        hg, ng = torch.randn(V, W, generator=gg), torch.randn(W, generator=gg)
+        ii = torch.randint(0, V, (T,), generator=gg)
+        rr = torch.randn(T, W, generator=gg)
+        parts.append((hg.index_add(0, ii, rr), ng))
+    want_emb = sum(p[0] for p in parts) / world
+    want_norm = sum(p[1] for p in parts) / world
+    ok = bool(torch.allclose(emb, want_emb, atol=1e-6)) and bool(torch.allclose(norm, want_norm, atol=1e-6))
+    ok &= bool(torch.allclose(blk, torch.full_like(blk, sum(range(1, world + 1)) / world)))
+    ok &= ddp.active() is None
+    # accumulation window: nothing is exchanged, the bucket keeps this rank's own sums
+    with sync.no_sync():
+        emb_l, _, _ = step(False)
+    ok &= bool(torch.allclose(emb_l, head_grad.index_add(0, ids, rows), atol=1e-6))
+    out.put((rank, ok))
+
+
+def test_tied_head_embedding_bucket_is_exchanged_in_two_parts_gloo():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_split_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(60)
+    assert all(p.exitcode == 0 for p in procs) and res == {0: True, 1: True}

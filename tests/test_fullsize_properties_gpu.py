@@ -80,12 +80,14 @@ def test_attention_fullsize_invariants(K):
     ones = torch.ones_like(v)
     o1, _ = K.attn_fwd(q, k, ones, B, S, HQ, HKV, DH, causal=True)
     assert float((o1.float() - 1).abs().max()) < 2 ** -7
-    # the first query attends to exactly one key: output == that value row, lse == its scaled score
+    # the first query attends to exactly one key: output == that value row, lse == its scaled score.  (To one bf16 rounding: a row's reference is
+    # not its exact maximum any more -- it moves only when the scores outgrow it by 2^8 -- so the single probability is some p != 1, rounded to bf16
+    # in the numerator and kept in fp32 in the denominator; the first-generation kernel, whose reference was the exact maximum, gave equal bits.)
     row0 = o.view(B, S, HQ, DH)[:, 0]
     vrow0 = v.view(B, S, HKV, DH)[:, 0].repeat_interleave(HQ // HKV, dim=1)
-    assert torch.equal(row0, vrow0)
+    assert float((row0.float() - vrow0.float()).abs().max()) <= 2 ** -7 * float(vrow0.float().abs().max())
     s00 = (q.view(B, S, HQ, DH)[:, 0].float() * k.view(B, S, HKV, DH)[:, 0].repeat_interleave(2, dim=1).float()).sum(-1) * DH ** -0.5
-    assert torch.allclose(lse[:, :, 0], s00, rtol=1e-5, atol=1e-4)
+    assert torch.allclose(lse[:, :, 0], s00, rtol=1e-5, atol=8e-3)  # the scale is folded into the bf16 query rows: one more operand rounding, ~1e-3 of a score
     # all-ones key mask == no mask, bit for bit
     km = torch.ones(B, S, dtype=torch.uint8, device="cuda")
     o4, _ = K.attn_fwd(q, k, v, B, S, HQ, HKV, DH, key_mask=km, causal=True)

@@ -826,3 +826,37 @@ def test_gemm_gelu_epilogues_equal_two_kernels_bit_for_bit(tanh):
         want = K.gelu_bwd(y_ref, K.gemm(L.GEMM_NN, dy, w2, allow_split_k=False), tanh=tanh)
         assert torch.equal(K.gemm_dgrad_gelu_bwd(dy, w2, y_ref, tanh=tanh), want)
     K._FUSE_GELU = False
+
+
+def test_embedding_backward_sorted_is_deterministic_and_matches_fp32(K):
+    """``mi355_embedding_bwd_sorted`` (the gradient of ``emb_dict``, reference qwen3_model.py:69 through autograd): heavy id repetition (the
+    case fp32 atomics make irreproducible), ids outside the table, a row-strided gradient buffer.  Against an fp32 index_add; bit-identical
+    between runs; rows no id names keep their bits; the non-accumulating form overwrites exactly the named rows."""
+    V, W, T = 1000, 1024, 6000
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, 40, (T,), generator=g)  # ~150 tokens per id
+    ids[::7] = torch.randint(0, V, (len(ids[::7]),), generator=g)
+    ids[5], ids[77] = -100, V + 3  # skipped
+    dout = torch.randn(T, W + 64, generator=g).to(BF16)[:, :W]  # row pitch W + 64
+    table0 = torch.randn(V, W, generator=g).to(BF16)
+    ok = (ids >= 0) & (ids < V)
+    ref = table0.float().index_add(0, ids[ok], 0.5 * dout[ok].float())
+    outs = []
+    for _ in range(2):
+        t = dev(table0.clone())
+        K.embedding_bwd_sorted(dev(ids), dev(dout), t, True, 0.5)
+        outs.append(t)
+    assert torch.equal(outs[0], outs[1])
+    named = torch.zeros(V, dtype=torch.bool)
+    named[ids[ok]] = True
+    assert torch.equal(outs[0].cpu()[~named], table0[~named])
+    assert rel_l2(outs[0][dev(named)], ref[named]) < 3e-3
+    t = dev(table0.clone())
+    K.embedding_bwd_sorted(dev(ids), dev(dout), t, False, 1.0)
+    ref2 = torch.zeros(V, W).index_add(0, ids[ok], dout[ok].float())
+    assert torch.equal(t.cpu()[~named], table0[~named]) and rel_l2(t[dev(named)], ref2[named]) < 3e-3
+    # every permutation of the same (id, row) pairs that keeps equal ids in order gives the same bits: the sum runs in token order
+    perm = torch.argsort(ids, stable=True)
+    t2 = dev(table0.clone())
+    K.embedding_bwd_sorted(dev(ids[perm]), dev(dout[perm].contiguous()), t2, False, 1.0)
+    assert torch.equal(t2, t)
