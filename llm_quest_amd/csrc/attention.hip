@@ -491,7 +491,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lean_kernel(int B, int S, int
 // 512/D adjacent heads of a token (contiguous in the token-major operands) per 1-KiB load instruction.
 template <int D>
 __global__ __launch_bounds__(256) void attn_delta_kernel(int B, int S, int Hq, const bf16_t* __restrict__ o, int64_t ldo,
-                                                         const bf16_t* __restrict__ d_o, int64_t lddo, float* __restrict__ delta) {
+                                                         const bf16_t* __restrict__ d_o, int64_t lddo, float* __restrict__ delta,
+                                                         const float* __restrict__ lse, float* __restrict__ nl2, float* __restrict__ ndl) {
+    // nl2 / ndl (optional): -lse * log2(e) and -delta, the INITIAL ACCUMULATORS of the dK/dV pass's S and dP products (its lean form)
     constexpr int LPR = D / 8, RPW = 64 / LPR;  // lanes per row, rows (heads) per wave-instruction
     const int lane = threadIdx.x & 63, sub = lane / LPR, li = lane % LPR;
     const int hgroups = (Hq + RPW - 1) / RPW;
@@ -511,7 +513,12 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(int B, int S, int Hq, c
         for (int off = LPR / 2; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
         if (li == 0 && h < Hq) {
             const int64_t bb = tok / S, sq = tok - bb * S;
-            delta[(bb * Hq + h) * S + sq] = s;
+            const int64_t di = (bb * Hq + h) * S + sq;
+            delta[di] = s;
+            if (nl2) {
+                nl2[di] = -lse[di] * LOG2E;
+                ndl[di] = -s;
+            }
         }
     }
 }
@@ -710,7 +717,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(int B, int S, int H
 //   B(st):  P = exp2(S*c - lse2[q]) ;  dS = P*(dP - delta[q])*scale                      (row constants come from LDS)
 //   C(st):  dV^T += dO^T P ;  dK^T += Q^T dS        (A operand: transposed reads of the dO / Q tile, B: packed P / dS)
 // Same schedule as the dQ pass: MFMAs in the order A(0) A(1) C(0) C(1), B(0) under A(1), B(1) under C(0), reads PD ahead.
-template <int D>
+// LEAN: the row constants are INITIAL ACCUMULATORS (`lse` / `delta` then point at -lse * log2(e) and -delta, written by the delta kernel) and the
+// scale log2(e) / sqrt(d) is folded into this wave's K rows once per key block (bf16(k * c): one more rounding of a bf16 operand), so the S chain
+// delivers the exponent of P and the dP chain dP - delta: the B phase shrinks from six vector instructions per score (scale the constant, fma, exp2,
+// subtract, multiply, pack) to three (exp2, multiply, pack) -- the pass is bound by what its lone wave has to issue.
+template <int D, bool LEAN>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int Hq, int Hkv, const bf16_t* __restrict__ q, int64_t ldq,
                                                               const bf16_t* __restrict__ k, int64_t ldk, const bf16_t* __restrict__ v,
                                                               int64_t ldv, const bf16_t* __restrict__ d_o, int64_t lddo,
@@ -805,6 +816,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
         const bool kvalid = kg < S;
         const bool kreal = kvalid && (key_mask == nullptr || key_mask[(int64_t)b * S + kg] != 0);
         owned_zero<OWNED, 0, 32 * DT>();
+        if constexpr (LEAN) {  // k * log2(e) / sqrt(d), rounded to bf16 again: the S chain then delivers the exponent of P
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                u32x4 w = __builtin_bit_cast(u32x4, tk[ks]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = pack_bf2(__uint_as_float(w[e] << 16) * scale_log2, __uint_as_float(w[e] & 0xffff0000u) * scale_log2);
+                tk[ks] = __builtin_bit_cast(bf16x8, w);
+            }
+        }
         static_for<KS>([&](auto ks) { owned_write4<OWNED, KF0 + 4 * ks.value>(tk[ks.value]); });
         static_for<KS>([&](auto ks) { owned_write4<OWNED, VF0 + 4 * ks.value>(tv[ks.value]); });
         const int qt0 = qt0_of(kb);
@@ -866,6 +886,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
                 f32x16 sacc[2], pacc[2];
                 unsigned pw[2][8] = {}, dsw[2][8] = {};  // packed P / dS: words 4s..4s+3 of sub-tile st are the B operand of k-step s
                 float lsr[2][16], dlr[2][16], tt[2][16], pv[2][16], dsv[2][16];
+                [[maybe_unused]] f32x16 linit[2], dinit[2];  // LEAN: -lse * log2(e) and -delta of the accumulator rows = the chains' initial values
                 auto load = [&](auto gc) {
                     constexpr int g = gc.value;
                     if constexpr (ATTN_ABL & 1) return;
@@ -887,7 +908,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
                         const f32x4 a = *reinterpret_cast<const f32x4*>(rc + st * 32 + 8 * g4);
                         const f32x4 c = *reinterpret_cast<const f32x4*>(rc + 64 + st * 32 + 8 * g4);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { lsr[st][4 * g4 + e] = a[e]; dlr[st][4 * g4 + e] = c[e]; }
+                        for (int e = 0; e < 4; ++e) {
+                            if constexpr (LEAN) {
+                                linit[st][4 * g4 + e] = a[e];
+                                dinit[st][4 * g4 + e] = c[e];
+                            } else {
+                                lsr[st][4 * g4 + e] = a[e];
+                                dlr[st][4 * g4 + e] = c[e];
+                            }
+                        }
                     }
                 };
                 // One element (accumulator register e of sub-tile st) in four stages.  A wave alone on its SIMD pays every dependent pair of
@@ -897,7 +926,27 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
                 auto stage = [&](auto stc, auto ec, auto kc) {
                     constexpr int st = stc.value, e = ec.value, k = kc.value;
                     if constexpr (e < 0 || e >= 16 || (ATTN_ABL & 2)) return;
-                    else if constexpr (k == 0) {
+                    else if constexpr (LEAN) {
+                        // sacc = the exponent of P already, pacc = dP - delta already: exp2, multiply, pack
+                        if constexpr (k == 1 && BOUNDARY) {
+                            const int qq = qt * 64 + st * 32 + acc_row(e, lane);
+                            const bool masked = (causal && kg > qq) || !kreal || qq >= S;
+                            sacc[st][e] = masked ? -INFINITY : sacc[st][e];  // exp2(-inf) = 0: no branch around the exp
+                            asm volatile("" : "+v"(sacc[st][e]));
+                        } else if constexpr (k == 2) {
+                            pv[st][e] = __builtin_amdgcn_exp2f(sacc[st][e]);
+                            asm volatile("" : "+v"(pv[st][e]));
+                        } else if constexpr (k == 3) {
+                            dsv[st][e] = pacc[st][e] * pv[st][e];  // dS / scale (the factor is applied to dK once)
+                            if constexpr (e % 2 == 1) {
+                                pw[st][e / 2] = pack_bf2(pv[st][e - 1], pv[st][e]);
+                                dsw[st][e / 2] = pack_bf2(dsv[st][e - 1], dsv[st][e]);
+                                asm volatile("" : "+v"(pw[st][e / 2]), "+v"(dsw[st][e / 2]));
+                            } else {
+                                asm volatile("" : "+v"(dsv[st][e]));
+                            }
+                        }
+                    } else if constexpr (k == 0) {
                         lsr[st][e] *= LOG2E;
                         asm volatile("" : "+v"(lsr[st][e]));
                     } else if constexpr (k == 1) {
@@ -932,6 +981,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
                             static_for<PER>([&](auto i) { stage(stc, std::integral_constant<int, (m - kc.value) * PER + i.value>{}, kc); });
                         });
                 };
+                if constexpr (LEAN) row_constants(std::integral_constant<int, 0>{});  // the first chains start from them
                 static_for<PD>([&](auto g) { load(g); });
                 [[maybe_unused]] unsigned long long t_seg = PROF_T();
                 static_for<NG>([&](auto gc) {
@@ -941,11 +991,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
                         if (prof_on) { const unsigned long long now = __builtin_readcyclecounter(); prof_acc[8 + (g == NA ? 0 : g == 2 * NA ? 1 : 2)] += now - t_seg; t_seg = now; }
                     }
 #endif
-                    if constexpr (g == NA - 1) row_constants(std::integral_constant<int, 0>{});
+                    if constexpr (!LEAN && g == NA - 1) row_constants(std::integral_constant<int, 0>{});
+                    if constexpr (LEAN && g == NA - 4) row_constants(std::integral_constant<int, 1>{});  // a few products ahead of the chains they start
                     load(std::integral_constant<int, g + PD>{});
                     if constexpr (g < 2 * NA) {
                         constexpr int st = g / NA, ks = (g % NA) / 2, which = g % 2;
                         if constexpr ((ATTN_ABL & 8) && ks > 0) {
+                        } else if constexpr (LEAN && ks == 0) {
+                            if constexpr (which == 0) mfma_ownedB_init<OWNED, KF0>(sacc[st], f[g % RING], linit[st]);
+                            else mfma_ownedB_init<OWNED, VF0>(pacc[st], f[g % RING], dinit[st]);
                         } else if constexpr (which == 0) mfma_ownedB<OWNED, KF0 + 4 * ks, ks == 0>(sacc[st], f[g % RING]);
                         else mfma_ownedB<OWNED, VF0 + 4 * ks, ks == 0>(pacc[st], f[g % RING]);
                     } else if constexpr (!(ATTN_ABL & 4)) {
@@ -967,7 +1021,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
                     static_assert(16 % NA == 0 && 16 % NC == 0 && 16 / (16 / NA) + 3 <= NA + NC / 2 && 16 / (16 / NC) + 3 <= NC + NC / 2, "B phase does not fit its gaps");
                     b_step(std::integral_constant<int, 0>{}, std::integral_constant<int, g - NA>{}, std::integral_constant<int, 16 / NA>{});
                     b_step(std::integral_constant<int, 1>{}, std::integral_constant<int, g - 2 * NA>{}, std::integral_constant<int, 16 / NC>{});
-                    if constexpr (g == 2 * NA - 1) row_constants(std::integral_constant<int, 1>{});
+                    if constexpr (!LEAN && g == 2 * NA - 1) row_constants(std::integral_constant<int, 1>{});
                     // keep this step's VALU where it is written: left alone, hipcc gathers a whole B phase into one MFMA gap
                     __builtin_amdgcn_sched_barrier(0);
                 });
@@ -1176,10 +1230,15 @@ extern "C" int mi355_attn_fwd(int B, int S, int Hq, int Hkv, int D, const void* 
     return 0;
 }
 
+// the dS scratch: one bf16 per (query, key) of the padded square
+static int64_t attn_bwd_ds_bytes(int B, int S, int Hq) {
+    const int64_t nqb = (S + 127) / 128;
+    return (int64_t)B * Hq * nqb * nqb * 128 * 128 * 2;
+}
 extern "C" int64_t mi355_attn_bwd_workspace_bytes(int B, int S, int Hq, int D) {
     if (D != 128 || B <= 0 || S <= 0 || Hq <= 0) return 0;  // the spilled form is built for head_dim 128
-    const int64_t nqb = (S + 127) / 128;
-    return (int64_t)B * Hq * nqb * nqb * 128 * 128 * 2;  // one bf16 per (query, key) of the padded square
+    // dS scratch, then -lse * log2(e) and -delta (fp32 [B, Hq, S] each): the initial accumulators of the dK/dV pass
+    return attn_bwd_ds_bytes(B, S, Hq) + 2 * (((int64_t)B * Hq * S * 4 + 15) & ~(int64_t)15);
 }
 
 extern "C" int mi355_attn_bwd_ws(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk,
@@ -1226,10 +1285,16 @@ extern "C" int mi355_attn_bwd_ws(int B, int S, int Hq, int Hkv, int D, const voi
         MI355_REQUIRE(((uintptr_t)workspace & 15) == 0, "mi355_attn_bwd_ws: workspace must be 16-byte aligned");
     }
     bf16_t* ds_ws = spill ? (bf16_t*)workspace : nullptr;
+    float* nl2 = spill ? (float*)((char*)workspace + attn_bwd_ds_bytes(B, S, Hq)) : nullptr;
+    float* ndl = spill ? (float*)((char*)nl2 + (((int64_t)B * Hq * S * 4 + 15) & ~(int64_t)15)) : nullptr;
 #define BWD_LAUNCH(DD)                                                                                                              \
-    hipLaunchKernelGGL(attn_delta_kernel<DD>, dim3(dgrid), dim3(256), 0, s, B, S, Hq, (const bf16_t*)o, ldo, (const bf16_t*)d_o, lddo, delta); \
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<DD>, dim3((unsigned)gk), dim3(256), 0, s, B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, \
-                       (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, key_mask, causal, scale, sl2, bpw_k, ds_ws); \
+    hipLaunchKernelGGL(attn_delta_kernel<DD>, dim3(dgrid), dim3(256), 0, s, B, S, Hq, (const bf16_t*)o, ldo, (const bf16_t*)d_o, lddo, delta, lse, nl2, ndl); \
+    if (spill && DD == 128)                                                                                                         \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, true>), dim3((unsigned)gk), dim3(256), 0, s, B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, \
+                           (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, nl2, ndl, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, key_mask, causal, scale, sl2, bpw_k, ds_ws); \
+    else                                                                                                                             \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<DD, false>), dim3((unsigned)gk), dim3(256), 0, s, B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, \
+                           (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, key_mask, causal, scale, sl2, bpw_k, ds_ws); \
     if (!spill)                                                                                                                      \
         hipLaunchKernelGGL(attn_bwd_dq_kernel<DD>, dim3((unsigned)gq), dim3(256), 0, s, B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,  \
                            (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dq, lddq, key_mask, causal, scale, sl2, bpw_q);

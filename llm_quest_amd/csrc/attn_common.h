@@ -245,6 +245,13 @@ __device__ __forceinline__ void mfma_ownedB(f32x16& acc, const bf16x8& a) {
     if constexpr (FIRST) OWNED_ASM(OWNED, "v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(acc) : "v"(a), "i"(R0), "i"(R0 + 3));
     else OWNED_ASM(OWNED, "v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(acc) : "v"(a), "i"(R0), "i"(R0 + 3));
 }
+// the same, the chain's first product: acc = A x ownedB + init (a compiler-allocated tile of initial values -- row constants such as -lse)
+template <int OWNED, int OFF>
+__device__ __forceinline__ void mfma_ownedB_init(f32x16& acc, const bf16x8& a, const f32x16& init) {
+    static_assert(OFF % 4 == 0 && OFF + 4 <= OWNED, "operand outside the owned range");
+    constexpr int R0 = 256 - OWNED + OFF;
+    OWNED_ASM(OWNED, "v_mfma_f32_32x32x16_bf16 %0, %1, a[%c3:%c4], %2" : "=&v"(acc) : "v"(a), "v"(init), "i"(R0), "i"(R0 + 3));
+}
 // wait states between the last MFMA into a compiler-allocated tile and its first VALU read (16-pass XDL -> read: 18)
 __device__ __forceinline__ void tiles_settle(f32x16& x, f32x16& y) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(x), "+v"(y)); }
 template <int OWNED, int OFF, int COUNT>

@@ -429,8 +429,10 @@ def test_attention_fwd_bwd(K, B, S, Hq, Hkv, D, causal, ragged):
                                                       (2, 200, 4, 2, True, "holes")])
 def test_attention_backward_scratch_form_equals_recompute_form(K, B, S, Hq, Hkv, causal, ragged):
     """mi355_attn_bwd_ws (the dK/dV pass leaves dS in a scratch buffer, dQ = scale * dS K is one product over it) against the form
-    without a workspace (the dQ pass recomputes S and dP): the same bf16 dS words meet the same K fragments in the same order, so
-    the three gradients are bit-identical; a scratch buffer that is too small is refused."""
+    without a workspace (the dQ pass recomputes S and dP).  The two were bit-identical while they shared their arithmetic; since round 3 the
+    scratch form's dK/dV pass folds the scale into its bf16 K rows and starts its chains from -lse / -delta (one more operand rounding, ~1e-3
+    of a score), so they agree to the bf16 level of a gradient, and each is checked against fp64 elsewhere; a scratch buffer that is too small
+    is refused."""
     D = 128
     g = torch.Generator().manual_seed(S + Hq)
     q, k, v, do = (dev(torch.randn(B * S, w * D, generator=g).to(BF16)) for w in (Hq, Hkv, Hkv, Hq))
@@ -453,11 +455,12 @@ def test_attention_backward_scratch_form_equals_recompute_form(K, B, S, Hq, Hkv,
         finally:
             K._ATTN_DS_SPILL = True
     for a, b in zip(*outs):
-        assert torch.isfinite(b.float()).all() and torch.equal(a, b)
+        assert torch.isfinite(b.float()).all() and rel_l2(a, b) < 6e-3
     from llm_quest_amd import _lib as L
 
     need = L.load().mi355_attn_bwd_workspace_bytes(B, S, Hq, D)
-    assert need == B * Hq * ((S + 127) // 128 * 128) ** 2 * 2 and L.load().mi355_attn_bwd_workspace_bytes(B, S, Hq, 64) == 0
+    rows = (B * Hq * S * 4 + 15) // 16 * 16  # -lse * log2(e) and -delta, fp32 [B, Hq, S] each, behind the dS scratch
+    assert need == B * Hq * ((S + 127) // 128 * 128) ** 2 * 2 + 2 * rows and L.load().mi355_attn_bwd_workspace_bytes(B, S, Hq, 64) == 0
     ws = torch.empty(need - 16, dtype=torch.uint8, device="cuda")
     delta = torch.empty_like(lse)
     L.require_gpu(q, ws)
@@ -477,7 +480,7 @@ def test_attention_backward_scratch_is_capped_and_falls_back_to_the_recompute_fo
     from llm_quest_amd import _lib as L
 
     need = L.load().mi355_attn_bwd_workspace_bytes(B, S, Hq, D)
-    assert need == B * Hq * S * S * 2
+    assert need == B * Hq * S * S * 2 + 2 * B * Hq * S * 4
     K.release_attention_scratch()
     monkeypatch.setattr(K, "_ATTN_DS_SPILL_MAX", need - 1)
     before = dict(K.attn_bwd_form)
@@ -493,7 +496,7 @@ def test_attention_backward_scratch_is_capped_and_falls_back_to_the_recompute_fo
     dq2, dk2, dv2 = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
     K.attn_bwd(q, k, v, o, do, lse, B, S, Hq, Hkv, D, dq2, dk2, dv2, causal=True)
     assert K.attn_bwd_form["spill"] == before["spill"] + 1 and len(K._ATTN_WS) == 1
-    assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)
+    assert rel_l2(dq, dq2) < 6e-3 and rel_l2(dk, dk2) < 6e-3 and rel_l2(dv, dv2) < 6e-3  # (the two forms round one operand differently)
     # a much smaller request on the same stream replaces the big buffer instead of pinning it
     K.attn_bwd(q[: 2 * 128], k[: 2 * 128], v[: 2 * 128], o[: 2 * 128], do[: 2 * 128], lse[:2, :, :128].contiguous(), 2, 128, Hq, Hkv, D,
                dq2[: 2 * 128], dk2[: 2 * 128], dv2[: 2 * 128], causal=True)

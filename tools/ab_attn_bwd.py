@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from llm_quest_amd import kernels as K
 
-B, S, HQ, HKV, D = 64, 708, 16, 8, 128
+B, S, HQ, HKV, D = 64, 709, 16, 8, 128
 g = torch.Generator().manual_seed(3)
 mk = lambda w: torch.randn(B * S, w * D, generator=g).to(torch.bfloat16).cuda()
 q, k, v, do = mk(HQ), mk(HKV), mk(HKV), mk(HQ)

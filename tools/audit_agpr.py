@@ -2,7 +2,7 @@
 an accumulator register of the range its statements own (the top `owned` AGPRs).  usage: audit_agpr.py <file.s>"""
 import re, sys
 
-OWNED = {"attn_bwd_dkv_kernelILi128E": 192, "attn_bwd_dq_kernelILi128E": 128, "attn_bwd_dkv_kernelILi64E": 96, "attn_bwd_dq_kernelILi64E": 64}
+OWNED = {"attn_bwd_dkv_kernelILi128ELb1E": 192, "attn_bwd_dkv_kernelILi128ELb0E": 192, "attn_bwd_dq_kernelILi128E": 128, "attn_bwd_dkv_kernelILi64ELb0E": 96, "attn_bwd_dq_kernelILi64E": 64}
 OWNED_FWD2 = {"attn_fwd2_kernelILi128E": 192}  # attention_fwd2.hip
 
 
