@@ -155,13 +155,13 @@ def _profile_json(name):
 def pmc_traffic():
     """TCC counters of the dominant kernel, collected with rocprofv3 --pmc in separate passes and committed (PMC cannot be read
     from inside the timed process)."""
-    d, why = _profile_json("r02_pmc_tcc_gemm.json")
+    d, why = _profile_json("r03_pmc_tcc_gemm.json")
     return (d["kernels"] if d else None), why
 
 
 def pmc_step_traffic():
-    """Whole-step TCC counters (profiles/r02_pmc_tcc_step.json), collected with rocprofv3 --pmc over this script."""
-    return _profile_json("r02_pmc_tcc_step.json")
+    """Whole-step TCC counters (profiles/r03_pmc_tcc_step.json), collected with rocprofv3 --pmc over this script."""
+    return _profile_json("r03_pmc_tcc_step.json")
 
 
 def dominant_kernel_rate(batch, device):
@@ -214,7 +214,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="per-GPU micro-batch (samples); 64 x 709 tokens keeps ~70 GB of the 288 GB HBM live")
+    ap.add_argument("--batch", type=int, default=92, help="per-GPU micro-batch (samples).  92 x 709 = 65 228 token rows = 254.8 row tiles of 256: the step's GEMM grids fill "
+                    "whole rounds of 256 CUs (99.6 %% of the last one; 92.7 %% at 64) and 92 x 8 kv heads = 2.9 rounds of the attention backward; ~100 GB of the 288 GB HBM live")
     ap.add_argument("--cpu-baseline", choices=["auto", "off"], default="auto")
     ap.add_argument("--ragged", action="store_true", help="text lengths ~ U[256, 512] (padding mask active in attention and loss) instead of all-ones masks")
     ap.add_argument("--optimizer", choices=["on", "off"], default="on", help="also time the same steps with clip + AdamW (reported beside the fwd+bwd metric)")
@@ -358,20 +359,21 @@ def main():
             line["roofline"]["dominant_kernel"] = {"name": "gemm_bf16_kernel", "hip_event_timing": dominant_kernel_rate(args.batch, device)}
             pmc, why_gemm = pmc_traffic()
             step_pmc, why_step = pmc_step_traffic()
-            if args.batch != 64:  # the PMC passes were taken at this batch's shapes
-                line["roofline"]["traffic_note"] = "the committed counter passes were taken at per-GPU batch 64"
+            pmc_batch = step_pmc.get("per_gpu_batch") if step_pmc else None
+            if step_pmc is not None and pmc_batch != args.batch:  # the PMC passes were taken at another batch's shapes
+                line["roofline"]["traffic_note"] = f"the committed counter passes were taken at per-GPU batch {pmc_batch}"
             elif step_pmc is None:
                 line["roofline"]["traffic_note"] = "traffic withheld: " + why_step
             else:
                 line["roofline"]["traffic"] = step_pmc["per_step"]["total_bytes"]
                 line["roofline"]["traffic_note"] = (
                     "memory-side bytes PER STEP (like `achieved`): 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE summed over every kernel of one step, separate "
-                    "rocprofv3 --pmc passes over this bench (profiles/r02_pmc_tcc_step.json, per-kernel table inside; fingerprint of the kernel sources checked); "
+                    "rocprofv3 --pmc passes over this bench (profiles/r03_pmc_tcc_step.json, per-kernel table inside; fingerprint of the kernel sources checked); "
                     "Infinity-Cache hits are counted in FETCH_SIZE")
-            if args.batch == 64 and pmc is not None:
+            if pmc is not None and pmc_batch == args.batch:
                 line["roofline"]["dominant_kernel"]["pmc_bytes_per_launch"] = {f: pmc[f]["hbm_bytes"] for f in pmc}
                 line["roofline"]["dominant_kernel"]["over_algorithmic"] = {f: pmc[f]["over_algorithmic"] for f in pmc}
-            elif args.batch == 64:
+            elif pmc is None:
                 line["roofline"]["dominant_kernel"]["pmc_note"] = "withheld: " + why_gemm
         if world == 1 and args.cpu_baseline == "auto":
             try:

@@ -218,8 +218,10 @@ int mi355_cast(int64_t n, const void* src, int src_dtype, void* dst, int dst_dty
 /* y[b, s, :] = x[b, s, :] + pos[s, :]  with row 0 of each batch = cls + pos[0] (vit_model.py:86-87,145) */
 int mi355_vit_embed_assemble(int B, int S, int width, const float* patch_proj, const float* cls, const float* pos,
                              float* out, void* stream);
-/* sum of squares of a bf16/fp32 vector into out[0] (+=) : global grad-norm for clip_grad_norm_ (engine.py:445) */
-int mi355_sumsq(int64_t n, const void* x, int dtype, float* out, void* stream);
+/* sum of squares of a bf16/fp32 vector into out[0] (+=) : global grad-norm for clip_grad_norm_ (engine.py:445).  partials: scratch of
+ * MI355_SUMSQ_PARTS floats owned by the caller -- one per stream (per-block partial sums, added in a fixed order: no float atomics). */
+#define MI355_SUMSQ_PARTS 4096
+int mi355_sumsq(int64_t n, const void* x, int dtype, float* out, float* partials, void* stream);
 /* x *= min(1, max_norm / (sqrt(*sumsq) + 1e-6))  (torch.nn.utils.clip_grad_norm_ semantics) */
 int mi355_clip_scale(int64_t n, void* x, int dtype, const float* sumsq, float max_norm, void* stream);
 /* y = x * (*scale), bf16, scale is a DEVICE fp32 scalar (autograd's incoming grad_output, no host sync) */

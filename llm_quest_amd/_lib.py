@@ -50,7 +50,7 @@ SIGNATURES = {
     "mi355_layernorm_bwd": [_L, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _F, _I, _P],
     "mi355_cast": [_L, _P, _I, _P, _I, _P],
     "mi355_vit_embed_assemble": [_I, _I, _I, _P, _P, _P, _P, _P],
-    "mi355_sumsq": [_L, _P, _I, _P, _P],
+    "mi355_sumsq": [_L, _P, _I, _P, _P, _P],
     "mi355_clip_scale": [_L, _P, _I, _P, _F, _P],
     "mi355_add_f32_to_bf16": [_L, _P, _P, _P, _P],
     "mi355_scale_bf16": [_L, _P, _P, _P, _P],
@@ -153,7 +153,10 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
-_call_device = None  # device of the tensors checked by the last require_gpu(): the launch that follows runs there
+import threading
+
+_tls = threading.local()  # .device: device of the tensors checked by this THREAD's last require_gpu() -- the launch that follows runs there
+# (autograd runs one thread per device: a module-level global would let one thread's require_gpu steer another thread's launch)
 
 
 def stream(device=None):
@@ -164,9 +167,9 @@ def call(name, *args):
     """Invoke an entry point on the current HIP stream OF THE DEVICE THE OPERANDS LIVE ON (``require_gpu`` recorded it); raise
     RuntimeError with the library's message on failure.  Without the guard a model on cuda:1 under a current device of cuda:0
     would be enqueued on cuda:0's stream with cuda:1's pointers."""
-    global _call_device
     lib = load()
-    dev, _call_device = _call_device, None
+    dev = getattr(_tls, "device", None)
+    _tls.device = None
     if dev is not None and dev.index is not None and dev.index != torch.cuda.current_device():
         with torch.cuda.device(dev):
             rc = getattr(lib, name)(*args, stream(dev))
@@ -178,7 +181,6 @@ def call(name, *args):
 
 def require_gpu(*tensors):
     """Every operand must be a HIP tensor, and all of them on ONE device; remembers that device for the ``call`` that follows."""
-    global _call_device
     dev = None
     for t in tensors:
         if t is None:
@@ -192,7 +194,7 @@ def require_gpu(*tensors):
             dev = t.device
         elif t.device != dev:
             raise RuntimeError(f"llm_quest_amd ops: operands live on different devices ({dev} and {t.device})")
-    _call_device = dev
+    _tls.device = dev
 
 
 def dt_code(dtype):

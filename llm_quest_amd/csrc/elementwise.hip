@@ -539,19 +539,19 @@ __global__ __launch_bounds__(256) void scale_bf16_kernel(int64_t n, const bf16_t
 
 // Global squared norm, bit-reproducible: every block leaves ONE partial in a per-device scratch row, a second one-wave kernel adds the
 // partials in a fixed order and accumulates into *out (no float atomics: their arrival order would move the last bits of the clip
-// factor from run to run).  The scratch is shared by all calls on a device: issue the calls of one optimizer step on one stream.
-constexpr int SUMSQ_MAX_PARTS = 4096;
-__device__ float g_sumsq_part[SUMSQ_MAX_PARTS];
+// factor from run to run).  The partials live in a caller-provided buffer (MI355_SUMSQ_PARTS floats): one per stream, so that calls on
+// different streams cannot race for it.
+constexpr int SUMSQ_MAX_PARTS = MI355_SUMSQ_PARTS;
 
-__global__ __launch_bounds__(64) void sumsq_finish_kernel(int parts, float* __restrict__ out) {
+__global__ __launch_bounds__(64) void sumsq_finish_kernel(int parts, const float* __restrict__ part, float* __restrict__ out) {
     float s = 0.f;
-    for (int i = threadIdx.x; i < parts; i += 64) s += g_sumsq_part[i];
+    for (int i = threadIdx.x; i < parts; i += 64) s += part[i];
     s = wave_sum(s);
     if (threadIdx.x == 0) *out += s;
 }
 
 template <int DT>
-__global__ __launch_bounds__(256) void sumsq_kernel(int64_t n, const void* __restrict__ x, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void sumsq_kernel(int64_t n, const void* __restrict__ x, float* __restrict__ part) {
     __shared__ float red[4];
     float s = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(int64_t n, const void* __res
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) g_sumsq_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 template <int DT>
 __global__ __launch_bounds__(256) void clip_scale_kernel(int64_t n, void* __restrict__ x, const float* __restrict__ sumsq, float max_norm) {
@@ -780,15 +780,15 @@ extern "C" int mi355_scale_bf16(int64_t n, const void* x, const float* scale, vo
     return 0;
 }
 
-extern "C" int mi355_sumsq(int64_t n, const void* x, int dtype, float* out, void* stream) {
-    MI355_REQUIRE(n > 0 && x && out, "mi355_sumsq: bad arguments");
+extern "C" int mi355_sumsq(int64_t n, const void* x, int dtype, float* out, float* partials, void* stream) {
+    MI355_REQUIRE(n > 0 && x && out && partials, "mi355_sumsq: bad arguments");
     int parts = grid_for(n, 256 * 8);
     if (parts > SUMSQ_MAX_PARTS) parts = SUMSQ_MAX_PARTS;
     if (dtype == MI355_DT_BF16)
-        hipLaunchKernelGGL(sumsq_kernel<MI355_DT_BF16>, dim3(parts), dim3(256), 0, STREAM, n, x, out);
+        hipLaunchKernelGGL(sumsq_kernel<MI355_DT_BF16>, dim3(parts), dim3(256), 0, STREAM, n, x, partials);
     else
-        hipLaunchKernelGGL(sumsq_kernel<MI355_DT_F32>, dim3(parts), dim3(256), 0, STREAM, n, x, out);
-    hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(64), 0, STREAM, parts, out);
+        hipLaunchKernelGGL(sumsq_kernel<MI355_DT_F32>, dim3(parts), dim3(256), 0, STREAM, n, x, partials);
+    hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(64), 0, STREAM, parts, partials, out);
     MI355_LAUNCH_CHECK("mi355_sumsq");
     return 0;
 }

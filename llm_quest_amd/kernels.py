@@ -512,10 +512,24 @@ def vit_embed_assemble(proj, cls, pos, B, S, width):
     return out
 
 
+_SUMSQ_PARTS = {}
+
+
+def _sumsq_parts(device):
+    """Per (device, stream) scratch of mi355_sumsq's per-block partial sums (4096 floats): calls on different streams never share one."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _SUMSQ_PARTS.get(key)
+    if buf is None:
+        if len(_SUMSQ_PARTS) > 16:
+            _SUMSQ_PARTS.clear()
+        buf = _SUMSQ_PARTS[key] = torch.empty(4096, dtype=F32, device=device)
+    return buf
+
+
 def sumsq_into(x, acc):
     L.require_gpu(x, acc)
     x = x if x.is_contiguous() else x.contiguous()
-    L.call("mi355_sumsq", x.numel(), L.ptr(x), L.dt_code(x.dtype), L.ptr(acc))
+    L.call("mi355_sumsq", x.numel(), L.ptr(x), L.dt_code(x.dtype), L.ptr(acc), L.ptr(_sumsq_parts(x.device)))
 
 
 def clip_scale_(x, sumsq, max_norm):

@@ -1,14 +1,19 @@
+# Round-3 evidence collection (GPU box, from the repo root):   GIT_SHA=<sha> BATCH=92 bash tools/collect_evidence.sh
+# Writes raw rocprofv3 output under gpurun_out/r03ev/ and a stamp (kernel-source fingerprint, sha-256 of the loaded library, git sha, batch)
+# taken HERE, at collection time; tools/aggregate_evidence.sh turns it into profiles/r03_* in the container and copies the stamp.
 set -e
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02ev; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03ev; rm -rf $O; mkdir -p $O
+B=${BATCH:-92}; M=$((B * 709))
+(cd $R && python3 -m llm_quest_amd.fingerprint ${GIT_SHA:-unknown} $B > $O/stamp.json)
 SQ1="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
 SQ2="SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 4 --warmup 2 --cpu-baseline off > $O/bench_trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --batch $B --steps 4 --warmup 2 --cpu-baseline off > $O/bench_trace.log 2>&1
 echo trace done
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/step_fetch -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-baseline off > $O/step_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/step_write -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-baseline off > $O/step_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/step_fetch -- python3 $R/bench.py --batch $B --steps 1 --warmup 1 --cpu-baseline off > $O/step_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/step_write -- python3 $R/bench.py --batch $B --steps 1 --warmup 1 --cpu-baseline off > $O/step_write.log 2>&1
 echo step pmc done
-for spec in "NT 45376 6144 1024 nt_gateup" "NT 45376 1024 6144 nt_dgrad" "TN 6144 1024 45376 tn_wgrad"; do
+for spec in "NT $M 6144 1024 nt_gateup" "NT $M 1024 6144 nt_dgrad" "TN 6144 1024 $M tn_wgrad"; do
   set -- $spec
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${5}_fetch -- python3 $R/tools/gemm_one.py $1 0 $2 $3 $4 3 > $O/${5}_fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${5}_write -- python3 $R/tools/gemm_one.py $1 0 $2 $3 $4 3 > $O/${5}_write.log 2>&1
@@ -16,8 +21,6 @@ for spec in "NT 45376 6144 1024 nt_gateup" "NT 45376 1024 6144 nt_dgrad" "TN 614
   rocprofv3 --pmc $SQ2 --kernel-trace --output-format csv -d $O/${5}_sq2 -- python3 $R/tools/gemm_one.py $1 0 $2 $3 $4 6 > $O/${5}_sq2.log 2>&1
   echo $5 done
 done
-rocprofv3 --pmc $SQ1 --kernel-trace --output-format csv -d $O/attn_sq1 -- python3 $R/tools/attn_one.py 64 3 > $O/attn_sq1.log 2>&1
-rocprofv3 --pmc $SQ2 --kernel-trace --output-format csv -d $O/attn_sq2 -- python3 $R/tools/attn_one.py 64 3 > $O/attn_sq2.log 2>&1
+rocprofv3 --pmc $SQ1 --kernel-trace --output-format csv -d $O/attn_sq1 -- python3 $R/tools/attn_one.py $B 3 > $O/attn_sq1.log 2>&1
+rocprofv3 --pmc $SQ2 --kernel-trace --output-format csv -d $O/attn_sq2 -- python3 $R/tools/attn_one.py $B 3 > $O/attn_sq2.log 2>&1
 echo attn done
-python3 $R/bench.py --steps 20 --warmup 3 > $O/bench_final.json 2> $O/bench_final.err
-cut -c1-400 $O/bench_final.json

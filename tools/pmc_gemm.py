@@ -1,10 +1,10 @@
 """Memory-side traffic of the step's dominant GEMM, per form, from rocprofv3 --pmc passes over tools/gemm_one.py (one GEMM per process):
-    python tools/pmc_gemm.py <out.json> FORM:<fetch_dir>:<write_dir>:M:N:K:what ...
+    python tools/pmc_gemm.py <out.json> <collection_dir> FORM:<fetch_dir>:<write_dir>:M:N:K:what ...
 FETCH_SIZE / WRITE_SIZE are collected in SEPARATE passes (TCC slots); rocprofv3 reports KiB; gfx950 correction: FETCH_SIZE doubled
 (128-byte requests tallied at 64), WRITE_SIZE exact (MI355X_MICROARCH.md, HBM section).  The first launch of a process is cold and is dropped."""
 import csv, glob, json, os, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from llm_quest_amd.fingerprint import kernel_sources_sha
+from llm_quest_amd.fingerprint import collection_stamp
 
 
 def avg(d, counter):
@@ -21,10 +21,10 @@ def avg(d, counter):
     return sum(vals) / len(vals), sum(durs) / len(durs)
 
 
-out = {"kernel_sources_sha": kernel_sources_sha(),
-       "git_sha": subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip(),
+stamp = collection_stamp(sys.argv[2])  # written on the GPU box when the counters were collected
+out = {"kernel_sources_sha": stamp["kernel_sources_sha"], "library_sha": stamp["library_sha"], "git_sha": stamp["git_sha"],
        "note": __doc__.strip().split("\n", 2)[2], "kernels": {}}
-for spec in sys.argv[2:]:
+for spec in sys.argv[3:]:
     form, fd, wd, M, N, K, what = spec.split(":", 6)
     M, N, K = int(M), int(N), int(K)
     f_kib, f_us = avg(fd, "FETCH_SIZE")

@@ -1,4 +1,4 @@
-"""Per-kernel SQ / GRBM counters from rocprofv3 --pmc passes:  python tools/pmc_sq.py <out.json> <label> <dir> [<dir> ...]
+"""Per-kernel SQ / GRBM counters from rocprofv3 --pmc passes:  python tools/pmc_sq.py <out.json> <label> <collection_dir> <dir> [<dir> ...]
 Each <dir> is the output of one `rocprofv3 --pmc ... --kernel-trace` pass over the same program (slots: 8 SQ + 2 GRBM per pass).
 Counters are averaged per dispatch and merged per kernel; derived columns follow MI355X_MICROARCH.md: SQ_WAVE_CYCLES / SQ_WAIT_* /
 SQ_ACTIVE_* count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles (32 per v_mfma_f32_32x32x16_bf16, 16 per 16x16x32);
@@ -12,7 +12,7 @@ def short(n):
     return re.sub(r"\(.*", "", n)[:100]
 
 
-out_path, label, dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
+out_path, label, coll, dirs = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4:]
 agg = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
 dur = defaultdict(lambda: [0, 0.0])
 for d in dirs:
@@ -26,10 +26,10 @@ for d in dirs:
             t = dur[short(r["Kernel_Name"])]
             t[0] += 1
             t[1] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
-try:
-    sha = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-except OSError:
-    sha = "unknown"
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from llm_quest_amd.fingerprint import collection_stamp
+stamp = collection_stamp(coll)  # written on the GPU box when the counters were collected
+sha = stamp["git_sha"]
 res = {"label": label, "git_sha": sha, "note": __doc__.split("\n\n")[0].split("\n", 1)[1] if False else "per-dispatch averages; see tools/pmc_sq.py for units", "kernels": {}}
 for k, cs in agg.items():
     row = {c: v[1] / v[0] for c, v in cs.items()}
@@ -55,9 +55,7 @@ try:
 except (OSError, ValueError):
     allres = {"runs": []}
 allres["runs"] = [r for r in allres["runs"] if r["label"] != label] + [res]
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
-from llm_quest_amd.fingerprint import kernel_sources_sha
-allres["kernel_sources_sha"] = kernel_sources_sha()  # the sources the newest run was measured on (collect every label in one go)
+allres["kernel_sources_sha"], allres["library_sha"] = stamp["kernel_sources_sha"], stamp["library_sha"]
 json.dump(allres, open(out_path, "w"), indent=1)
 for k, row in sorted(res["kernels"].items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[:12]:
     print(k[:70], {c: (round(v, 3) if v < 100 else int(v)) for c, v in row.items() if c.endswith(("pct", "GHz", "cycles", "mfma", "pmc"))})

@@ -1,10 +1,10 @@
 """Whole-step memory-side traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, each with --kernel-trace) over
-`python3 bench.py --steps 1 --warmup 1 --cpu-baseline off`:  python tools/pmc_step.py <fetch_dir> <write_dir> <steps_in_trace> <out.json>
+`python3 bench.py --steps 1 --warmup 1 --cpu-baseline off`:  python tools/pmc_step.py <fetch_dir> <write_dir> <steps_in_trace> <out.json> <collection_dir>
 Units and corrections as MI355X_MICROARCH.md prescribes: rocprofv3 reports KiB; on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, so it is doubled."""
 import csv, glob, json, os, re, subprocess, sys
 from collections import defaultdict
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from llm_quest_amd.fingerprint import kernel_sources_sha
+from llm_quest_amd.fingerprint import collection_stamp
 
 
 def load(d, counter):
@@ -37,11 +37,11 @@ for name in set(fetch) | set(write):
     rows.append({"kernel": short(name), "launches_per_step": per_step, "fetch_bytes": int(fb), "write_bytes": int(wb)})
 rows.sort(key=lambda r: -(r["fetch_bytes"] + r["write_bytes"]))
 tot_f, tot_w = sum(r["fetch_bytes"] for r in rows), sum(r["write_bytes"] for r in rows)
+stamp = collection_stamp(sys.argv[5])  # written on the GPU box when the counters were collected
 out = {
-    "kernel_sources_sha": kernel_sources_sha(),
-    "git_sha": subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip(),
+    "kernel_sources_sha": stamp["kernel_sources_sha"], "library_sha": stamp["library_sha"], "git_sha": stamp["git_sha"], "per_gpu_batch": stamp["per_gpu_batch"],
     "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, TCC slots) with --kernel-trace over `python3 bench.py --steps 1 --warmup 1 "
-            "--cpu-baseline off` (per-GPU batch 64: 4 steps in each trace -- warm-up + timed, without and with the optimizer); figures are PER STEP = per-launch "
+            "--cpu-baseline off` (per-GPU batch as stamped: 4 steps in each trace -- warm-up + timed, without and with the optimizer); figures are PER STEP = per-launch "
             "average x launches per step, so the bench's 13 stand-alone launches of each gate-up GEMM form drop out, and the optimizer's own kernels are left out (the headline step has none).  KiB units from rocprofv3; gfx950 correction: FETCH_SIZE doubled (128-byte requests "
             "tallied at 64), WRITE_SIZE exact.  Infinity-Cache hits are included in FETCH_SIZE (memory-side L2 requests).",
     "per_step": {"fetch_bytes": tot_f, "write_bytes": tot_w, "total_bytes": tot_f + tot_w},
