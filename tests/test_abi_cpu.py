@@ -61,6 +61,29 @@ def test_host_side_validation_rejects_bad_calls_without_touching_the_gpu():
     assert rc != 0 and b"head_dim" in lib.mi355_last_error()
 
 
+def test_host_side_of_every_entry_point_is_clean_under_address_sanitizer():
+    """SURVEY.md section 5 (sanitizers, CPU build only): the AddressSanitizer build of the library (`make asan`: host code instrumented,
+    device code untouched) takes degenerate calls of EVERY entry point -- null pointers, zero / negative / huge sizes, odd enums -- in a
+    child process with the ASAN runtime preloaded (tools/asan_abi_probe.py).  Each call must return a code; ASAN must report nothing."""
+    import glob
+    import shutil
+    import subprocess
+    import sys
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    rts = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
+    if not os.path.exists(hipcc) or not rts:
+        pytest.skip("hipcc or its ASAN runtime not available")
+    csrc = os.path.join(ROOT, "llm_quest_amd", "csrc")
+    res = subprocess.run(["make", "-C", csrc, "-j8", "asan"], capture_output=True, text=True, timeout=1500)  # incremental: seconds when up to date
+    assert res.returncode == 0, res.stderr[-2000:]
+    lib = os.path.join(ROOT, "llm_quest_amd", "libmi355vlm_asan.so")
+    env = dict(os.environ, LD_PRELOAD=rts[0], ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=23")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asan_abi_probe.py"), lib], capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0 and "no fault" in res.stdout, (res.stdout[-500:], res.stderr[-3000:])
+    assert "AddressSanitizer" not in res.stderr, res.stderr[-3000:]
+
+
 def test_no_cpu_fallback():
     from llm_quest_amd import kernels
 
