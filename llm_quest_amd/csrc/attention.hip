@@ -308,6 +308,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lean_kernel(int B, int S, int
         }
     };
     const LaneOff<D> lo = lane_offsets<D>(lane);
+    const unsigned lds0 = (unsigned)(unsigned long long)LDS_PTR(smem);
     issue(0, 0);  // first tile first, then the query rows: their latencies overlap
     bf16x8 qf[C::KS];
     load_rows_frag<D>(q + (int64_t)b * S * ldq + (int64_t)hq * D, ldq, qg, qvalid, lane, qf);
@@ -319,7 +320,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lean_kernel(int B, int S, int
         qf[ks] = __builtin_bit_cast(bf16x8, w);
     }
     // key-padding byte of this lane's key in the NEXT tile: loaded one tile ahead so its latency hides behind a whole tile
-    uint8_t mk = (key_mask && lane < S) ? key_mask[(int64_t)b * S + lane] : (uint8_t)0;
+    // (unconditional, address clamped to the row: a guarded load becomes a branch whose join the compiler serves with `s_waitcnt vmcnt(0)`
+    // right behind the load, i.e. behind the tile request in front of it; bits of keys beyond S are cleared by `kbits` below)
+    const uint8_t* mrow = key_mask ? key_mask + (int64_t)b * S : nullptr;
+    uint8_t mk = mrow ? mrow[min(lane, S - 1)] : (uint8_t)0;
     unsigned tri16 = 0;  // causal mask of a diagonal 32 x 32 sub-tile: bit ee set <=> key row acc_row(ee) lies behind this lane's query
 #pragma unroll
     for (int ee = 0; ee < 16; ++ee) tri16 |= (acc_row(ee, lane) > (lane & 31) ? 1u : 0u) << ee;
@@ -338,22 +342,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lean_kernel(int B, int S, int
 
     for (int kt = 0; kt < ntiles; ++kt) {
         [[maybe_unused]] const unsigned long long t_sync = PROF_T();
+        // this wave's share of tile kt (requested a whole tile ago) and the mask byte have landed.  Explicit: the compiler orders LDS-DMA only against
+        // ds_read_tr INTRINSICS, and the V fragments below are read from asm statements
+        wait_vmcnt<0>();
         __syncthreads();
         PROF_ADD(1, t_sync);
+        // bit per key of this tile: 1 = a real token that exists (consumed before the next request, so its wait costs nothing)
+        const int nv = S - kt * 64;
+        unsigned long long kbits = nv >= 64 ? ~0ull : ((1ull << nv) - 1ull);
+        if (mrow) kbits &= __ballot(mk != 0);
         [[maybe_unused]] const unsigned long long t_iss = PROF_T();
         if (kt + 1 < ntiles) issue(kt + 1, (kt + 1) & 1);
         PROF_ADD(2, t_iss);
+        if (mrow) mk = mrow[min((kt + 1) * 64 + lane, S - 1)];
         [[maybe_unused]] unsigned long long t_seg = PROF_T();
         if (prof_on) prof_acc[7] += 1;
         const int koff = (kt & 1) * 2 * C::TILE, voff = koff + C::TILE;
-        // bit per key of this tile: 1 = a real token that exists
-        const int nv = S - kt * 64;
-        unsigned long long kbits = nv >= 64 ? ~0ull : ((1ull << nv) - 1ull);
-        if (key_mask) {
-            kbits &= __ballot(mk != 0);
-            const int kn = (kt + 1) * 64 + lane;
-            mk = kn < S ? key_mask[(int64_t)b * S + kn] : (uint8_t)0;
-        }
         // a wave whose 32 queries all precede this tile has nothing visible here
         if (causal && !allt && kt * 64 > qw + 31) continue;
         int vkx[C::KS], vv[C::DT];
@@ -369,6 +373,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lean_kernel(int B, int S, int
             for (int ks = 1; ks < C::KS; ++ks)
                 sacc[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(smem, vkx[ks], st * 32 * C::ROWB), qf[ks], sacc[st], 0, 0, 0);
         }
+        TrHalves ft[2][C::DT];
+        auto issue_v = [&](auto g_) {
+            constexpr int g = g_.value, imm = 16 * g * C::ROWB;
+            static_for<C::DT>([&](auto dt_) { tr_issue<imm, imm + 8 * C::ROWB>(ft[g & 1][dt_.value], lds0 + vv[dt_.value], lds0 + vv[dt_.value]); });
+        };
+        issue_v(std::integral_constant<int, 0>{});  // the first 16 keys' V fragments travel behind the softmax
 #if ATTN_ABL & 16
         asm volatile("" : "+v"(sacc[0]), "+v"(sacc[1]));
         if (prof_on) { const unsigned long long now = __builtin_readcyclecounter(); prof_acc[3] += now - t_seg; t_seg = now; }
@@ -446,15 +456,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lean_kernel(int B, int S, int
         asm volatile("" : "+v"(sacc[0]), "+v"(sacc[1]), "+v"(l));
         if (prof_on) { const unsigned long long now = __builtin_readcyclecounter(); prof_acc[4] += now - t_seg; t_seg = now; }
 #endif
-#pragma unroll
-        for (int st = 0; st < 2; ++st)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 pf = pack_frag(sacc[st], s);
-#pragma unroll
-                for (int dt = 0; dt < C::DT; ++dt)
-                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr<D>(smem, vv[dt], (st * 32 + 16 * s) * C::ROWB), pf, oacc[dt], 0, 0, 0);
-            }
+        // V fragments from asm statements (attn_common.h: an intrinsic read would draw `s_waitcnt vmcnt(0)` -- the whole latency of the tile
+        // just requested -- into the middle of this one); group g = 16 keys, its successor is requested before it is consumed
+        static_for<4>([&](auto g_) {
+            constexpr int g = g_.value;
+            if constexpr (g + 1 < 4) issue_v(std::integral_constant<int, g + 1>{});
+            const bf16x8 pf = pack_frag(sacc[g >> 1], g & 1);
+            static_for<C::DT>([&](auto dt_) {
+                constexpr int dt = dt_.value;
+                constexpr int younger = 2 * (C::DT - 1 - dt) + (g + 1 < 4 ? 2 * C::DT : 0);
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_wait<younger>(ft[g & 1][dt]), pf, oacc[dt], 0, 0, 0);
+            });
+        });
 #if ATTN_ABL & 16
         asm volatile("" : "+v"(oacc[0]), "+v"(oacc[1]));
         PROF_ADD(5, t_seg);
