@@ -114,7 +114,8 @@ int mi355_qknorm_rope_fwd(int64_t tokens, int Hq, int Hkv, int D, const void* qk
                           const float* cos, const float* sin, const int32_t* pos, void* q_out, void* k_out,
                           float* rstd, float eps, void* stream);
 /* backward: dq,dk (post-RoPE grads) -> d(qkv)[:, :Hq*D + Hkv*D] written into dqkv (v part untouched);
- * weight-grad partials fp32 [parts, 2*D] (q then k). */
+ * weight-grad partials fp32 [parts, 2*D] (q then k).  dq == NULL: the key heads only (their rows of dqkv, the k half of the partials; the q half is
+ * written as zeros) -- the query heads' share then runs inside mi355_attn_bwd_qnorm. */
 int mi355_qknorm_rope_bwd(int64_t tokens, int Hq, int Hkv, int D, const void* qkv, const void* qw, const void* kw,
                           const float* cos, const float* sin, const int32_t* pos, const float* rstd,
                           const void* dq, const void* dk, void* dqkv, float* dw_partial, int parts, void* stream);
@@ -150,6 +151,18 @@ int mi355_attn_bwd_ws(int B, int S, int Hq, int Hkv, int D, const void* q, int64
                       const float* lse, float* delta, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv,
                       int64_t lddv, const uint8_t* key_mask, int causal, float scale, void* workspace, int64_t workspace_bytes,
                       void* stream);
+/* The same with the backward of the projection's QK-norm + RoPE (mi355_qknorm_rope_bwd, query heads) as the write-out of the dQ pass: dQ never
+ * exists as a matrix.  head_dim 128 and the workspace form only.  qkv: the PRE-norm projections (query head h at column h*D of a row of pitch
+ * ldqkv), q_weight bf16 [D], cos / sin fp32 [positions, D], pos int32 [B*S], rstd fp32 [B*S, rstd_heads] as mi355_qknorm_rope_fwd left them;
+ * d(qkv) rows of the query heads go to dqkv (pitch lddqkv); dqw_partial fp32 [mi355_attn_bwd_qnorm_partials(B,S,Hq), D]: one row per
+ * workgroup, summed by the caller (mi355_reduce_rows_f32) into the norm-weight gradient.  The key heads: mi355_qknorm_rope_bwd with dq = NULL.
+ * Reference: GroupedQueryAttention.forward, llm_quest/qwen/qwen3/qwen3_attention.py:103-160 (q_norm, RoPE, SDPA) under autograd. */
+int64_t mi355_attn_bwd_qnorm_partials(int B, int S, int Hq);
+int mi355_attn_bwd_qnorm(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                         const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* lse, float* delta, void* dk, int64_t lddk,
+                         void* dv, int64_t lddv, const uint8_t* key_mask, int causal, float scale, void* workspace, int64_t workspace_bytes,
+                         const void* qkv, int64_t ldqkv, const void* q_weight, const float* cos, const float* sin, const int32_t* pos,
+                         const float* rstd, int rstd_heads, void* dqkv, int64_t lddqkv, float* dqw_partial, void* stream);
 
 /* Row-wise cross entropy on bf16 logits with ignore_index=-100 (engine.py:45,60; vlm_engine.py:39).
  * logits [rows, V] ld=ldl.  loss_rows fp32 [rows] (0 for ignored).  If dlogits != NULL writes

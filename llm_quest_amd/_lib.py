@@ -38,6 +38,8 @@ SIGNATURES = {
     "mi355_attn_fwd": [_I, _I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _I, _F, _P],
     "mi355_attn_bwd": [_I, _I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _L, _P, _L, _P, _L, _P, _I, _F, _P],
     "mi355_attn_bwd_ws": [_I, _I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _L, _P, _L, _P, _L, _P, _I, _F, _P, _L, _P],
+    "mi355_attn_bwd_qnorm": [_I, _I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _L, _P, _L, _P, _I, _F, _P, _L,
+                             _P, _L, _P, _P, _P, _P, _P, _I, _P, _L, _P, _P],
     "mi355_cross_entropy": [_L, _L, _P, _L, _P, _P, _P, _P, _P],
     "mi355_ce_finalize": [_L, _P, _P, _P, _P],
     "mi355_embedding_fwd": [_L, _I, _L, _P, _P, _P, _L, _P],
@@ -100,6 +102,7 @@ QUERIES = {
     "mi355_gated_delta_rule_chunk": ([], _I),
     "mi355_gated_delta_rule_bwd_workspace_bytes": ([_I, _I, _I, _I, _I], _L),
     "mi355_attn_bwd_workspace_bytes": ([_I, _I, _I, _I], _L),
+    "mi355_attn_bwd_qnorm_partials": ([_I, _I, _I], _L),
 }
 
 _lib = None

@@ -1096,10 +1096,35 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
 // dS block in LDS: 2 pieces (c2) of 64 16-byte units; unit (h, key) sits in slot (32 h + key) ^ (h << 2) (the DMA lane for slot i fetches unit
 // i ^ ((i >> 5) << 2)), so the 16 lanes of a transposing read -- 4 keys x {h = 0, 1} x two 8-byte halves -- cover 16 distinct 8-byte bank slots.
 // Unit (c2, h, key) holds queries 16 c2 + 4 h + {0..3} and + {8..11}: query quad qd (of the wave's 8) is half (qd >> 1) & 1 of unit (c2 = qd >> 2, h = qd & 1).
-template <int D>
+// FUSE: the write-out is the backward of the projection's QK-norm + RoPE for the query heads (norm_rope.hip's qknorm_rope_bwd_kernel, same
+// arithmetic, on the fp32 accumulators instead of a bf16 dQ read back from memory): a lane holds 64 of its query row's 128 features, and
+// feature d's rotary partner d + 64 is in the same lane; d(qkv) rows go out directly, the norm-weight gradient as one partial row per workgroup
+// (summed in a fixed order: bit-reproducible).
+struct QkFuse {
+    const bf16_t* qkv;   // pre-norm projections [tokens, ldqkv]: query head h at column h * D
+    int64_t ldqkv;
+    const bf16_t* qw;    // RMSNorm weight of the query heads [D]
+    const float* cosT;   // [positions, D]
+    const float* sinT;
+    const int32_t* pos;  // [tokens]
+    const float* rstd;   // [tokens, rstd_heads]
+    int rstd_heads;
+    bf16_t* dqkv;        // d(qkv) [tokens, lddqkv]
+    int64_t lddqkv;
+    float* dwp;          // [gridDim.x, D]
+};
+__device__ __forceinline__ void unpack4(const u32x2 v, float (&o)[4]) {
+    o[0] = __uint_as_float(v[0] << 16);
+    o[1] = __uint_as_float(v[0] & 0xffff0000u);
+    o[2] = __uint_as_float(v[1] << 16);
+    o[3] = __uint_as_float(v[1] & 0xffff0000u);
+}
+__device__ __forceinline__ float round_bf(float x) { return bf2f(f2bf(x)); }
+
+template <int D, bool FUSE>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_spill_kernel(int B, int S, int Hq, int Hkv, const bf16_t* __restrict__ k, int64_t ldk,
                                                                    const bf16_t* __restrict__ ds, bf16_t* __restrict__ dq, int64_t lddq,
-                                                                   int causal, float scale) {
+                                                                   int causal, float scale, QkFuse f) {
     using C = Cfg<D>;
     constexpr int DT = C::DT, DSW = 4096, STAGE = C::TILE + 4 * DSW;  // a wave's dS bytes per 64-key tile: 2 key groups x 2 KiB
     // Two stages and two workgroups per CU: one workgroup's LDS-DMA issue (~100 cycles per piece and wave when four waves issue together) runs under
@@ -1175,18 +1200,155 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_spill_kernel(int B, int S,
             });
         });
     }
-    if (qg < S) {
-        bf16_t* row = dq + ((int64_t)b * S + qg) * lddq + (int64_t)hq * D;
+    if constexpr (!FUSE) {
+        if (qg < S) {
+            bf16_t* row = dq + ((int64_t)b * S + qg) * lddq + (int64_t)hq * D;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+            for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int d = dt * 32 + 8 * g4 + 4 * (lane >> 5);
-                const u32x2 pk = {pack_bf2(acc[dt][4 * g4] * scale, acc[dt][4 * g4 + 1] * scale), pack_bf2(acc[dt][4 * g4 + 2] * scale, acc[dt][4 * g4 + 3] * scale)};
-                *reinterpret_cast<u32x2*>(row + d) = pk;
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int d = dt * 32 + 8 * g4 + 4 * (lane >> 5);
+                    const u32x2 pk = {pack_bf2(acc[dt][4 * g4] * scale, acc[dt][4 * g4 + 1] * scale), pack_bf2(acc[dt][4 * g4 + 2] * scale, acc[dt][4 * g4 + 3] * scale)};
+                    *reinterpret_cast<u32x2*>(row + d) = pk;
+                }
+        }
+    } else {
+        static_assert(D == 128 && NST * STAGE >= 128 * D * 4, "fused write-out: head_dim 128, the tile stages hold the workgroup's [128][D] fp32 block");
+        // the write-out's own operands (four rows per thread: row slot + 32 it) are requested first -- rows 0 and 1 here, under the transposition,
+        // rows 2 and 3 under the arithmetic of rows 0 and 1 -- so the pass pays two memory latencies, not eight
+        const int sub = threadIdx.x >> 3, i = (threadIdx.x & 7) * 8;
+        struct RowIn {
+            u32x4 xa, xb;
+            f32x4 c[4], sn[4];  // cos / sin of features i..i+3, i+4..i+7, 64+i.., 64+i+4..
+            float r;
+            int64_t tok;
+            bool live;
+        };
+        RowIn in[4];
+        int64_t pp[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int qrow = q0 + sub + 32 * it;
+            in[it].live = qrow < S;
+            in[it].tok = (int64_t)b * S + (in[it].live ? qrow : S - 1);
+            pp[it] = f.pos[in[it].tok];
+        }
+        auto fetch = [&](int it) {
+            const bf16_t* xr = f.qkv + in[it].tok * f.ldqkv + (int64_t)hq * D + i;
+            in[it].xa = *reinterpret_cast<const u32x4*>(xr);
+            in[it].xb = *reinterpret_cast<const u32x4*>(xr + D / 2);
+            in[it].r = f.rstd[in[it].tok * f.rstd_heads + hq];
+            const float *cr = f.cosT + pp[it] * D + i, *sr = f.sinT + pp[it] * D + i;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                in[it].c[hh] = *reinterpret_cast<const f32x4*>(cr + 4 * hh);
+                in[it].sn[hh] = *reinterpret_cast<const f32x4*>(sr + 4 * hh);
+                in[it].c[2 + hh] = *reinterpret_cast<const f32x4*>(cr + D / 2 + 4 * hh);
+                in[it].sn[2 + hh] = *reinterpret_cast<const f32x4*>(sr + D / 2 + 4 * hh);
             }
+        };
+        fetch(0);
+        fetch(1);
+        __syncthreads();  // every wave is past its last tile: the stages become the transposition buffer
+        // scale * dQ to LDS, row-major with the 16-byte chunk index XORed by the row (a lane holds 4-feature runs of ONE row; the rows of a half-wave
+        // are 512 B apart): the stores of 8 consecutive rows then fall on 8 different chunk columns, and so do the loads of a row's 8 lanes below
+        float* xs = reinterpret_cast<float*>(smem);
+        {
+            const int row = wave * 32 + (lane & 31), hb = lane >> 5;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int chunk = dt * 8 + 2 * g4 + hb;  // features 4 chunk .. 4 chunk + 3
+                    const f32x4 val = {acc[dt][4 * g4] * scale, acc[dt][4 * g4 + 1] * scale, acc[dt][4 * g4 + 2] * scale, acc[dt][4 * g4 + 3] * scale};
+                    *reinterpret_cast<f32x4*>(xs + row * D + 4 * (chunk ^ (row & 31))) = val;
+                }
+        }
+        __syncthreads();
+        fetch(2);
+        fetch(3);
+        // the arithmetic of qknorm_rope_bwd_kernel: 8 lanes per row, a lane owns features i..i+7 and their rotary partners 64+i..64+i+7
+        float w1[8], w2[8], dw1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dw2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        {
+            const u32x4 a = *reinterpret_cast<const u32x4*>(f.qw + i), bq = *reinterpret_cast<const u32x4*>(f.qw + D / 2 + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                w1[2 * e] = __uint_as_float(a[e] << 16);
+                w1[2 * e + 1] = __uint_as_float(a[e] & 0xffff0000u);
+                w2[2 * e] = __uint_as_float(bq[e] << 16);
+                w2[2 * e + 1] = __uint_as_float(bq[e] & 0xffff0000u);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = sub + 32 * it;
+            const float r = in[it].r;
+            float g1[8], g2[8], c1[8], s1[8], c2[8], s2[8];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int ch = (i >> 2) + hh;
+                const f32x4 ga = *reinterpret_cast<const f32x4*>(xs + row * D + 4 * (ch ^ (row & 31)));
+                const f32x4 gb = *reinterpret_cast<const f32x4*>(xs + row * D + 4 * ((ch + 16) ^ (row & 31)));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    g1[4 * hh + e] = ga[e];
+                    g2[4 * hh + e] = gb[e];
+                    c1[4 * hh + e] = round_bf(in[it].c[hh][e]);  // coefficients rounded to bf16, as the forward applies them
+                    s1[4 * hh + e] = round_bf(in[it].sn[hh][e]);
+                    c2[4 * hh + e] = round_bf(in[it].c[2 + hh][e]);
+                    s2[4 * hh + e] = round_bf(in[it].sn[2 + hh][e]);
+                }
+            }
+            float dn1[8], dn2[8], xh1[8], xh2[8];
+            float dot = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x1 = (e & 1) ? __uint_as_float(in[it].xa[e >> 1] & 0xffff0000u) : __uint_as_float(in[it].xa[e >> 1] << 16);
+                const float x2 = (e & 1) ? __uint_as_float(in[it].xb[e >> 1] & 0xffff0000u) : __uint_as_float(in[it].xb[e >> 1] << 16);
+                // y1 = c1 n1 - s1 n2, y2 = c2 n2 + s2 n1
+                dn1[e] = c1[e] * g1[e] + s2[e] * g2[e];
+                dn2[e] = c2[e] * g2[e] - s1[e] * g1[e];
+                xh1[e] = x1 * r;
+                xh2[e] = x2 * r;
+                dot += dn1[e] * w1[e] * xh1[e] + dn2[e] * w2[e] * xh2[e];
+            }
+            dot += __shfl_xor(dot, 4, 64);
+            dot += __shfl_xor(dot, 2, 64);
+            dot += __shfl_xor(dot, 1, 64);
+            dot *= 1.0f / (float)D;
+            if (in[it].live) {
+                u32x4 o1, o2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o1[e] = pack_bf2(r * (dn1[2 * e] * w1[2 * e] - xh1[2 * e] * dot), r * (dn1[2 * e + 1] * w1[2 * e + 1] - xh1[2 * e + 1] * dot));
+                    o2[e] = pack_bf2(r * (dn2[2 * e] * w2[2 * e] - xh2[2 * e] * dot), r * (dn2[2 * e + 1] * w2[2 * e + 1] - xh2[2 * e + 1] * dot));
+                }
+                bf16_t* orow = f.dqkv + in[it].tok * f.lddqkv + (int64_t)hq * D + i;
+                *reinterpret_cast<u32x4*>(orow) = o1;
+                *reinterpret_cast<u32x4*>(orow + D / 2) = o2;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    dw1[e] += dn1[e] * xh1[e];
+                    dw2[e] += dn2[e] * xh2[e];
+                }
+            }
+        }
+        __syncthreads();  // the transposition buffer is dead: its first 16 KB take one [D] row per row slot, summed in a fixed order
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            xs[sub * D + i + e] = dw1[e];
+            xs[sub * D + D / 2 + i + e] = dw2[e];
+        }
+        __syncthreads();
+        if (threadIdx.x < D) {
+            float sum = 0.f;
+#pragma unroll
+            for (int rgn = 0; rgn < 32; ++rgn) sum += xs[rgn * D + threadIdx.x];
+            f.dwp[(int64_t)blockIdx.x * D + threadIdx.x] = sum;
+        }
     }
 }
+
 
 int check_common(const char* name, int B, int S, int Hq, int Hkv, int D) {
     MI355_REQUIRE(D == 64 || D == 128, "%s: head_dim must be 64 or 128 (got %d)", name, D);
@@ -1268,12 +1430,16 @@ extern "C" int mi355_attn_bwd(int B, int S, int Hq, int Hkv, int D, const void* 
                              nullptr, 0, stream);
 }
 
-extern "C" int mi355_attn_bwd_ws(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk,
-                                 const void* v, int64_t ldv, const void* o, int64_t ldo, const void* d_o, int64_t lddo,
-                                 const float* lse, float* delta, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv,
-                                 int64_t lddv, const uint8_t* key_mask, int causal, float scale, void* workspace, int64_t workspace_bytes,
-                                 void* stream) {
+static int attn_bwd_impl(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk,
+                         const void* v, int64_t ldv, const void* o, int64_t ldo, const void* d_o, int64_t lddo,
+                         const float* lse, float* delta, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv,
+                         int64_t lddv, const uint8_t* key_mask, int causal, float scale, void* workspace, int64_t workspace_bytes,
+                         void* stream, const QkFuse* fuse) {
     if (check_common("mi355_attn_bwd", B, S, Hq, Hkv, D)) return 1;
+    if (fuse) {  // dQ never exists as a matrix: the dQ pass writes d(qkv) rows
+        dq = const_cast<void*>(q);
+        lddq = ldq;
+    }
     MI355_REQUIRE(q && k && v && o && d_o && lse && delta && dq && dk && dv, "mi355_attn_bwd: null pointer");
     MI355_REQUIRE(((ldq | ldk | ldv | ldo | lddo | lddq | lddk | lddv) & 7) == 0, "mi355_attn_bwd: leading dimensions must be multiples of 8");
     MI355_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)d_o | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0,
@@ -1292,6 +1458,7 @@ extern "C" int mi355_attn_bwd_ws(int B, int S, int Hq, int Hkv, int D, const voi
     MI355_REQUIRE(gq < 0x7fffffffLL, "mi355_attn_bwd: grid too large");
     // workspace given (head_dim 128): the dK/dV pass spills dS and dQ is one product over it; otherwise the dQ pass recomputes S and dP
     const bool spill = D == 128 && workspace != nullptr && !((causal >> 8) & 1024);  // ablation bit 10: the three-product dQ pass
+    MI355_REQUIRE(!fuse || spill, "mi355_attn_bwd_qnorm: head_dim 128 and a workspace (the one-product dQ pass) are required");
     if (spill) {
         MI355_REQUIRE(workspace_bytes >= mi355_attn_bwd_workspace_bytes(B, S, Hq, D), "mi355_attn_bwd_ws: workspace of %lld bytes, %lld needed",
                       (long long)workspace_bytes, (long long)mi355_attn_bwd_workspace_bytes(B, S, Hq, D));
@@ -1313,13 +1480,43 @@ extern "C" int mi355_attn_bwd_ws(int B, int S, int Hq, int Hkv, int D, const voi
                            (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dq, lddq, key_mask, causal, scale, sl2, bpw_q);
     if (D == 128) {
         BWD_LAUNCH(128)
-        if (spill)
-            hipLaunchKernelGGL(attn_bwd_dq_spill_kernel<128>, dim3((unsigned)((int64_t)B * Hq * nblk)), dim3(256), 0, s, B, S, Hq, Hkv, (const bf16_t*)k, ldk,
-                               (const bf16_t*)ds_ws, (bf16_t*)dq, lddq, causal & 0xff, scale);
+        if (spill && fuse)
+            hipLaunchKernelGGL((attn_bwd_dq_spill_kernel<128, true>), dim3((unsigned)((int64_t)B * Hq * nblk)), dim3(256), 0, s, B, S, Hq, Hkv, (const bf16_t*)k, ldk,
+                               (const bf16_t*)ds_ws, (bf16_t*)nullptr, (int64_t)0, causal & 0xff, scale, *fuse);
+        else if (spill)
+            hipLaunchKernelGGL((attn_bwd_dq_spill_kernel<128, false>), dim3((unsigned)((int64_t)B * Hq * nblk)), dim3(256), 0, s, B, S, Hq, Hkv, (const bf16_t*)k, ldk,
+                               (const bf16_t*)ds_ws, (bf16_t*)dq, lddq, causal & 0xff, scale, QkFuse{});
     } else {
         BWD_LAUNCH(64)
     }
 #undef BWD_LAUNCH
     MI355_LAUNCH_CHECK("mi355_attn_bwd");
     return 0;
+}
+
+extern "C" int mi355_attn_bwd_ws(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk,
+                                 const void* v, int64_t ldv, const void* o, int64_t ldo, const void* d_o, int64_t lddo,
+                                 const float* lse, float* delta, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv,
+                                 int64_t lddv, const uint8_t* key_mask, int causal, float scale, void* workspace, int64_t workspace_bytes,
+                                 void* stream) {
+    return attn_bwd_impl(B, S, Hq, Hkv, D, q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo, lse, delta, dq, lddq, dk, lddk, dv, lddv, key_mask, causal, scale, workspace,
+                         workspace_bytes, stream, nullptr);
+}
+
+extern "C" int64_t mi355_attn_bwd_qnorm_partials(int B, int S, int Hq) { return (int64_t)B * Hq * ((S + 127) / 128); }
+
+extern "C" int mi355_attn_bwd_qnorm(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                                    const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* lse, float* delta, void* dk, int64_t lddk,
+                                    void* dv, int64_t lddv, const uint8_t* key_mask, int causal, float scale, void* workspace, int64_t workspace_bytes,
+                                    const void* qkv, int64_t ldqkv, const void* q_weight, const float* cos, const float* sin, const int32_t* pos,
+                                    const float* rstd, int rstd_heads, void* dqkv, int64_t lddqkv, float* dqw_partial, void* stream) {
+    MI355_REQUIRE(D == 128, "mi355_attn_bwd_qnorm: head_dim must be 128 (got %d)", D);
+    MI355_REQUIRE(qkv && q_weight && cos && sin && pos && rstd && dqkv && dqw_partial && workspace, "mi355_attn_bwd_qnorm: null pointer");
+    MI355_REQUIRE(rstd_heads >= Hq && ldqkv >= (int64_t)Hq * D && lddqkv >= (int64_t)Hq * D && ((ldqkv | lddqkv) & 3) == 0,
+                  "mi355_attn_bwd_qnorm: qkv / dqkv rows must hold the query heads (8-byte aligned pitches), rstd one column per head");
+    MI355_REQUIRE((((uintptr_t)qkv | (uintptr_t)dqkv | (uintptr_t)q_weight) & 7) == 0 && (((uintptr_t)cos | (uintptr_t)sin) & 15) == 0,
+                  "mi355_attn_bwd_qnorm: qkv / dqkv / weight 8-byte aligned, cos / sin 16-byte aligned");
+    const QkFuse f{(const bf16_t*)qkv, ldqkv, (const bf16_t*)q_weight, cos, sin, pos, rstd, rstd_heads, (bf16_t*)dqkv, lddqkv, dqw_partial};
+    return attn_bwd_impl(B, S, Hq, Hkv, D, q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo, lse, delta, nullptr, 0, dk, lddk, dv, lddv, key_mask, causal, scale, workspace,
+                         workspace_bytes, stream, &f);
 }

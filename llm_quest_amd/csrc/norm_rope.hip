@@ -314,7 +314,8 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(int64_t tokens, in
     const int lane = threadIdx.x & 63;
     const int sub = lane / G::LPH, i = (lane % G::LPH) * QV;
     const int H = Hq + Hkv;
-    const int groups = (H + G::HPW - 1) / G::HPW;
+    const int h0 = dq ? 0 : Hq;  // dq == NULL: the key heads only (the query heads' share ran as the write-out of the attention backward's dQ pass)
+    const int groups = (H - h0 + G::HPW - 1) / G::HPW;
     const int64_t ld = (int64_t)(Hq + 2 * Hkv) * D;
     float dwq1[QV] = {0, 0, 0, 0, 0, 0, 0, 0}, dwq2[QV] = {0, 0, 0, 0, 0, 0, 0, 0}, dwk1[QV] = {0, 0, 0, 0, 0, 0, 0, 0}, dwk2[QV] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool norm = qw != nullptr;
@@ -336,9 +337,9 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(int64_t tokens, in
 #pragma unroll
         for (int e = 0; e < QV; ++e) { cb1[e] = rbf(cb1[e]); sb1[e] = rbf(sb1[e]); cb2[e] = rbf(cb2[e]); sb2[e] = rbf(sb2[e]); }
         for (int grp = 0; grp < groups; ++grp) {
-            const int h = grp * G::HPW + sub;
+            const int h = h0 + grp * G::HPW + sub;
             const bool valid = h < H;
-            const int hh = valid ? h : 0;
+            const int hh = valid ? h : h0;
             const bool isq = hh < Hq;
             const bf16_t* src = qkv + t * ld + (int64_t)hh * D;
             const bf16_t* g = isq ? dq + t * (int64_t)Hq * D + (int64_t)hh * D : dk + t * (int64_t)Hkv * D + (int64_t)(hh - Hq) * D;
@@ -623,7 +624,7 @@ extern "C" int mi355_qknorm_rope_bwd(int64_t tokens, int Hq, int Hkv, int D, con
                                      const float* cos, const float* sin, const int32_t* pos, const float* rstd,
                                      const void* dq, const void* dk, void* dqkv, float* dw_partial, int parts, void* stream) {
     MI355_REQUIRE(D == 128 || D == 64, "mi355_qknorm_rope_bwd: head_dim must be 64 or 128 (got %d)", D);
-    MI355_REQUIRE(tokens > 0 && parts > 0 && qkv && cos && sin && pos && dq && dk && dqkv && dw_partial, "mi355_qknorm_rope_bwd: bad arguments");
+    MI355_REQUIRE(tokens > 0 && parts > 0 && qkv && cos && sin && pos && dk && dqkv && dw_partial, "mi355_qknorm_rope_bwd: bad arguments");  // dq may be NULL: key heads only
     MI355_REQUIRE((qw == nullptr) == (kw == nullptr) && (qw == nullptr || rstd != nullptr), "mi355_qknorm_rope_bwd: pass both norm weights (and rstd) or neither (RoPE only)");
     hipStream_t s = (hipStream_t)stream;
     if (D == 128)

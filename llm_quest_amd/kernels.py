@@ -254,10 +254,14 @@ def qknorm_rope_fwd(qkv, qw, kw, cos, sin, pos, Hq, Hkv, D, eps=1e-6):
 
 
 def qknorm_rope_bwd(qkv, qw, kw, cos, sin, pos, rstd, dq, dk, dqkv, Hq, Hkv, D):
-    """Writes d(qkv)[:, :(Hq+Hkv)*D] into dqkv (the V third is left to the caller); returns (dqw_f32, dkw_f32)."""
-    L.require_gpu(qkv, dq, dk, dqkv)
+    """Writes d(qkv)[:, :(Hq+Hkv)*D] into dqkv (the V third is left to the caller); returns (dqw_f32, dkw_f32).
+    dq=None: the key heads only (the query heads' share ran inside attn_bwd_qnorm); dqw_f32 is then zeros."""
+    L.require_gpu(qkv, dk, dqkv)
     tokens = qkv.shape[0]
     for t, n in ((dq, Hq * D), (dk, Hkv * D)):
+        if t is None:
+            continue
+        L.require_gpu(t)
         if not (t.is_contiguous() and t.dtype == BF16 and tuple(t.shape) == (tokens, n)):
             raise ValueError("qknorm_rope_bwd: dq/dk must be contiguous bf16 [tokens,H*D]")
     if not (dqkv.is_contiguous() and dqkv.shape == qkv.shape and dqkv.dtype == BF16):
@@ -372,6 +376,51 @@ def attn_bwd(q, k, v, o, do, lse, B, S, Hq, Hkv, D, dq, dk, dv, key_mask=None, c
         L.ptr(do), do.stride(0), L.ptr(lse), L.ptr(delta), L.ptr(dq), dq.stride(0), L.ptr(dk), dk.stride(0), L.ptr(dv), dv.stride(0),
         L.ptr(key_mask), int(causal) | _ATTN_ABLATE, scale, L.ptr(ws), need,
     )
+
+
+FUSE_QNORM_BWD = os.environ.get("MI355_FUSE_QNORM_BWD", "1") != "0"  # A/B knob: 0 = dQ matrix + the separate QK-norm / RoPE backward for every head
+
+
+def attn_bwd_qnorm(q, k, v, o, do, lse, B, S, Hq, Hkv, D, dk, dv, qkv, qw, cos, sin, pos, rstd, dqkv, key_mask=None, causal=True, scale=None):
+    """attn_bwd whose dQ pass ends in the backward of the QK-norm + RoPE of the query heads: writes d(qkv)[:, :Hq*D] into ``dqkv`` (dQ never exists
+    as a matrix) and returns the fp32 [D] gradient of the query norm weight -- or None when this form does not apply (head_dim != 128, no scratch
+    for the one-product dQ pass, knob off): the caller then runs attn_bwd + qknorm_rope_bwd."""
+    if not (FUSE_QNORM_BWD and _ATTN_DS_SPILL and D == 128) or qw is None:
+        return None
+    L.require_gpu(q, k, v, o, do, lse, dk, dv, qkv, qw, cos, sin, pos, rstd, dqkv)
+    for t, n, w in ((q, "q", Hq), (k, "k", Hkv), (v, "v", Hkv), (o, "o", Hq), (do, "do", Hq), (dk, "dk", Hkv), (dv, "dv", Hkv)):
+        _check_attn_operand(t, n, B * S, w * D)
+    if not (lse.dtype == F32 and lse.is_contiguous() and tuple(lse.shape) == (B, Hq, S)):
+        raise ValueError("attention: lse must be contiguous fp32 [B,Hq,S]")
+    H = rstd.shape[1]
+    if not (qkv.dtype == BF16 and dqkv.dtype == BF16 and qkv.shape == dqkv.shape and qkv.shape[0] == B * S and qkv.stride(1) == 1 and dqkv.stride(1) == 1
+            and rstd.dtype == F32 and rstd.is_contiguous() and rstd.shape[0] == B * S and H >= Hq and qw.dtype == BF16 and qw.numel() == D
+            and cos.dtype == F32 and sin.dtype == F32 and cos.is_contiguous() and sin.is_contiguous() and cos.shape[-1] == D and pos.dtype == torch.int32 and pos.numel() == B * S):
+        raise ValueError("attn_bwd_qnorm: qkv / dqkv bf16 [B*S, >=Hq*D], rstd fp32 [B*S, heads], q weight bf16 [D], cos / sin fp32 [positions, D], pos int32 [B*S]")
+    need = L.load().mi355_attn_bwd_workspace_bytes(B, S, Hq, D)
+    ws = _attn_scratch(q.device, need) if need else None
+    if ws is None:
+        return None
+    attn_bwd_form["spill"] += 1
+    delta = torch.empty_like(lse)
+    scale = D ** -0.5 if scale is None else scale
+    parts = L.load().mi355_attn_bwd_qnorm_partials(B, S, Hq)
+    part = torch.empty((parts, D), dtype=F32, device=q.device)
+    L.call(
+        "mi355_attn_bwd_qnorm", B, S, Hq, Hkv, D, L.ptr(q), q.stride(0), L.ptr(k), k.stride(0), L.ptr(v), v.stride(0), L.ptr(o), o.stride(0),
+        L.ptr(do), do.stride(0), L.ptr(lse), L.ptr(delta), L.ptr(dk), dk.stride(0), L.ptr(dv), dv.stride(0), L.ptr(key_mask), int(causal) | _ATTN_ABLATE, scale,
+        L.ptr(ws), need, L.ptr(qkv), qkv.stride(0), L.ptr(qw), L.ptr(cos), L.ptr(sin), L.ptr(pos), L.ptr(rstd), H, L.ptr(dqkv), dqkv.stride(0), L.ptr(part),
+    )
+    # one partial row per workgroup: summed in two fixed-order levels (a single launch over thousands of rows runs on two workgroups)
+    dw = torch.empty(D, dtype=F32, device=q.device)
+    fold = next((f for f in (64, 32, 16, 8) if parts % f == 0 and parts // f >= 8), 1)
+    if fold > 1:
+        mid = torch.empty(fold * D, dtype=F32, device=q.device)
+        L.call("mi355_reduce_rows_f32", parts // fold, fold * D, L.ptr(part), L.ptr(mid), L.DT_F32, 0)
+        L.call("mi355_reduce_rows_f32", fold, D, L.ptr(mid), L.ptr(dw), L.DT_F32, 0)
+    else:
+        L.call("mi355_reduce_rows_f32", parts, D, L.ptr(part), L.ptr(dw), L.DT_F32, 0)
+    return dw
 
 
 def cross_entropy(logits2d, targets, want_grad, grad_scale=None, inplace=True):

@@ -119,10 +119,16 @@ def attention_backward(att, arena, h1, ctx, saved, dctx, rt, defer=None):
     qkv, q, k, rstd, lse = saved
     v = qkv[:, (Hq + Hkv) * D :]
     dqkv = torch.empty_like(qkv)
-    dq = torch.empty_like(q)
     dk = torch.empty_like(k)
-    K.attn_bwd(q, k, v, ctx, dctx, lse, rt.B, rt.S, Hq, Hkv, D, dq, dk, dqkv[:, (Hq + Hkv) * D :], key_mask=rt.key_mask, causal=True, scale=att.att_scaling)
-    dqw, dkw = K.qknorm_rope_bwd(qkv, att.q_norm.weight, att.k_norm.weight, rt.cos, rt.sin, rt.pos, rstd, dq, dk, dqkv, Hq, Hkv, D)
+    # the dQ pass ends in the QK-norm + RoPE backward of the query heads when it can (head_dim 128, scratch for the one-product form) ...
+    dqw = K.attn_bwd_qnorm(q, k, v, ctx, dctx, lse, rt.B, rt.S, Hq, Hkv, D, dk, dqkv[:, (Hq + Hkv) * D :], qkv, att.q_norm.weight, rt.cos, rt.sin, rt.pos, rstd, dqkv,
+                           key_mask=rt.key_mask, causal=True, scale=att.att_scaling)
+    if dqw is not None:
+        _, dkw = K.qknorm_rope_bwd(qkv, att.q_norm.weight, att.k_norm.weight, rt.cos, rt.sin, rt.pos, rstd, None, dk, dqkv, Hq, Hkv, D)
+    else:  # ... otherwise dQ is a matrix and one kernel handles every head
+        dq = torch.empty_like(q)
+        K.attn_bwd(q, k, v, ctx, dctx, lse, rt.B, rt.S, Hq, Hkv, D, dq, dk, dqkv[:, (Hq + Hkv) * D :], key_mask=rt.key_mask, causal=True, scale=att.att_scaling)
+        dqw, dkw = K.qknorm_rope_bwd(qkv, att.q_norm.weight, att.k_norm.weight, rt.cos, rt.sin, rt.pos, rstd, dq, dk, dqkv, Hq, Hkv, D)
     for p, g in ((att.q_norm.weight, dqw), (att.k_norm.weight, dkw)):
         view, acc = _vecgrad(arena, p)
         if view is not None:

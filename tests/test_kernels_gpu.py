@@ -510,6 +510,63 @@ def test_attention_backward_scratch_is_capped_and_falls_back_to_the_recompute_fo
         assert rel_l2(got, ref) < 8e-3, name
 
 
+@pytest.mark.parametrize("B,S,Hq,Hkv,ragged", [(2, 709, 4, 2, False), (3, 300, 2, 2, True), (1, 128, 2, 1, False)])
+def test_attention_backward_with_the_query_norm_backward_as_its_write_out(K, B, S, Hq, Hkv, ragged):
+    """mi355_attn_bwd_qnorm (the dQ pass ends in the QK-norm + RoPE backward of the query heads; dQ is never a matrix) against the pair it
+    replaces, attn_bwd + qknorm_rope_bwd: the same d(qkv) and norm-weight gradient up to the bf16 rounding of dQ the pair goes through (the fused
+    form is the more exact one: checked against fp32 autograd of the norm + RoPE fed with the pair's own dQ), the key heads' rows bit for bit,
+    dK / dV bit for bit, the weight gradient bit-reproducible."""
+    from oracle import ops
+
+    D = 128
+    qkv, qw, kw = _qkv_case(B, S, Hq, Hkv, D, 31)
+    cos, sin = ops.rope_tables(1_000_000, D, 1024)
+    pos = torch.arange(S, dtype=torch.int32).repeat(B)
+    km = None
+    if ragged:
+        km = torch.ones(B, S, dtype=torch.uint8)
+        km[0, S - 37 :] = 0
+        km[1, S // 2 :] = 0
+        km = dev(km)
+    qkv_d, qw_d, kw_d, cos_d, sin_d, pos_d = dev(qkv), dev(qw), dev(kw), dev(cos), dev(sin), dev(pos)
+    q, k, rstd = K.qknorm_rope_fwd(qkv_d, qw_d, kw_d, cos_d, sin_d, pos_d, Hq, Hkv, D)
+    v = qkv_d[:, (Hq + Hkv) * D :]
+    o, lse = K.attn_fwd(q, k, v, B, S, Hq, Hkv, D, key_mask=km, causal=True)
+    g = torch.Generator().manual_seed(32)
+    do = dev(torch.randn(B * S, Hq * D, generator=g).to(BF16))
+    # the pair
+    dq, dk0, dqkv0 = torch.empty_like(q), torch.empty_like(k), torch.zeros_like(qkv_d)
+    K.attn_bwd(q, k, v, o, do, lse, B, S, Hq, Hkv, D, dq, dk0, dqkv0[:, (Hq + Hkv) * D :], key_mask=km, causal=True)
+    dqw0, dkw0 = K.qknorm_rope_bwd(qkv_d, qw_d, kw_d, cos_d, sin_d, pos_d, rstd, dq, dk0, dqkv0, Hq, Hkv, D)
+    # the fused form
+    dk1, dqkv1 = torch.empty_like(k), torch.zeros_like(qkv_d)
+    dqw1 = K.attn_bwd_qnorm(q, k, v, o, do, lse, B, S, Hq, Hkv, D, dk1, dqkv1[:, (Hq + Hkv) * D :], qkv_d, qw_d, cos_d, sin_d, pos_d, rstd, dqkv1, key_mask=km, causal=True)
+    assert dqw1 is not None, "the fused form must apply at head_dim 128 with the scratch available"
+    z, dkw1 = K.qknorm_rope_bwd(qkv_d, qw_d, kw_d, cos_d, sin_d, pos_d, rstd, None, dk1, dqkv1, Hq, Hkv, D)
+    assert torch.equal(dk0, dk1) and torch.equal(dqkv0[:, (Hq + Hkv) * D :], dqkv1[:, (Hq + Hkv) * D :]), "dK / dV do not depend on the dQ write-out"
+    assert torch.equal(dqkv0[:, Hq * D : (Hq + Hkv) * D], dqkv1[:, Hq * D : (Hq + Hkv) * D]) and torch.equal(dkw0, dkw1), "key heads: the same kernel, the same bits"
+    assert torch.count_nonzero(z) == 0
+    nq = Hq * D
+    assert rel_l2(dqkv1[:, :nq], dqkv0[:, :nq]) < 4e-3, rel_l2(dqkv1[:, :nq], dqkv0[:, :nq])
+    assert rel_l2(dqw1, dqw0) < 2e-3, rel_l2(dqw1, dqw0)
+    # fp32 autograd of the norm + RoPE fed with the pair's (bf16) dQ: both forms are within bf16 rounding of it, the fused one no further than the pair
+    x32 = qkv[:, :nq].float().requires_grad_(True)
+    w32 = qw.float().requires_grad_(True)
+    cb, sb = cos[:S].to(BF16).float(), sin[:S].to(BF16).float()
+    xh = x32.view(B, S, Hq, D).transpose(1, 2)
+    n = xh * torch.rsqrt(xh.pow(2).mean(-1, keepdim=True) + 1e-6) * w32
+    y = (cb * n + sb * torch.cat((-n[..., D // 2 :], n[..., : D // 2]), -1)).transpose(1, 2).reshape(B * S, nq)
+    (y * dq.float().cpu()).sum().backward()
+    e0, e1 = rel_l2(dqkv0[:, :nq], x32.grad), rel_l2(dqkv1[:, :nq], x32.grad)
+    assert e0 < 4e-3 and e1 < 5e-3, (e0, e1)
+    assert rel_l2(dqw1, w32.grad) < 3e-3 and rel_l2(dqw0, w32.grad) < 1e-4
+    # rows of masked / out-of-range queries contribute nothing odd, and the result is bit-reproducible
+    dk2, dqkv2 = torch.empty_like(k), torch.zeros_like(qkv_d)
+    dqw2 = K.attn_bwd_qnorm(q, k, v, o, do, lse, B, S, Hq, Hkv, D, dk2, dqkv2[:, (Hq + Hkv) * D :], qkv_d, qw_d, cos_d, sin_d, pos_d, rstd, dqkv2, key_mask=km, causal=True)
+    assert torch.equal(dqw1, dqw2) and torch.equal(dqkv1[:, :nq], dqkv2[:, :nq])
+    assert torch.isfinite(dqkv1.float()).all() and torch.isfinite(dqw1).all()
+
+
 def test_attention_strided_views(K):
     """k/v read in place from the fused QKV projection buffer (row pitch = (Hq+2Hkv)*D)."""
     B, S, Hq, Hkv, D = 1, 100, 4, 2, 128
