@@ -265,10 +265,12 @@ class LinearFn(torch.autograd.Function):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         x2 = x2 if x2.is_contiguous() else x2.contiguous()
-        y = K.gemm(L.GEMM_NT, x2, weight, bias=bias_f32, gelu=gelu)
+        ctx.pre = None
+        if gelu and (ctx.needs_input_grad[0] or ctx.needs_input_grad[2]):
+            ctx.pre, y = K.gemm_gelu_dual(x2, weight, bias=bias_f32)  # the pre-activation stays for the backward (one launch writes both)
+        else:
+            y = K.gemm(L.GEMM_NT, x2, weight, bias=bias_f32, gelu=gelu)
         ctx.owner, ctx.weight, ctx.x2, ctx.shp, ctx.gelu = owner, weight, x2, shp, gelu
-        if gelu:
-            raise NotImplementedError("LinearFn: GELU epilogue has no backward yet (inference only)")
         return y.view(*shp[:-1], weight.shape[0])
 
     @staticmethod
@@ -276,6 +278,8 @@ class LinearFn(torch.autograd.Function):
         w = ctx.weight
         dy2 = dy.reshape(-1, w.shape[0])
         dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+        if ctx.gelu:
+            dy2 = K.gelu_bwd(ctx.pre, dy2)
         dx = K.dgrad(dy2, w)
         _wgrad(arena_for(ctx.owner), w, None, dy2, ctx.x2)
         return dx.view(ctx.shp), None, None, None, None

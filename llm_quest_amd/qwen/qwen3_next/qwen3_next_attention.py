@@ -47,9 +47,21 @@ def compute_alpha_factor(log_A, a, dt_bias):
 
 def gated_delta_rule(queries, keys, values, beta, alpha, prev_state=None):
     """Reference :103-159.  (b, h, s, d) operands, beta / alpha (b, h, s); returns (attn_output, last_state).  Differentiable."""
-    if prev_state is not None:
-        raise NotImplementedError("a carried-in recurrent state is the decode path (SURVEY.md section 8 f4), outside the training hot path")
     L.require_gpu(queries, keys, values, beta, alpha)
+    if prev_state is not None:
+        # a carried-in recurrent state (b, h, v_head_dim, qk_head_dim): prefill continuation / decode.  Forward only -- the backward pass replays
+        # from its own checkpoints and has no d(prev_state); the returned state is a new tensor, prev_state is left as it was (as upstream).
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (queries, keys, values, beta, alpha, prev_state)):
+            raise NotImplementedError("gated_delta_rule: training through a carried-in recurrent state is not built (forward / no_grad only)")
+        L.require_gpu(prev_state)
+        b, h, s, dk = queries.shape
+        dv = values.shape[-1]
+        tm = lambda t: t.permute(0, 2, 1, 3).reshape(b * s, -1).contiguous()
+        state = prev_state.to(torch.float32).contiguous().clone()
+        o, _, fin = Q.gated_delta_rule_fwd(tm(queries.to(torch.bfloat16)), tm(keys.to(torch.bfloat16)), tm(values.to(torch.bfloat16)),
+                                           beta.to(torch.float32).permute(0, 2, 1).reshape(b * s, h).contiguous(),
+                                           alpha.to(torch.float32).permute(0, 2, 1).reshape(b * s, h).contiguous(), b, s, h, h, dk, dv, keep=False, state=state)
+        return o.view(b, s, h, dv).permute(0, 2, 1, 3).to(queries.dtype), fin
     return ops_q35.GatedDeltaRuleFn.apply(queries, keys, values, beta, alpha)
 
 

@@ -258,3 +258,26 @@ def test_rope_apply_positions_outside_the_table_do_not_read_out_of_bounds():
     assert torch.isnan(y[1, :, 1]).all() and torch.isnan(y[1, :, 2]).all()
     good = RoPE.apply(x, cos, sin, pid.clamp(0, 7)).float()
     assert torch.equal(y.permute(0, 2, 1, 3)[ok], good.permute(0, 2, 1, 3)[ok])
+
+
+@pytest.mark.gpu
+def test_linear_with_gelu_epilogue_is_differentiable():
+    """ops.LinearFn with the GELU epilogue (the ViT FFN's first projection, vit_transformer_block.py:70-127, used stand-alone) trains: the
+    pre-activation is kept by the dual-output GEMM and the backward goes through gelu'(pre).  Against fp32 autograd of the same math."""
+    import torch.nn as nn
+
+    from llm_quest_amd import ops
+
+    torch.manual_seed(5)
+    lin = nn.Linear(96, 256, bias=True, dtype=torch.bfloat16).cuda()
+    x = torch.randn(3, 40, 96, device="cuda").to(torch.bfloat16).requires_grad_(True)
+    y = ops.LinearFn.apply(x, lin, lin.weight, lin.bias.detach().float(), True)
+    g = torch.randn_like(y)
+    y.backward(g)
+    x32, w32, b32 = x.detach().float().requires_grad_(True), lin.weight.detach().float().requires_grad_(True), lin.bias.detach().float()
+    y32 = torch.nn.functional.gelu(x32 @ w32.T + b32)
+    y32.backward(g.float())
+    rel = lambda a, b: float((a.float() - b).norm() / b.norm())
+    assert rel(y, y32) < 6e-3 and rel(x.grad, x32.grad) < 1e-2, (rel(y, y32), rel(x.grad, x32.grad))
+    wg = lin.weight.grad  # attached to the owner's arena by the weight-gradient GEMM
+    assert wg is not None and rel(wg, w32.grad) < 1e-2, rel(wg, w32.grad)

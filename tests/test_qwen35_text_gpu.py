@@ -468,6 +468,27 @@ def test_functional_gated_delta_rule_has_the_reference_signature(golden):
         assert ten.grad.dtype == t["gdr.grad." + name].dtype and rel_l2(ten.grad, t["gdr.grad." + name]) < 8e-3, name
 
 
+def test_functional_gated_delta_rule_carries_a_previous_state(golden):
+    """prev_state (reference :103-159): running the sequence in two pieces, the second from the first piece's state, gives the one-piece result;
+    prev_state itself is left untouched and training through it is refused loudly."""
+    from llm_quest_amd.qwen.qwen3_next.qwen3_next_attention import gated_delta_rule
+
+    t = golden("qwen35_text_tiny")
+    q, k, v, beta, alpha = (t["gdr." + n].cuda() for n in ("q", "k", "v", "beta", "alpha"))
+    s = q.shape[2]
+    cut = s // 2
+    with torch.no_grad():
+        o_all, st_all = gated_delta_rule(q, k, v, beta, alpha)
+        o1, st1 = gated_delta_rule(q[:, :, :cut], k[:, :, :cut], v[:, :, :cut], beta[:, :, :cut], alpha[:, :, :cut])
+        keep = st1.clone()
+        o2, st2 = gated_delta_rule(q[:, :, cut:], k[:, :, cut:], v[:, :, cut:], beta[:, :, cut:], alpha[:, :, cut:], prev_state=st1)
+    assert torch.equal(st1, keep), "prev_state must not be modified"
+    assert torch.equal(o1, o_all[:, :, :cut]) and ulp_diff(o2, o_all[:, :, cut:].contiguous()) <= 1 and rel_l2(st2, st_all) < 1e-6
+    assert ulp_diff(torch.cat((o1, o2), 2), t["gdr.out"]) <= 1 and rel_l2(st2, t["gdr.state"]) < 1e-5
+    with pytest.raises(NotImplementedError, match="carried-in"):
+        gated_delta_rule(q.requires_grad_(True), k, v, beta, alpha, prev_state=st1)
+
+
 def test_text_model_loss_path_and_determinism():
     """forward_hidden + lm_loss == CE of forward()'s logits; two identical steps give bit-identical gradients."""
     from llm_quest_amd.qwen.qwen3_5.qwen3_5_text_model import Qwen3_5TextModel
