@@ -183,9 +183,13 @@ int mi355_embedding_bwd(int64_t tokens, int width, int64_t vocab, const int64_t*
  * qwen3_model.py:69 -> its autograd backward).  sorted_ids: the ids sorted STABLY, perm: the permutation that sorted them (sorted_ids[j] =
  * ids[perm[j]]); dout bf16 [tokens, width] indexed by perm; table bf16 [vocab, width], row pitch ldt: every vocabulary row that occurs becomes
  * (accumulate ? row : 0) + scale * sum of its tokens' rows (summed in token order, fp32); rows that do not occur are left untouched.
- * Ids outside [0, vocab) are skipped.  width, ldd, ldt multiples of 8. */
+ * Ids outside [0, vocab) are skipped.  width, ldd, ldt multiples of 8.  The sum is a fixed two-level tree over blocks of 32 sorted positions (a run
+ * of thousands of equal ids -- padding, placeholder tokens -- does not serialise on one wave): workspace fp32, 16-byte aligned,
+ * mi355_embedding_bwd_sorted_workspace_bytes(tokens, width) bytes, holds the per-block parts between the two passes. */
+int64_t mi355_embedding_bwd_sorted_workspace_bytes(int64_t tokens, int width);
 int mi355_embedding_bwd_sorted(int64_t tokens, int width, int64_t vocab, const int64_t* sorted_ids, const int64_t* perm, const void* dout,
-                               int64_t ldd, float scale, void* table, int64_t ldt, int accumulate, void* stream);
+                               int64_t ldd, float scale, void* table, int64_t ldt, int accumulate, float* workspace, int64_t workspace_bytes,
+                               void* stream);
 
 /* y[c][r] = x[r][c], bf16, pitches in elements.  rows, cols, ldx, ldy multiples of 8; pointers 16-byte aligned.  The backward of a Linear
  * (reference: every nn.Linear on the path, e.g. llm_quest/qwen/qwen3/qwen3_transformer_block.py:7-53) uses it once per weight so that the

@@ -44,7 +44,7 @@ SIGNATURES = {
     "mi355_ce_finalize": [_L, _P, _P, _P, _P],
     "mi355_embedding_fwd": [_L, _I, _L, _P, _P, _P, _L, _P],
     "mi355_embedding_bwd": [_L, _I, _L, _P, _P, _L, _P, _P],
-    "mi355_embedding_bwd_sorted": [_L, _I, _L, _P, _P, _P, _L, _F, _P, _L, _I, _P],
+    "mi355_embedding_bwd_sorted": [_L, _I, _L, _P, _P, _P, _L, _F, _P, _L, _I, _P, _L, _P],
     "mi355_copy2d": [_L, _L, _P, _L, _P, _L, _P],
     "mi355_transpose_bf16": [_L, _L, _P, _L, _P, _L, _P],
     "mi355_patchify": [_I, _I, _I, _I, _I, _P, _P, _I, _P],
@@ -103,6 +103,7 @@ QUERIES = {
     "mi355_gated_delta_rule_bwd_workspace_bytes": ([_I, _I, _I, _I, _I], _L),
     "mi355_attn_bwd_workspace_bytes": ([_I, _I, _I, _I], _L),
     "mi355_attn_bwd_qnorm_partials": ([_I, _I, _I], _L),
+    "mi355_embedding_bwd_sorted_workspace_bytes": ([_L, _I], _L),
 }
 
 _lib = None

@@ -380,40 +380,110 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(int64_t tokens, int 
 }
 
 // Deterministic form: the ids arrive SORTED (stably: equal ids keep the order of their token positions) together with the permutation that
-// sorted them.  One wave per sorted position; the first position of each run of equal ids owns the run, sums its rows in run order in fp32
-// registers and updates that vocabulary row once: no atomics, the same bits every time whatever the ids repeat, and only the touched rows move
-// (the atomic form walks a dense fp32 copy of the table).  scale: 1 / world under data parallelism (the runs then hold every rank's tokens).
+// sorted them.  Every vocabulary row that occurs is written once with the fp32 sum of its tokens' rows: no atomics, the same bits every time
+// whatever the ids repeat, and only the touched rows move (the atomic form walks a dense fp32 copy of the table).
+// A run of equal ids can be long (padding or placeholder tokens: thousands of positions), so the sum is a fixed two-level tree over blocks of
+// EMB_BLK sorted positions, whatever the launch geometry: pass 1, one wave per block, sums each run's part inside the block in position order --
+// a run that lies inside one block is finished there; a part that began before the block goes to scratch slot 0 of the block, a part that goes on
+// past it to slot 1 -- and pass 2, one wave per block whose slot 1 is in use (the block that holds the run's first position), adds the slot-0
+// parts of the following blocks in block order and writes the row.  scale: 1 / world under data parallelism.
+constexpr int EMB_BLK = 32;
+__device__ __forceinline__ void emb_store_row(bf16_t* row, const float (&acc)[8], float scale, int accumulate) {
+    u32x4 o;
+    if (accumulate) {
+        const u32x4 old = *reinterpret_cast<const u32x4*>(row);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack_bf2(__uint_as_float(old[e] << 16) + acc[2 * e] * scale, __uint_as_float(old[e] & 0xffff0000u) + acc[2 * e + 1] * scale);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack_bf2(acc[2 * e] * scale, acc[2 * e + 1] * scale);
+    }
+    *reinterpret_cast<u32x4*>(row) = o;
+}
+
 __global__ __launch_bounds__(256) void embedding_bwd_sorted_kernel(int64_t tokens, int width, int64_t vocab, const int64_t* __restrict__ sid,
                                                                    const int64_t* __restrict__ perm, const bf16_t* __restrict__ dout, int64_t ldd,
-                                                                   float scale, bf16_t* __restrict__ table, int64_t ldt, int accumulate) {
+                                                                   float scale, bf16_t* __restrict__ table, int64_t ldt, int accumulate,
+                                                                   float* __restrict__ part) {
     const int lane = threadIdx.x & 63;
-    for (int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); j < tokens; j += (int64_t)gridDim.x * 4) {
-        const int64_t id = sid[j];
-        if (id < 0 || id >= vocab) continue;
-        if (j > 0 && sid[j - 1] == id) continue;  // not the head of its run
-        for (int c0 = 0; c0 < width; c0 += 512) {  // 8 columns per lane and sweep
-            const int c = c0 + lane * 8;
-            if (c >= width) continue;
-            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int64_t jj = j; jj < tokens && sid[jj] == id; ++jj) {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(dout + perm[jj] * ldd + c);
+    const int64_t nblk = (tokens + EMB_BLK - 1) / EMB_BLK;
+    for (int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); blk < nblk; blk += (int64_t)gridDim.x * 4) {
+        const int64_t lo = blk * EMB_BLK, hi = min(tokens, lo + EMB_BLK);
+        int64_t j = lo;
+        while (j < hi) {
+            const int64_t id = sid[j];
+            int64_t e = j + 1;
+            while (e < hi && sid[e] == id) ++e;
+            const bool before = j == lo && lo > 0 && sid[lo - 1] == id, after = e == hi && hi < tokens && sid[hi] == id;
+            if (id >= 0 && id < vocab) {
+                for (int c0 = 0; c0 < width; c0 += 512) {  // 8 columns per lane and sweep
+                    const int c = c0 + lane * 8;
+                    if (c >= width) continue;
+                    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    for (int64_t jj = j; jj < e; jj += 8) {  // eight rows requested together, added in position order
+                        u32x4 v[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc[2 * e] += __uint_as_float(v[e] << 16);
-                    acc[2 * e + 1] += __uint_as_float(v[e] & 0xffff0000u);
+                        for (int u = 0; u < 8; ++u) v[u] = jj + u < e ? *reinterpret_cast<const u32x4*>(dout + perm[jj + u] * ldd + c) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                acc[2 * q] += __uint_as_float(v[u][q] << 16);
+                                acc[2 * q + 1] += __uint_as_float(v[u][q] & 0xffff0000u);
+                            }
+                    }
+                    if (!before && !after) {
+                        emb_store_row(table + id * ldt + c, acc, scale, accumulate);
+                    } else {
+                        float* dst = part + ((blk * 2 + (before ? 0 : 1)) * (int64_t)width + c);
+                        *reinterpret_cast<f32x4*>(dst) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+                        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+                    }
                 }
             }
-            bf16_t* row = table + id * ldt + c;
-            u32x4 o;
-            if (accumulate) {
-                const u32x4 old = *reinterpret_cast<const u32x4*>(row);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = pack_bf2(__uint_as_float(old[e] << 16) + acc[2 * e] * scale, __uint_as_float(old[e] & 0xffff0000u) + acc[2 * e + 1] * scale);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = pack_bf2(acc[2 * e] * scale, acc[2 * e + 1] * scale);
+            j = e;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void embedding_bwd_join_kernel(int64_t tokens, int width, int64_t vocab, const int64_t* __restrict__ sid, float scale,
+                                                                 bf16_t* __restrict__ table, int64_t ldt, int accumulate, const float* __restrict__ part) {
+    const int lane = threadIdx.x & 63;
+    const int64_t nblk = (tokens + EMB_BLK - 1) / EMB_BLK;
+    for (int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); blk + 1 < nblk; blk += (int64_t)gridDim.x * 4) {
+        const int64_t lo = blk * EMB_BLK, hi = lo + EMB_BLK;  // a block with a successor is full
+        const int64_t id = sid[hi - 1];
+        if (sid[hi] != id || id < 0 || id >= vocab) continue;             // the last run of the block does not go on
+        if (sid[lo] == id && lo > 0 && sid[lo - 1] == id) continue;      // ... or it began before the block: an earlier block owns it
+        // blocks blk + 1 .. last hold the run's further parts in their slot 0; the run ends in the first block it does not fill to the end
+        int64_t last = blk + 1;
+        while (last + 1 < nblk && sid[(last + 1) * EMB_BLK - 1] == id && sid[(last + 1) * EMB_BLK] == id) ++last;
+        for (int c0 = 0; c0 < width; c0 += 512) {
+            const int c = c0 + lane * 8;
+            if (c >= width) continue;
+            float acc[8];
+            {
+                const float* src = part + ((blk * 2 + 1) * (int64_t)width + c);
+                const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+                acc[0] = a[0]; acc[1] = a[1]; acc[2] = a[2]; acc[3] = a[3]; acc[4] = b[0]; acc[5] = b[1]; acc[6] = b[2]; acc[7] = b[3];
             }
-            *reinterpret_cast<u32x4*>(row) = o;
+            for (int64_t nb = blk + 1; nb <= last; nb += 4) {  // four parts requested together, added in block order
+                f32x4 a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float* src = part + (((nb + u) * 2) * (int64_t)width + c);
+                    a[u] = nb + u <= last ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    b[u] = nb + u <= last ? *reinterpret_cast<const f32x4*>(src + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc[q] += a[u][q];
+                        acc[4 + q] += b[u][q];
+                    }
+            }
+            emb_store_row(table + id * ldt + c, acc, scale, accumulate);
         }
     }
 }
@@ -702,13 +772,25 @@ extern "C" int mi355_embedding_bwd(int64_t tokens, int width, int64_t vocab, con
     return 0;
 }
 
+extern "C" int64_t mi355_embedding_bwd_sorted_workspace_bytes(int64_t tokens, int width) {
+    return tokens > 0 && width > 0 ? ((tokens + EMB_BLK - 1) / EMB_BLK) * 2 * (int64_t)width * 4 : 0;
+}
+
 extern "C" int mi355_embedding_bwd_sorted(int64_t tokens, int width, int64_t vocab, const int64_t* sorted_ids, const int64_t* perm, const void* dout,
-                                          int64_t ldd, float scale, void* table, int64_t ldt, int accumulate, void* stream) {
+                                          int64_t ldd, float scale, void* table, int64_t ldt, int accumulate, float* workspace, int64_t workspace_bytes,
+                                          void* stream) {
     MI355_REQUIRE(tokens > 0 && width > 0 && vocab > 0 && sorted_ids && perm && dout && table, "mi355_embedding_bwd_sorted: bad arguments");
     MI355_REQUIRE((width & 7) == 0 && (ldd & 7) == 0 && (ldt & 7) == 0 && (((uintptr_t)dout | (uintptr_t)table) & 15) == 0,
                   "mi355_embedding_bwd_sorted: width and both row pitches must be multiples of 8 elements, pointers 16-byte aligned");
-    hipLaunchKernelGGL(embedding_bwd_sorted_kernel, dim3(grid_for(tokens, 4)), dim3(256), 0, STREAM, tokens, width, vocab, sorted_ids, perm, (const bf16_t*)dout, ldd,
-                       scale, (bf16_t*)table, ldt, accumulate);
+    MI355_REQUIRE(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= mi355_embedding_bwd_sorted_workspace_bytes(tokens, width),
+                  "mi355_embedding_bwd_sorted: a 16-byte aligned workspace of %lld bytes is needed (mi355_embedding_bwd_sorted_workspace_bytes)",
+                  (long long)mi355_embedding_bwd_sorted_workspace_bytes(tokens, width));
+    const int64_t nblk = (tokens + EMB_BLK - 1) / EMB_BLK;
+    hipLaunchKernelGGL(embedding_bwd_sorted_kernel, dim3(grid_for(nblk, 4)), dim3(256), 0, STREAM, tokens, width, vocab, sorted_ids, perm, (const bf16_t*)dout, ldd,
+                       scale, (bf16_t*)table, ldt, accumulate, workspace);
+    if (nblk > 1)
+        hipLaunchKernelGGL(embedding_bwd_join_kernel, dim3(grid_for(nblk - 1, 4)), dim3(256), 0, STREAM, tokens, width, vocab, sorted_ids, scale, (bf16_t*)table, ldt,
+                           accumulate, (const float*)workspace);
     MI355_LAUNCH_CHECK("mi355_embedding_bwd_sorted");
     return 0;
 }

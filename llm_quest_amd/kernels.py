@@ -469,7 +469,8 @@ def embedding_bwd(ids, dout, dtable_f32):
 
 def embedding_bwd_sorted(ids, dout, table, accumulate, scale=1.0):
     """table[id] = (accumulate ? table[id] : 0) + scale * sum of dout rows whose id it is -- deterministic (no atomics): the ids are sorted
-    stably first (index preparation, one device-side sort), then one wave per run of equal ids sums that run's rows in token order.
+    stably first (index preparation, one device-side sort), then each run of equal ids is summed in token order by a fixed two-level tree over
+    blocks of 32 sorted positions (a run of thousands of padding / placeholder tokens does not serialise on one wave).
     Rows of ``table`` (bf16 [vocab, width], row-strided views allowed) that no id names are left untouched."""
     L.require_gpu(ids, dout, table)
     flat = ids.reshape(-1).contiguous()
@@ -478,8 +479,10 @@ def embedding_bwd_sorted(ids, dout, table, accumulate, scale=1.0):
     if dout.dtype != BF16 or table.dtype != BF16 or dout.shape[0] != flat.numel() or dout.shape[1] != table.shape[1] or flat.dtype != torch.int64:
         raise ValueError("embedding_bwd_sorted: int64 ids, bf16 dout [tokens, width] and bf16 table [vocab, width]")
     sid, perm = torch.sort(flat, stable=True)
+    need = L.load().mi355_embedding_bwd_sorted_workspace_bytes(flat.numel(), dout.shape[1])
+    ws = torch.empty((need + 3) // 4, dtype=F32, device=dout.device)  # per-block parts between the two passes of the fixed summation tree
     L.call("mi355_embedding_bwd_sorted", flat.numel(), dout.shape[1], table.shape[0], L.ptr(sid), L.ptr(perm), L.ptr(dout), dout.stride(0), float(scale),
-           L.ptr(table), table.stride(0), int(bool(accumulate)))
+           L.ptr(table), table.stride(0), int(bool(accumulate)), L.ptr(ws), need)
     return table
 
 

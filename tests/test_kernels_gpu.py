@@ -920,3 +920,33 @@ def test_embedding_backward_sorted_is_deterministic_and_matches_fp32(K):
     t2 = dev(table0.clone())
     K.embedding_bwd_sorted(dev(ids[perm]), dev(dout[perm].contiguous()), t2, False, 1.0)
     assert torch.equal(t2, t)
+
+
+@pytest.mark.parametrize("T", [4099, 64, 33, 31])
+def test_embedding_backward_sorted_long_runs_span_blocks(K, T):
+    """Padding / placeholder tokens: one id thousands of times.  The sum is a two-level tree over blocks of 32 sorted positions (pass 1 per block,
+    pass 2 joins the parts of a run that crosses blocks): runs that start and end on and off block boundaries, a run that fills whole blocks, the
+    last (short) block, ids outside the table inside a long run's neighbourhood.  Against fp64, bit-identical between launches."""
+    V, W = 300, 512
+    g = torch.Generator().manual_seed(T)
+    ids = torch.randint(0, V, (T,), generator=g)
+    ids[torch.rand(T, generator=g) < 0.7] = 17  # ~70 % of the positions: one run over many blocks
+    if T > 200:
+        ids[100:164] = 250  # 64 positions: two full blocks' worth, wherever the sort puts them
+        ids[200:233] = 251  # 33 positions
+        ids[7] = -5
+    dout = torch.randn(T, W, generator=g).to(BF16)
+    ok = (ids >= 0) & (ids < V)
+    ref = torch.zeros(V, W, dtype=torch.float64).index_add(0, ids[ok], dout[ok].double())
+    outs = []
+    for _ in range(2):
+        t = dev(torch.full((V, W), 7.0).to(BF16))
+        K.embedding_bwd_sorted(dev(ids), dev(dout), t, False, 1.0)
+        outs.append(t)
+    assert torch.equal(outs[0], outs[1])
+    named = torch.zeros(V, dtype=torch.bool)
+    named[ids[ok]] = True
+    got = outs[0].cpu()
+    assert torch.equal(got[~named], torch.full((V, W), 7.0).to(BF16)[~named])
+    err = (got[named].double() - ref[named]).abs().max() / ref[named].abs().max()
+    assert err < 6e-3, float(err)  # one bf16 rounding of sums of up to thousands of rows
