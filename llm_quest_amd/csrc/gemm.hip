@@ -207,7 +207,10 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
     // super-group height by in-step A/B on the VLM step (ms/step, two runs each): 2: 245.9 / 246.2, 3: 243.8 / 243.8, 4: 245.3 / 245.3, 6: 243.8 / 244.3,
     // 8: 245.2 / 245.6, 16: 249.7 / 248.0.  Profiling bits 5-7 of the tile hint select another height.
     const int gsel = (p.ablate >> 5) & 7;
-    const int GROUP_M = gsel == 1 ? 4 : gsel == 2 ? 16 : gsel == 3 ? 2 : gsel == 4 ? 6 : gsel == 5 ? 8 : 3;
+    // Round 3, NT gate-up shape alone (profiles/r03_tile_walk.json): fabric reads 1 383 / 1 116 / 996 / 946 / 1 010 / 1 390 MB at heights 2 / 3 / 4 / 6 / 8 / 16, time
+    // 602 / 595 / 582 / 584 / 583 / 585 us -- the walk moves the re-fetch by 1.5x and the time by 2 %; in the step, all NT launches at 6 against 3: 194.5 / 194.6 against
+    // 194.9 / 195.2 ms.  NT launches therefore walk 6-row groups, the K-strided forms stay at 3 (selector 6 = 3 rows for A/B runs).
+    const int GROUP_M = gsel == 1 ? 4 : gsel == 2 ? 16 : gsel == 3 ? 2 : gsel == 4 ? 6 : gsel == 5 ? 8 : gsel == 6 ? 3 : (!A_TR && !B_TR) ? 6 : 3;
     const int in_group = GROUP_M * p.tiles_n;
     const int first_m = (pid / in_group) * GROUP_M;
     const int gsz = min(p.tiles_m - first_m, GROUP_M);
