@@ -352,7 +352,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lean_kernel(int B, int S, int
         unsigned long long kbits = nv >= 64 ? ~0ull : ((1ull << nv) - 1ull);
         if (mrow) kbits &= __ballot(mk != 0);
         [[maybe_unused]] const unsigned long long t_iss = PROF_T();
-        if (kt + 1 < ntiles) issue(kt + 1, (kt + 1) & 1);
+        // the next tile's 2 PPW pieces: a whole tile's are spread over the S product below, one behind every second MFMA (requested in one burst, the
+        // four waves' 32 pieces queue at the CU's address unit and each wave sits ~75 cycles per piece in front of it); a ragged last tile keeps the burst
+        const bool more = kt + 1 < ntiles;
+        const bool spread = more && S - (kt + 1) * 64 >= 64 && !(abl & 512);
+        if (more && !spread) issue(kt + 1, (kt + 1) & 1);
+        const auto nkr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kbase + (int64_t)(kt + 1) * 64 * ldk), 0, 0x7fffffff, 0x00020000);
+        const auto nvr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vbase + (int64_t)(kt + 1) * 64 * ldv), 0, 0x7fffffff, 0x00020000);
+        char* const nst = smem + ((kt + 1) & 1) * 2 * C::TILE;
+        auto piece = [&](auto i_) {
+            constexpr int i = i_.value;
+            if constexpr (i < C::PPW) {
+                const int row = (wave * C::PPW + i) * C::RPP + prow;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(nkr, LDS_PTR(nst + (wave * C::PPW + i) * 1024), 16, dk_row + (unsigned)(swz_row<D>(pch, row) << 4), (int)(i * C::RPP * ldk * 2), 0, 0);
+            } else {
+                constexpr int j = i - C::PPW;
+                const int row = (wave * C::PPW + j) * C::RPP + prow;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(nvr, LDS_PTR(nst + C::TILE + (wave * C::PPW + j) * 1024), 16, dv_row + (unsigned)(swz_tr<D>(pch, row) << 4), (int)(j * C::RPP * ldv * 2), 0, 0);
+            }
+        };
         PROF_ADD(2, t_iss);
         if (mrow) mk = mrow[min((kt + 1) * 64 + lane, S - 1)];
         [[maybe_unused]] unsigned long long t_seg = PROF_T();
@@ -366,13 +384,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lean_kernel(int B, int S, int
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt) vv[dt] = lo.col[dt] + voff;
         f32x16 sacc[2];
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            sacc[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(smem, vkx[0], st * 32 * C::ROWB), qf[0], ninit, 0, 0, 0);
-#pragma unroll
-            for (int ks = 1; ks < C::KS; ++ks)
-                sacc[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(smem, vkx[ks], st * 32 * C::ROWB), qf[ks], sacc[st], 0, 0, 0);
-        }
+        static_assert(2 * C::PPW == C::KS, "one next-tile piece behind every second MFMA of the S product");
+        // two straight-line copies: a branch per piece would keep hipcc from requesting the K fragments ahead.  (K fragments from asm statements, four
+        // products ahead of their MFMA -- hipcc does not move a visible LDS read across an LDS-DMA request, so the spread copy reads only one pair
+        // ahead -- measured 254 us against 245 for this form: the compiler's own placement of the reads is the better one; attn_common.h keeps the helper.)
+        auto s_product = [&](auto spread_c) {
+            static_for<2>([&](auto st_) {
+                constexpr int st = st_.value;
+                static_for<C::KS>([&](auto ks_) {
+                    constexpr int ks = ks_.value, m = st * C::KS + ks;
+                    sacc[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(smem, vkx[ks], st * 32 * C::ROWB), qf[ks], ks == 0 ? ninit : sacc[st], 0, 0, 0);
+                    if constexpr (decltype(spread_c)::value && m % 2 == 1) piece(std::integral_constant<int, m / 2>{});
+                });
+            });
+        };
+        if (spread) s_product(std::true_type{});
+        else s_product(std::false_type{});
         TrHalves ft[2][C::DT];
         auto issue_v = [&](auto g_) {
             constexpr int g = g_.value, imm = 16 * g * C::ROWB;

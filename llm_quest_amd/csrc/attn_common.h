@@ -156,6 +156,20 @@ __device__ __forceinline__ bf16x8 tr_wait(TrHalves& f) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.lo), "+v"(f.hi) : "n"(N) : "memory");
     return __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
+// Row-image fragment (ds_read_b128) from an asm statement, for loops that interleave LDS-DMA requests with their fragment reads: hipcc orders
+// every compiler-visible LDS read behind an LDS-DMA in front of it and so cannot request fragments ahead across one.  Same contract as tr_issue /
+// tr_wait: the value is dead until rowfrag_wait<N> (N = LDS operations issued after this read) has named it.
+template <int IMM>
+__device__ __forceinline__ void rowfrag_issue(u32x4& f, unsigned a) {
+    static_assert(IMM >= 0 && IMM < 65536, "ds offset field is 16 bits");
+    asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=&v"(f) : "v"(a), "i"(IMM));
+}
+template <int N>
+__device__ __forceinline__ bf16x8 rowfrag_wait(u32x4& f) {
+    static_assert(N >= 0 && N <= 15, "lgkmcnt field is 4 bits");
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N) : "memory");
+    return __builtin_bit_cast(bf16x8, f);
+}
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
