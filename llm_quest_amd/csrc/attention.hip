@@ -245,8 +245,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lean_kernel(int B, int S, int
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nqb = (S + 127) / 128;
     const int vid = xcd_chunked((int)blockIdx.x, (int)gridDim.x);
-    const int qb = nqb - 1 - (vid % nqb);  // heaviest (latest) query blocks first under the causal mask
-    const int bh = vid / nqb;
+    int qb, bh;
+    heavy_first(vid, nqb, B * Hq, (abl & 256) ? 1 : (abl & 1024) ? 8 : (abl & 128) ? 32 : (abl & 64) ? 64 : ATTN_HEAD_GROUP, qb, bh);  // ablation bits 8 / 10 / 7 / 6: head by head, groups of 8 / 32 / 64
     const int hq = bh % Hq, b = bh / Hq;
     const int hkv = hq / (Hq / Hkv);
     const int q0 = qb * 128;
@@ -1163,8 +1163,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_spill_kernel(int B, int S,
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nqb = (S + 127) / 128;
     const int vid = xcd_chunked((int)blockIdx.x, (int)gridDim.x);
-    const int qb = nqb - 1 - (vid % nqb);  // heaviest (latest) query blocks first under the causal mask
-    const int bh = vid / nqb;
+    int qb, bh;
+    heavy_first(vid, nqb, B * Hq, ATTN_HEAD_GROUP, qb, bh);
     const int hq = bh % Hq, b = bh / Hq;
     const int hkv = hq / (Hq / Hkv);
     const int q0 = qb * 128;

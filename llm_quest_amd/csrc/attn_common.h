@@ -156,6 +156,20 @@ __device__ __forceinline__ bf16x8 tr_wait(TrHalves& f) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.lo), "+v"(f.hi) : "n"(N) : "memory");
     return __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
+// Workgroup id -> (query block, head) of the per-block attention kernels.  Under the causal mask a block's work grows with its index (2, 4, ... tiles), so
+// the heaviest blocks go first -- not head by head (the light blocks of the LAST heads then run on a half-empty chip: 116 tile-times where 108 are the
+// ideal on 64 slots per XCD at the headline shape) but over groups of GROUP consecutive heads: all heaviest blocks of the group, then the next lighter
+// ones, ...  (GROUP = 8: 110; 16: 110; 32: 108 -- but from 32 on the K / V rows of the heads running together no longer fit an XCD's 4 MB L2; measured forward at the headline shape: 250 us head by head, 241 at 8, 237 at 16, 242 at 32, 244 at 64).
+#ifndef ATTN_HEAD_GROUP
+#define ATTN_HEAD_GROUP 16
+#endif
+__device__ __forceinline__ void heavy_first(int vid, int nqb, int heads, int group, int& qb, int& bh) {
+    const int per = group * nqb, sg = vid / per, r = vid - sg * per;
+    const int gsz = min(group, heads - sg * group);
+    qb = nqb - 1 - r / gsz;
+    bh = sg * group + r % gsz;
+}
+
 // Row-image fragment (ds_read_b128) from an asm statement, for loops that interleave LDS-DMA requests with their fragment reads: hipcc orders
 // every compiler-visible LDS read behind an LDS-DMA in front of it and so cannot request fragments ahead across one.  Same contract as tr_issue /
 // tr_wait: the value is dead until rowfrag_wait<N> (N = LDS operations issued after this read) has named it.

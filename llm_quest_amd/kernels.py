@@ -5,12 +5,15 @@ pointer reaches the GPU, allocates outputs with torch (device memory plumbing on
 torch's current stream.
 """
 
+import os
+
 import torch
 
 from . import _lib as L
 
 BF16, F32 = torch.bfloat16, torch.float32
 NORM_PARTS = 512  # max blocks (= partial rows) of the norm backward kernels
+QK_PARTS = int(os.environ.get("MI355_QK_PARTS", "512"))  # ... of the QK-norm + RoPE backward (a wave walks one token at a time: more blocks = more rows in flight)
 
 
 def _rowmajor(t, name):
@@ -267,7 +270,7 @@ def qknorm_rope_bwd(qkv, qw, kw, cos, sin, pos, rstd, dq, dk, dqkv, Hq, Hkv, D):
     if not (dqkv.is_contiguous() and dqkv.shape == qkv.shape and dqkv.dtype == BF16):
         raise ValueError("qknorm_rope_bwd: dqkv must be contiguous bf16 like qkv")
     hpw = 4 if D == 128 else 8
-    parts = min(NORM_PARTS, (tokens * ((Hq + Hkv + hpw - 1) // hpw) + 3) // 4)
+    parts = min(QK_PARTS, (tokens * ((Hq + Hkv + hpw - 1) // hpw) + 3) // 4)
     part = torch.empty((parts, 2 * D), dtype=F32, device=qkv.device)
     L.call("mi355_qknorm_rope_bwd", tokens, Hq, Hkv, D, L.ptr(qkv), L.ptr(qw), L.ptr(kw), L.ptr(cos), L.ptr(sin), L.ptr(pos), L.ptr(rstd), L.ptr(dq), L.ptr(dk), L.ptr(dqkv), L.ptr(part), parts)
     dw = torch.empty(2 * D, dtype=F32, device=qkv.device)
