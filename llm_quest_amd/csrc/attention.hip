@@ -311,7 +311,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lean_kernel(int B, int S, int
     const unsigned lds0 = (unsigned)(unsigned long long)LDS_PTR(smem);
     issue(0, 0);  // first tile first, then the query rows: their latencies overlap
     bf16x8 qf[C::KS];
-    load_rows_frag<D>(q + (int64_t)b * S * ldq + (int64_t)hq * D, ldq, qg, qvalid, lane, qf);
+    if (abl & 32) {  // ablation: a query row per lane straight from memory (64 lanes in 64 rows: the slow access shape)
+        load_rows_frag<D>(q + (int64_t)b * S * ldq + (int64_t)hq * D, ldq, qg, qvalid, lane, qf);
+    } else {
+        // the 128 query rows as two 64-row row images in stage 1 (free until tile 1 is requested behind the loop's first barrier), by LDS-DMA: whole
+        // rows per request instead of a row per lane; the fragments are then A-shaped reads of a row image, which is what a B operand of S^T = K Q^T is
+        const bf16_t* qblk = q + ((int64_t)b * S + q0) * ldq + (int64_t)hq * D;
+        dma_tile<D, IMG_ROW>(qblk, ldq, S - q0, smem + 2 * C::TILE, wave, lane);
+        dma_tile<D, IMG_ROW>(qblk + 64 * ldq, ldq, S - q0 - 64, smem + 3 * C::TILE, wave, lane);
+        wait_vmcnt<0>();
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) qf[ks] = frag_rows<D>(smem + (2 + (wave >> 1)) * C::TILE, (wave & 1) * 32, ks, lane);
+    }
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) {  // q * log2(e) / sqrt(d), rounded to bf16 again
         u32x4 w = __builtin_bit_cast(u32x4, qf[ks]);
@@ -509,19 +521,44 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lean_kernel(int B, int S, int
 
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
-    // whole 16-byte pieces: one v_permlane32_swap per word pairs the half-waves' 8-byte pieces of a row
-    bf16_t* orow = o + ((int64_t)b * S + qg) * ldo + (int64_t)hq * D + 8 * (lane >> 5);
+    if (abl & 32) {
+        // whole 16-byte pieces: one v_permlane32_swap per word pairs the half-waves' 8-byte pieces of a row
+        bf16_t* orow = o + ((int64_t)b * S + qg) * ldo + (int64_t)hq * D + 8 * (lane >> 5);
 #pragma unroll
-    for (int dt = 0; dt < C::DT; ++dt)
+        for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
-        for (int gp = 0; gp < 2; ++gp) {
-            const int r0 = 8 * gp;
-            const unsigned a0 = pack_bf2(oacc[dt][r0] * inv, oacc[dt][r0 + 1] * inv), a1 = pack_bf2(oacc[dt][r0 + 2] * inv, oacc[dt][r0 + 3] * inv);
-            const unsigned b0 = pack_bf2(oacc[dt][r0 + 4] * inv, oacc[dt][r0 + 5] * inv), b1 = pack_bf2(oacc[dt][r0 + 6] * inv, oacc[dt][r0 + 7] * inv);
-            const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false), s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-            const u32x4 w = {s0[0], s1[0], s0[1], s1[1]};
-            if (qvalid) *reinterpret_cast<u32x4*>(orow + dt * 32 + 16 * gp) = w;
+            for (int gp = 0; gp < 2; ++gp) {
+                const int r0 = 8 * gp;
+                const unsigned a0 = pack_bf2(oacc[dt][r0] * inv, oacc[dt][r0 + 1] * inv), a1 = pack_bf2(oacc[dt][r0 + 2] * inv, oacc[dt][r0 + 3] * inv);
+                const unsigned b0 = pack_bf2(oacc[dt][r0 + 4] * inv, oacc[dt][r0 + 5] * inv), b1 = pack_bf2(oacc[dt][r0 + 6] * inv, oacc[dt][r0 + 7] * inv);
+                const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false), s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                const u32x4 w = {s0[0], s1[0], s0[1], s1[1]};
+                if (qvalid) *reinterpret_cast<u32x4*>(orow + dt * 32 + 16 * gp) = w;
+            }
+    } else {
+        // through LDS (the tile stages are dead): [128 rows][2 D bytes], the 16-byte piece index XORed with the row so that the 8-byte writes of a
+        // half-wave's 32 rows spread over the banks; then every store instruction of a wave covers whole rows (a row per lane is the 17x slower shape)
+        constexpr int RB = 2 * D, PCS = RB / 16;  // row bytes, 16-byte pieces per row
+        __syncthreads();
+        {
+            const int row = wave * 32 + (lane & 31), hb = lane >> 5;
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int chunk = dt * 8 + 2 * g4 + hb;  // features 4 chunk .. 4 chunk + 3 (8 bytes)
+                    const u32x2 pk = {pack_bf2(oacc[dt][4 * g4] * inv, oacc[dt][4 * g4 + 1] * inv), pack_bf2(oacc[dt][4 * g4 + 2] * inv, oacc[dt][4 * g4 + 3] * inv)};
+                    *reinterpret_cast<u32x2*>(smem + row * RB + (((chunk >> 1) ^ (row & (PCS - 1))) << 4) + (chunk & 1) * 8) = pk;
+                }
         }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 128 * PCS / 256; ++it) {
+            const int i = it * 256 + (int)threadIdx.x, row = i / PCS, pc = i % PCS;
+            const u32x4 w = *reinterpret_cast<const u32x4*>(smem + row * RB + ((pc ^ (row & (PCS - 1))) << 4));
+            if (q0 + row < S) *reinterpret_cast<u32x4*>(o + ((int64_t)b * S + q0 + row) * ldo + (int64_t)hq * D + pc * 8) = w;
+        }
+    }
     // a row whose visible keys are all padding reports the fill value as its maximum, as the first-generation kernel does
     if (qvalid && lane < 32) lse[((int64_t)b * Hq + hq) * S + qg] = ((qrow ? MASK_T : mref) + __builtin_amdgcn_logf(l)) * LN2;
 }
