@@ -25,6 +25,18 @@
 
 namespace {
 
+// -DGEMM_SWAP=1 (round-3 experiment, NOT the default): the B-matrix fragment as the MFMA's first operand, so that an accumulator tile holds four consecutive
+// COLUMNS of one row per lane and the epilogue's staging writes are 16 16-byte LDS stores per 64x64 sub-block instead of 64 4-byte ones.  Correct (all GEMM tests),
+// level in isolation (gate-up + SwiGLU 606.6 against 606 us, plain 523) and SLOWER in the step: 192.7 / 193.1 / 192.6 against 190.6 / 190.9 / 191.1 ms in three
+// same-box pairs -- the main loops are the same instructions with the operand registers exchanged, and that is enough to move the step by 1 %.
+#ifndef GEMM_SWAP
+#define GEMM_SWAP 0
+#endif
+#if GEMM_SWAP
+#define MFMA_CT(af, bf, c) (c) = __builtin_amdgcn_mfma_f32_16x16x32_bf16((bf), (af), (c), 0, 0, 0)
+#else
+#define MFMA_CT(af, bf, c) (c) = __builtin_amdgcn_mfma_f32_16x16x32_bf16((af), (bf), (c), 0, 0, 0)
+#endif
 constexpr int EPI_LD = 68;             // fp32 row pitch of the epilogue staging (bank-spread, 16-B aligned)
 constexpr unsigned OOB = 0x80000000u;  // beyond num_records (0x7fffffff): load returns zeros
 
@@ -367,7 +379,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
                 for (int i = 0; i < HM; ++i)
 #pragma unroll
                     for (int j = 0; j < T::FN; ++j)
-                        acc[ph * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[ph * HM + i][j], 0, 0, 0);
+                        acc[ph * HM + i][j] = MFMA_CT(a[i], b[j], acc[ph * HM + i][j]);
                 if (p.ablate & 1) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -395,7 +407,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
         // The accumulators are pinned to the accumulation registers by the operand constraint: with the builtin, hipcc keeps part of the
         // 256 values in vector registers and moves four in and four out around every MFMA (measured: 594 TFLOP/s on the gate-up shape).
         auto mma = [&](f32x4& c, const bf16x8& av, const bf16x8& bv) {
+#if GEMM_SWAP
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %1, %0" : "+a"(c) : "v"(av), "v"(bv));  // B fragment first: see MFMA_CT
+#else
             asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(av), "v"(bv));
+#endif
         };
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -542,7 +558,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
                 for (int i = 0; i < HM; ++i)
 #pragma unroll
                     for (int j = 0; j < T::FN; ++j)
-                        acc[ph * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[ph * HM + i][j], 0, 0, 0);
+                        acc[ph * HM + i][j] = MFMA_CT(a[i], b[j], acc[ph * HM + i][j]);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 GP_ADD(5, gt);  // MFMA cluster issued
@@ -587,7 +603,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
         for (int i = 0; i < HM; ++i)
 #pragma unroll
             for (int j = 0; j < T::FN; ++j)
-                acc[mh * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[mh * HM + i][j], 0, 0, 0);
+                acc[mh * HM + i][j] = MFMA_CT(a[i], b[j], acc[mh * HM + i][j]);
         if constexpr (T::NW != 8) __builtin_amdgcn_s_setprio(0);
     };
     auto wait_tile = [&](int younger) {  // returns once at most min(NS-2, younger) younger tiles of this wave are in flight
@@ -734,6 +750,15 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
                         }
                     }
                 }
+#if GEMM_SWAP
+                // every MFMA takes the B fragment as its first operand (MFMA_CT), so a 16x16 accumulator tile is the TRANSPOSE of the usual layout: the lane holds
+                // C[lane & 15][4 (lane >> 4) + e], four consecutive COLUMNS of one row -- one 16-byte LDS store per tile (16 per sub-block) instead of four 4-byte ones (64)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        *reinterpret_cast<f32x4*>(stg + (i * 16 + (lane & 15)) * EPI_LD + j * 16 + (lane >> 4) * 4) = acc[sm * 4 + i][sn * 4 + j];
+#else
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -741,6 +766,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             stg[(i * 16 + (lane >> 4) * 4 + e) * EPI_LD + j * 16 + (lane & 15)] = acc[sm * 4 + i][sn * 4 + j][e];
+#endif
                 __builtin_amdgcn_wave_barrier();
                 const int64_t gn = n0 + wc0 + sn * 64 + (lane & 7) * 8;
                 const int64_t gm0 = m0 + wr0 + sm * 64;
