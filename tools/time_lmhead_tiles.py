@@ -15,7 +15,7 @@ def bench(fn, n=6):
     return s.elapsed_time(e) / n
 for rnd in range(2):
     for name, fn in (("tile 2", lambda: K.gemm(L.GEMM_NT, a, b, out=out, tile=2, allow_split_k=False)), ("tile 5", lambda: K.gemm(L.GEMM_NT, a, b, out=out, tile=5, allow_split_k=False)),
-                     ("tile 3", lambda: K.gemm(L.GEMM_NT, a, b, out=out, tile=3, allow_split_k=False)), ("tile 4", lambda: K.gemm(L.GEMM_NT, a, b, out=out, tile=4, allow_split_k=False)),
+                     ("tile 1", lambda: K.gemm(L.GEMM_NT, a, b, out=out, tile=1, allow_split_k=False)), ("tile 3", lambda: K.gemm(L.GEMM_NT, a, b, out=out, tile=3, allow_split_k=False)), ("tile 4", lambda: K.gemm(L.GEMM_NT, a, b, out=out, tile=4, allow_split_k=False)),
                      ("library", lambda: torch.matmul(a, b.t(), out=out))):
         t = bench(fn)
         print(f"round {rnd}: {name:10s} {t:7.3f} ms  {2.0 * M * N * Kd / t / 1e9:7.0f} TFLOP/s", flush=True)
