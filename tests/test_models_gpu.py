@@ -296,6 +296,52 @@ def test_vlm_training_loop_runs_and_learns(golden):
     assert after < before - 0.5, (before, after)
 
 
+def test_vlm_training_loop_equals_its_steps_written_out(golden):
+    """vlm_training_loop_simple on the GPU (frozen tower one batch ahead on a second stream, device-side loss accumulation) against the reference's step
+    written out by hand on a second copy of the models -- loss, backward, clip_grad_norm_(1.0), optimizer.step, zero_grad (reference vlm_engine.py:44-164),
+    tower in front of the decoder on the same stream: after three different batches every parameter is bit-identical (the kernels are deterministic), so the
+    order of the loop's operations and the look-ahead tower are pinned on the HIP path, not only that the loss falls."""
+    from llm_quest_amd.engine import clip_grad_norm_
+    from llm_quest_amd.multimodal.vision_transformer.vit_engine import ViTAdapter
+    from llm_quest_amd.multimodal.vision_transformer.vit_model import ViTModel
+    from llm_quest_amd.multimodal.vlm_engine import vlm_step_loss, vlm_training_loop_simple
+
+    t = golden("vlm_tiny")
+    dev = torch.device("cuda")
+
+    def build():
+        vit = ViTModel(dict(TINY_VIT))
+        load_into(vit, sub_dict(t, "vit."))
+        llm = make_qwen(t, "llm.")
+        ad = ViTAdapter(64, 128, adapter_type="ffn", dtype=BF16)
+        ad.load_state_dict(sub_dict(t, "ad."))
+        return vit.to(dev), llm.to(dev), ad.to(dev)
+
+    g = torch.Generator().manual_seed(7)
+    loader = []
+    for i in range(3):  # three DIFFERENT batches: a tower that ran on the wrong batch, or a stale gradient, would show
+        loader.append({"image": t["in.image"] + 0.1 * i * torch.randn(t["in.image"].shape, generator=g),
+                       "input_ids": torch.randint(0, 512, t["in.ids"].shape, generator=g), "attention_mask": t["in.text_mask"].bool()})
+    vit1, llm1, ad1 = build()
+    opt1 = torch.optim.AdamW(list(llm1.parameters()) + list(ad1.parameters()), lr=1e-3)
+    vlm_training_loop_simple(vit1, llm1, ad1, loader, opt1, 1, dev, hf_vit_model=False)
+    vit2, llm2, ad2 = build()
+    vit2.eval()
+    for p in vit2.parameters():
+        p.requires_grad = False
+    opt2 = torch.optim.AdamW(list(llm2.parameters()) + list(ad2.parameters()), lr=1e-3)
+    for b in loader:
+        loss = vlm_step_loss(vit2, llm2, ad2, b["image"].to(dev), b["input_ids"].to(dev), b["attention_mask"].to(dev), False)
+        loss.backward()
+        clip_grad_norm_(list(llm2.parameters()) + list(ad2.parameters()), max_norm=1.0)
+        opt2.step()
+        opt2.zero_grad()
+    for (n1, p1), (n2, p2) in zip(list(llm1.named_parameters()) + list(ad1.named_parameters()), list(llm2.named_parameters()) + list(ad2.named_parameters())):
+        assert n1 == n2 and torch.equal(p1, p2), n1
+    moved = sum(float((p1.detach().float() - p0.detach().float().to(dev)).abs().sum()) for (_, p1), p0 in zip(llm1.named_parameters(), make_qwen(t, "llm.").parameters()))
+    assert moved > 0, "the loop must have updated the decoder"
+
+
 def test_lm_engine_loop_on_gpu(golden):
     """training_eval_loop (reference signature) with the HIP Qwen3: clip, scheduler, accumulation, eval."""
     from llm_quest_amd.engine import LearningRateScheduler, training_eval_loop
@@ -308,6 +354,38 @@ def test_lm_engine_loop_on_gpu(golden):
     sch = LearningRateScheduler(opt, total_steps=6, init_lr=1e-5, peak_lr=1e-3, warmup_steps=2, min_lr=1e-4, decay="cosine")
     tr, va = training_eval_loop(data, data[:2], m, opt, 2, sch, eval_freq=2, eval_iter=1, device=torch.device("cuda"), accumulation_steps=2)
     assert len(tr) == len(va) >= 2 and all(torch.isfinite(torch.tensor(tr)))
+
+
+def test_lm_training_eval_loop_equals_its_steps_written_out(golden):
+    """training_eval_loop on the GPU (reference engine.py:377-470) against its step written out on a second copy of the model: accumulation windows of two
+    with a ragged last one (5 batches), clip_grad_norm_(1) before lr_scheduler.step(step) before optimizer.step, zero_grad; every parameter bit-identical
+    after one epoch, and the evaluations it interleaves (model.eval / train toggles, no_grad forwards) leave no trace in the weights."""
+    from llm_quest_amd.engine import LearningRateScheduler, clip_grad_norm_, global_loss, training_eval_loop
+
+    t = golden("qwen3_tiny")
+    g = torch.Generator().manual_seed(3)
+    data = [(torch.randint(0, 512, (2, 24), generator=g), torch.randint(0, 512, (2, 24), generator=g)) for _ in range(5)]
+    dev = torch.device("cuda")
+    sched = lambda opt: LearningRateScheduler(opt, total_steps=6, init_lr=1e-5, peak_lr=1e-3, warmup_steps=2, min_lr=1e-4, decay="cosine")
+    m1 = make_qwen(t)
+    opt1 = torch.optim.AdamW(m1.parameters(), lr=1e-3)
+    training_eval_loop(data, data[:2], m1, opt1, 1, sched(opt1), eval_freq=2, eval_iter=1, device=dev, accumulation_steps=2)
+    m2 = make_qwen(t)
+    opt2 = torch.optim.AdamW(m2.parameters(), lr=1e-3)
+    sch2, step, acc = sched(opt2), 0, 2
+    for i, (X, y) in enumerate(data):
+        last, pos = i == len(data) - 1, (i + 1) % acc
+        loss = global_loss(m2(X.to(dev)), y.to(dev), model=m2)  # (the loop's autocast is a no-op on the device: the HIP model computes in explicit bf16)
+        (loss / pos if (last and pos != 0) else loss / acc).backward()
+        if pos == 0 or last:
+            clip_grad_norm_(m2.parameters(), max_norm=1)
+            sch2.step(step)
+            opt2.step()
+            opt2.zero_grad()
+            step += 1
+    assert step == 3
+    for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2), n1
 
 
 def test_rccl_gradsync_single_rank(golden):
