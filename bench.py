@@ -214,9 +214,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="per-GPU micro-batch (samples); 64 x 709 tokens keeps ~70 GB of the 288 GB HBM live.  (92 x 709 = 254.8 row tiles of "
-                    "256 fills the GEMM grids' last round of CUs to 99.6 %% instead of 92.7 %%, but measures the same img+tok/s on the same box: the tail tiles of a "
-                    "partial round run faster -- the chip is power-limited -- so the quantisation is worth nothing)")
+    ap.add_argument("--batch", type=int, default=160, help="per-GPU micro-batch (samples).  160 x 709 tokens keep 165 GiB of the 288 GB of HBM live; same-box pairs: 64 -> 34.2 / 34.1 %%, "
+                    "128 -> +1.4 %%, 160 -> 35.0 / 34.9 %%, 192 -> level with 160 (202 GiB).  More rounds of tiles per launch amortise every launch's fill and tail.  (92 -- every "
+                    "launch a whole number of rounds at batch ~64 -- measured the same as 64: the tail tiles of a partial round run faster, the chip is power-limited)")
     ap.add_argument("--cpu-baseline", choices=["auto", "off"], default="auto")
     ap.add_argument("--ragged", action="store_true", help="text lengths ~ U[256, 512] (padding mask active in attention and loss) instead of all-ones masks")
     ap.add_argument("--optimizer", choices=["on", "off"], default="on", help="also time the same steps with clip + AdamW (reported beside the fwd+bwd metric)")
@@ -359,7 +359,7 @@ def main():
                 "basis": "algorithmic 2.566 TFLOP/sample (SURVEY 8d) x per-GPU batch / step time; device-side (HIP events) "
                          f"{dev_ms / args.steps:.3f} ms/step",
             },
-            "loss": round(loss_gpu, 5),
+            "loss": round(loss_gpu, 5), "peak_memory_gib": round(torch.cuda.max_memory_allocated(device) / 2**30, 1),
         }
         if train_step is not None:
             line["with_optimizer_step"] = train_step
