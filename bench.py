@@ -229,6 +229,8 @@ def main():
     # (rank start-up, broadcast, bucketed exchange on the communication stream, split tied-weight bucket, barriers, max-over-ranks timing, the one
     # JSON line) runs except RCCL itself.  The line it prints carries "rehearsal": true and is no measurement.
     rehearsal = os.environ.get("MI355_DDP_REHEARSAL") == "1"
+    if rehearsal and args.gpus > torch.cuda.device_count() and args.batch * args.gpus > 192 * max(torch.cuda.device_count(), 1):
+        raise SystemExit("rehearsal: the ranks share the visible GPU(s) -- pass a small --batch (e.g. 8), the default would not fit")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         n_dev = torch.cuda.device_count()  # counts devices without creating a HIP context
         if n_dev < args.gpus and not rehearsal:
