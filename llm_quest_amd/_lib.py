@@ -78,6 +78,7 @@ SIGNATURES = {
     "mi355_l2norm_fwd": [_L, _I, _I, _P, _L, _P, _P],
     "mi355_l2norm_bwd": [_L, _I, _I, _P, _L, _P, _P, _L, _P],
     "mi355_gated_delta_rule_fwd": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P],
+    "mi355_gated_delta_rule_chunked_fwd": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _L, _P],
     "mi355_causal_conv_silu_step": [_I, _I, _I, _P, _L, _P, _P, _P, _P],
     "mi355_gated_delta_rule_bwd": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _P],
     "mi355_gated_rmsnorm_fwd": [_L, _I, _I, _P, _P, _P, _L, _P, _P, _F, _P],
@@ -103,6 +104,7 @@ QUERIES = {
     "mi355_gated_delta_rule_bwd_workspace_bytes": ([_I, _I, _I, _I, _I], _L),
     "mi355_attn_bwd_workspace_bytes": ([_I, _I, _I, _I], _L),
     "mi355_attn_bwd_qnorm_partials": ([_I, _I, _I], _L),
+    "mi355_gated_delta_rule_chunked_workspace_bytes": ([_I, _I, _I], _L),
     "mi355_embedding_bwd_sorted_workspace_bytes": ([_L, _I], _L),
 }
 
