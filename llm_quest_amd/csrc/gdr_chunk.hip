@@ -12,6 +12,7 @@
 // (e = 0..3) of column lane & 15 -- exactly the four k values a lane supplies to four consecutive 16x16x4 steps when the contraction index is permuted
 // as k = 16 kb + 4 (lane >> 4) + e, which the A operand (read from LDS as one 16-byte piece per lane) follows for free.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -34,7 +35,7 @@ __device__ __forceinline__ f32x4 ldsv(const float* p) { return *reinterpret_cast
 // ---------------------------------------------------------------------------------------------------------------- the part that needs no state
 __global__ __launch_bounds__(256) void gdr_chunk_prep_kernel(int B, int S, int Hqk, int Hv, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                              const bf16_t* __restrict__ v, int64_t ldv, const float* __restrict__ beta,
-                                                             const float* __restrict__ alpha, float* __restrict__ ws, int nchunk, float scale) {
+                                                             const float* __restrict__ alpha, float* __restrict__ ws, int nchunk, float scale, int abl) {
     __shared__ __attribute__((aligned(16))) float Ks[GC * LDW];   // K rows
     __shared__ __attribute__((aligned(16))) float Xs[GD * LDC];   // Q rows ([GC][LDW] fits), later V^T
     __shared__ __attribute__((aligned(16))) float KT[GD * LDC];   // K^T
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void gdr_chunk_prep_kernel(int B, int S, int H
 
     // ---- b. K K^T and Q K^T (wave = 16-row block), masked and decayed
 #pragma unroll 1
-    for (int nt = 0; nt < 4; ++nt) {
+    for (int nt = 0; nt < ((abl & 2) ? 0 : 4); ++nt) {
         f32x4 akk = {0.f, 0.f, 0.f, 0.f}, aqk = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < GD / 16; ++kb) {
@@ -108,6 +109,10 @@ __global__ __launch_bounds__(256) void gdr_chunk_prep_kernel(int B, int S, int H
     // ---- c. wave 0: R = (I + M)^-1 by forward substitution, a column per lane (row i of R = e_i - sum_{k<i} M[i][k] R[k]);  waves 1-3: Q', then K^T, V^T, K'T
     if (wave == 0) {
         float R[GC];
+        if (abl & 1) {  // profiling only: T = diag(beta)
+#pragma unroll
+            for (int i = 0; i < GC; ++i) Ts[i * LDC + lane] = i == lane ? bet[lane] : 0.0f;
+        } else {
 #pragma unroll
         for (int i = 0; i < GC; ++i) {
             float s = i == lane ? 1.0f : 0.0f;
@@ -118,6 +123,7 @@ __global__ __launch_bounds__(256) void gdr_chunk_prep_kernel(int B, int S, int H
         const float bc = bet[lane];
 #pragma unroll
         for (int i = 0; i < GC; ++i) Ts[i * LDC + lane] = R[i] * bc;
+        }
     } else {
         const int t3 = tid - 64;  // 0..191
         for (int idx = t3; idx < GC * GD / 4; idx += 192) {  // Q' = scale gam_i Q, row-major [GC][GD]
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(256) void gdr_chunk_prep_kernel(int B, int S, int H
 
     // ---- d / e. Uv = T V (accumulator-tile layout of the scan), nKw = -(T diag(gam)) K (row-major)
 #pragma unroll 1
-    for (int nt = 0; nt < GD / 16; ++nt) {
+    for (int nt = 0; nt < ((abl & 4) ? 0 : GD / 16); ++nt) {
         f32x4 au = {0.f, 0.f, 0.f, 0.f}, ak = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < GC / 16; ++kb) {
@@ -275,9 +281,11 @@ extern "C" int mi355_gated_delta_rule_chunked_fwd(int B, int S, int Hqk, int Hv,
     const int nchunk = (S + GC - 1) / GC;
     hipStream_t s = (hipStream_t)stream;
     const float scale = 1.0f / sqrtf((float)Dk);
+    static const int abl = getenv("MI355_GDR_ABL") ? atoi(getenv("MI355_GDR_ABL")) : 0;  // profiling only: 1 no inverse, 2 no K K^T / Q K^T, 4 no T V / T K, 8 no scan
     hipLaunchKernelGGL(gdr_chunk_prep_kernel, dim3((unsigned)nchunk, (unsigned)Hv, (unsigned)B), dim3(256), 0, s, B, S, Hqk, Hv, (const bf16_t*)q, (const bf16_t*)k,
-                       (const bf16_t*)v, ldv, beta, alpha, workspace, nchunk, scale);
-    if ((int64_t)B * Hv >= 256)
+                       (const bf16_t*)v, ldv, beta, alpha, workspace, nchunk, scale, abl);
+    if (abl & 8) {
+    } else if ((int64_t)B * Hv >= 256)
         hipLaunchKernelGGL(gdr_chunk_scan_kernel<1>, dim3((unsigned)Hv, (unsigned)B), dim3(256), 0, s, B, S, Hv, (const float*)workspace, nchunk, (bf16_t*)o, initial_state, final_state);
     else
         hipLaunchKernelGGL(gdr_chunk_scan_kernel<2>, dim3((unsigned)Hv * 2, (unsigned)B), dim3(256), 0, s, B, S, Hv, (const float*)workspace, nchunk, (bf16_t*)o, initial_state, final_state);
