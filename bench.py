@@ -273,7 +273,7 @@ def main():
 
     def step():
         loss = vlm_step_loss(vit, llm, ad, img, ids, mask, hf_vit_model=False, vit_hidden=vision())
-        sync.begin_step()
+        sync.begin_step(embedding_tokens=ids.numel())  # the tied head / embedding bucket: dense or in two parts, by bytes (ddp.GradSync.split_pays)
         (loss * sync.loss_weight(n_targets) if (args.ragged and world > 1) else loss).backward()
         sync.finish_step()
         llm.zero_grad(set_to_none=True)
@@ -315,7 +315,7 @@ def main():
 
         def full_step():
             loss_ = vlm_step_loss(vit, llm, ad, img, ids, mask, hf_vit_model=False, vit_hidden=vision())
-            sync.begin_step()
+            sync.begin_step(embedding_tokens=ids.numel())
             (loss_ * sync.loss_weight(n_targets) if (args.ragged and world > 1) else loss_).backward()
             sync.finish_step()
             opt.step()

@@ -335,15 +335,6 @@ int mi355_gated_delta_rule_bwd(int B, int S, int Hqk, int Hv, int Dk, int Dv, co
                                const float* beta, const float* alpha, const float* checkpoints, const void* d_o, void* dq, void* dk, void* dv,
                                int64_t lddv, float* dbeta, float* dalpha, void* workspace, int64_t workspace_bytes, void* stream);
 
-/* The same forward in the chunked (WY / UT-transform) form on fp32-input MFMA, head dims 128 x 128: no checkpoints, i.e. the no-grad / prefill path of
- * gated_delta_rule (qwen3_next_attention.py:103-159); operands and states as mi355_gated_delta_rule_fwd (initial_state / final_state optional, may be
- * the same buffer).  workspace: fp32, 16-byte aligned, mi355_gated_delta_rule_chunked_workspace_bytes(B, S, Hv) bytes (144 KB per 64-token chunk and head:
- * the chunk-parallel products the scan over chunks consumes).  Same results contract as the sequential kernel up to fp32 re-association. */
-int64_t mi355_gated_delta_rule_chunked_workspace_bytes(int B, int S, int Hv);
-int mi355_gated_delta_rule_chunked_fwd(int B, int S, int Hqk, int Hv, int Dk, int Dv, const void* q, const void* k, const void* v, int64_t ldv,
-                                       const float* beta, const float* alpha, void* o, const float* initial_state, float* final_state,
-                                       float* workspace, int64_t workspace_bytes, void* stream);
-
 /* out = bf16(silu(float(gate)) * RMSNorm_fp32(float(o)))  (post_norm + output gate, qwen3_5_text_model.py:181-187): o bf16
  * [tokens, H*D], w fp32 [D], gate bf16 at gate[t*ldg + h*D]. */
 int mi355_gated_rmsnorm_fwd(int64_t tokens, int H, int D, const void* o, const float* w, const void* gate, int64_t ldg, void* out, float* rstd,

@@ -78,7 +78,6 @@ SIGNATURES = {
     "mi355_l2norm_fwd": [_L, _I, _I, _P, _L, _P, _P],
     "mi355_l2norm_bwd": [_L, _I, _I, _P, _L, _P, _P, _L, _P],
     "mi355_gated_delta_rule_fwd": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P],
-    "mi355_gated_delta_rule_chunked_fwd": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _L, _P],
     "mi355_causal_conv_silu_step": [_I, _I, _I, _P, _L, _P, _P, _P, _P],
     "mi355_gated_delta_rule_bwd": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _P],
     "mi355_gated_rmsnorm_fwd": [_L, _I, _I, _P, _P, _P, _L, _P, _P, _F, _P],
@@ -104,7 +103,6 @@ QUERIES = {
     "mi355_gated_delta_rule_bwd_workspace_bytes": ([_I, _I, _I, _I, _I], _L),
     "mi355_attn_bwd_workspace_bytes": ([_I, _I, _I, _I], _L),
     "mi355_attn_bwd_qnorm_partials": ([_I, _I, _I], _L),
-    "mi355_gated_delta_rule_chunked_workspace_bytes": ([_I, _I, _I], _L),
     "mi355_embedding_bwd_sorted_workspace_bytes": ([_L, _I], _L),
 }
 
@@ -161,7 +159,7 @@ def ptr(t):
 
 import threading
 
-_tls = threading.local()  # .device: device of the tensors checked by this THREAD's last require_gpu() -- the launch that follows runs there
+_tls = threading.local()  # .device: device of the tensors checked by this THREAD's last require_gpu() -- the launches that follow run there
 # (autograd runs one thread per device: a module-level global would let one thread's require_gpu steer another thread's launch)
 
 
@@ -172,10 +170,11 @@ def stream(device=None):
 def call(name, *args):
     """Invoke an entry point on the current HIP stream OF THE DEVICE THE OPERANDS LIVE ON (``require_gpu`` recorded it); raise
     RuntimeError with the library's message on failure.  Without the guard a model on cuda:1 under a current device of cuda:0
-    would be enqueued on cuda:0's stream with cuda:1's pointers."""
+    would be enqueued on cuda:0's stream with cuda:1's pointers.  The recorded device stays in force until the thread's NEXT
+    ``require_gpu``: a wrapper that launches several kernels (a backward followed by its partial-sum reductions) checks its operands
+    once and every launch of it lands on their device."""
     lib = load()
     dev = getattr(_tls, "device", None)
-    _tls.device = None
     if dev is not None and dev.index is not None and dev.index != torch.cuda.current_device():
         with torch.cuda.device(dev):
             rc = getattr(lib, name)(*args, stream(dev))
@@ -186,7 +185,8 @@ def call(name, *args):
 
 
 def require_gpu(*tensors):
-    """Every operand must be a HIP tensor, and all of them on ONE device; remembers that device for the ``call`` that follows."""
+    """Every operand must be a HIP tensor, and all of them on ONE device; remembers that device for the ``call``s that follow (until the
+    thread's next ``require_gpu``; a call with no tensor operand at all clears it: the current device's stream is used)."""
     dev = None
     for t in tensors:
         if t is None:

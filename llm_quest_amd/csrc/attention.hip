@@ -216,9 +216,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int B, int S, int Hq, 
 //   * rows whose visible keys are ALL padding (reference semantics: uniform attention over all S keys) are known before the first tile -- under the
 //     causal mask they are the queries in front of the first real key of a left-padded batch row -- and get score 0 for every existing key; their
 //     batch rows walk every tile.
-// (An experiment with ONE wave per SIMD, both heads of a kv pair per wave and a hand-placed schedule -- csrc/attention_fwd2.hip -- is kept behind
-// ablation bit 13: its MFMAs hide completely, but a lone wave pays ~10 cycles for every dependent vector instruction and nothing covers its
-// per-block prologue / epilogue: 322 us against this kernel's time at the headline shape)
+// (An experiment with ONE wave per SIMD, both heads of a kv pair per wave and a hand-placed schedule lives outside the product library in
+// tools/experimental/attention_fwd2.hip: its MFMAs hide completely, but a lone wave pays ~10 cycles for every dependent vector instruction and
+// nothing covers its per-block prologue / epilogue: 322 us against this kernel's time at the headline shape)
 constexpr float LEAN_THR = 8.0f;
 constexpr unsigned LEAN_FILL = __builtin_bit_cast(unsigned, MASK_T);
 __device__ __forceinline__ float lean_max3(float m, float x, float y) {
@@ -1434,9 +1434,6 @@ extern "C" int mi355_debug_prof(unsigned long long* out, int reset) {
 }
 #endif
 
-int mi355_attn_fwd2_launch(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
-                           void* o, int64_t ldo, float* lse, const uint8_t* key_mask, int causal, float scale_log2, hipStream_t s);  // attention_fwd2.hip
-
 extern "C" int mi355_attn_fwd(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk,
                               const void* v, int64_t ldv, void* o, int64_t ldo, float* lse, const uint8_t* key_mask,
                               int causal, float scale, void* stream) {
@@ -1448,11 +1445,6 @@ extern "C" int mi355_attn_fwd(int B, int S, int Hq, int Hkv, int D, const void* 
     MI355_REQUIRE(grid < 0x7fffffffLL, "mi355_attn_fwd: grid too large");
     hipStream_t s = (hipStream_t)stream;
     const float sl2 = scale * LOG2E;
-    // ablation bit 13: the one-wave-per-SIMD experiment (attention_fwd2.hip; head_dim 128, an even number of query heads per kv head)
-    if (((causal >> 8) & 8192) && mi355_attn_fwd2_launch(B, S, Hq, Hkv, D, q, ldq, k, ldk, v, ldv, o, ldo, lse, key_mask, causal & 0xff, sl2, s) == 0) {
-        MI355_LAUNCH_CHECK("mi355_attn_fwd");
-        return 0;
-    }
     if (!((causal >> 8) & 2048)) {  // the lean-softmax kernel; ablation bit 11 keeps the first-generation one
         if (D == 128)
             hipLaunchKernelGGL(attn_fwd_lean_kernel<128>, dim3((unsigned)grid), dim3(256), 0, s, B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, key_mask, causal, sl2);

@@ -1,4 +1,4 @@
-// Shared device helpers of the attention kernels (attention.hip, attention_fwd2.hip): tile configuration, LDS images and their swizzles,
+// Shared device helpers of the attention kernels (attention.hip; tools/experimental/attention_fwd2.hip): tile configuration, LDS images and their swizzles,
 // LDS-DMA tile copies, fragment reads, and the statements that own registers of the accumulator file by name.  gfx950 only.
 #pragma once
 #include <type_traits>

@@ -20,11 +20,18 @@ mask).  For ragged masks multiply the loss by ``sync.loss_weight(n_target_tokens
 returns ``sum_r grad(sum-loss_r) / sum_r n_r`` -- the gradient of the global-batch mean.
 
 The tied embedding / LM-head matrix (311 MB, the largest bucket) receives the head's weight gradient FIRST in the backward and the embedding's
-scatter LAST, so as one bucket it could only be exchanged after the backward, fully exposed (~1.8 ms on xGMI).  It is split instead
-(``early_tail``): the dense part -- head gradient + final norm -- is all-reduced as soon as the last transformer block's backward has finished,
-under the 27 blocks still to come; the embedding's part is sparse (one row per token), so at the end the ranks all-gather their token ids and
-token-gradient rows (67 MB per rank at 64 x 512 tokens, direct xGMI links) and every rank runs the same deterministic segmented sum
+scatter LAST, so as one bucket it can only be exchanged after the backward, fully exposed (~1.8 ms on xGMI: a ring all-reduce moves
+2 (w - 1) / w x 311 MB per rank).  It CAN be split (``early_tail``): the dense part -- head gradient + final norm -- is all-reduced as soon as the
+last transformer block's backward has finished, under the 27 blocks still to come; the embedding's part is sparse (one row per token), so at the end
+the ranks all-gather their token ids and token-gradient rows and every rank runs the same deterministic segmented sum
 (``mi355_embedding_bwd_sorted``) over all ranks' tokens with scale 1 / world -- identical bits on every rank, nothing dense left to exchange.
+Whether that pays is a matter of BYTES, decided per step in ``begin_step(embedding_tokens=T)`` (``split_pays``): the exposed all-gather delivers
+(w - 1) x T x (row bytes + 8) to every rank against the dense ring's 2 (w - 1) / w x bucket bytes.  At 64 x 512 tokens and 8 ranks that is 0.47 GB
+against 0.54 GB (split); at the bench's 160 x 512 it is 1.18 GB against 0.54 GB, so the bucket stays whole and goes out in ``finish_step``; at 2 ranks
+and 160 x 512 it is 0.17 GB against 0.31 GB (split).  Without a token count (``begin_step()``) the bucket stays whole.  ``MI355_DDP_SPLIT_TIED`` =
+``on`` / ``off`` overrides the rule (A/B runs).  The all-gather needs equally many tokens on every rank: every step that passes a count checks that
+with one 16-byte all-reduce (MIN / MAX of T, on a control stream of its own) and raises on EVERY rank instead of hanging in ``all_gather_into_tensor``.
+All ranks must either pass a count or pass none.
 
 Gradient accumulation: wrap every micro-step but the last in ``with sync.no_sync():`` -- the hooks then leave the buckets
 alone (they keep accumulating locally) and ``finish_step`` is a no-op; the last micro-step exchanges the sums.
@@ -52,6 +59,13 @@ def init_from_env(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
+        # RCCL's collectives are kernels: each channel is one workgroup on one CU, taken from the compute stream's GEMMs (whose 256x256 tiles run one
+        # 8-wave workgroup per CU and size their grids for 256 free CUs: DESIGN.md section 6).  MI355_RCCL_CHANNELS caps / pins that number for A/B
+        # runs on an 8-GPU node (it sets NCCL_MIN_NCHANNELS / NCCL_MAX_NCHANNELS, which RCCL reads at communicator creation); unset = RCCL's own choice.
+        ch = os.environ.get("MI355_RCCL_CHANNELS")
+        if ch:
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", ch)
+            os.environ.setdefault("NCCL_MIN_NCHANNELS", ch)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -90,6 +104,8 @@ class GradSync:
         # (trigger owner, arena): the arena is complete -- except for sparse embedding rows that travel separately -- once the trigger's backward ran
         self.early_tail = early_tail
         self._events = {}
+        self._split_now = False       # this step exchanges the early_tail arena in two parts (decided in begin_step)
+        self._ctl_stream = None       # the per-step token-count check runs here (begin_step)
 
     # ---------------------------------------------------------------- loss weighting / accumulation
     def loss_weight(self, n_tokens):
@@ -153,7 +169,7 @@ class GradSync:
     def _on_ready(self, module):
         if not self.enabled or not self._sync_on:
             return
-        if self.early_tail is not None and module is self.early_tail[0]:
+        if self._split_now and module is self.early_tail[0]:
             top = self.early_tail[1]
             if id(top) not in self._done and top.trainable():
                 self._done.add(id(top))
@@ -170,12 +186,51 @@ class GradSync:
     def splits(self, arena):
         """True while this step exchanges ``arena`` in two parts: its dense part has been (or is being) all-reduced, embedding rows go through
         ``gather_embedding``."""
-        return self.enabled and self._sync_on and self.early_tail is not None and arena is self.early_tail[1] and id(arena) in self._done
+        return self.enabled and self._sync_on and self._split_now and arena is self.early_tail[1] and id(arena) in self._done
+
+    def split_pays(self, tokens, row_bytes=None):
+        """The byte rule: exchange the tied bucket in two parts iff the exposed all-gather of the token rows delivers fewer bytes to a rank
+        than the dense ring all-reduce of the whole bucket would move."""
+        if self.early_tail is None or not self.enabled:
+            return False
+        forced = os.environ.get("MI355_DDP_SPLIT_TIED", "auto")
+        if forced in ("on", "off"):
+            return forced == "on"
+        top = self.early_tail[1]
+        if row_bytes is None:
+            table = next(p for p in top.params if p.dim() == 2)  # the embedding / head matrix [V, d]
+            row_bytes = table.shape[1] * table.element_size()
+        bucket_bytes = top.grad.numel() * top.grad.element_size() if top.grad is not None else sum(p.numel() * p.element_size() for p in top.params)
+        w = self.world
+        sparse = (w - 1) * int(tokens) * (row_bytes + 8)
+        dense = 2.0 * (w - 1) / w * bucket_bytes
+        return sparse < dense
+
+    def _check_equal_tokens(self, tokens):
+        """all_gather_into_tensor needs the same count on every rank.  One 16-byte MAX all-reduce of (T, -T), EVERY step that passes a token
+        count (whatever this rank's byte rule says: the check itself must be collective), on a control stream of its own so that the host only
+        waits for this one small collective, not for the compute stream (~0.1 ms against a step of hundreds)."""
+        if self.backend == "nccl":
+            dev = self._device()
+            if self._ctl_stream is None:
+                self._ctl_stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(self._ctl_stream):
+                t = torch.tensor([int(tokens), -int(tokens)], dtype=torch.int64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                hi, lo = t.tolist()
+        else:
+            t = torch.tensor([int(tokens), -int(tokens)], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            hi, lo = t.tolist()
+        if hi != -lo:
+            raise RuntimeError(f"GradSync: ranks hold different embedding token counts ({-lo}..{hi}); the split tied-weight exchange all-gathers "
+                               "equal shards -- pad the batches alike or call begin_step() without embedding_tokens (dense exchange)")
 
     def gather_embedding(self, ids, rows):
         """Every rank's token ids [T] and token-gradient rows [T, width], concatenated in rank order, and the factor 1 / world: what the
         deterministic embedding backward sums on every rank alike.  The dense all-reduce of the split bucket runs on the communication stream;
-        the rows are added to that bucket afterwards, so the current stream waits for it here.  All ranks must hold equally many tokens."""
+        the rows are added to that bucket afterwards, so the current stream waits for it here.  All ranks hold equally many tokens
+        (``begin_step`` checked it)."""
         flat = ids.reshape(-1).contiguous()
         rows = rows.contiguous()
         ids_all = torch.empty(self.world * flat.numel(), dtype=flat.dtype, device=flat.device)
@@ -187,9 +242,15 @@ class GradSync:
         return ids_all, rows_all, 1.0 / self.world
 
     # ---------------------------------------------------------------- step protocol
-    def begin_step(self):
+    def begin_step(self, embedding_tokens=None, embedding_row_bytes=None):
+        """``embedding_tokens``: this rank's token count of the tied embedding's backward (``ids.numel()``); given it, the tied bucket is
+        exchanged in two parts when ``split_pays`` says so.  Every rank must pass the same value (checked on first use)."""
         global _ACTIVE
         self._done.clear()
+        self._split_now = False
+        if embedding_tokens is not None and self.enabled and self._sync_on and self.early_tail is not None:
+            self._check_equal_tokens(int(embedding_tokens))  # collective: every rank that passes a count takes part, whatever it then decides
+            self._split_now = self.split_pays(embedding_tokens, embedding_row_bytes)
         _ACTIVE = self
 
     def finish_step(self):

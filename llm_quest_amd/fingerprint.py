@@ -1,17 +1,32 @@
-"""Fingerprint of the kernel sources the headline step runs (csrc/*.hip that the step launches, their shared headers, csrc/Makefile).
+"""Fingerprint of the kernel sources the headline step runs: the csrc/*.hip files the step launches, their shared headers, and the compile
+flags those files are built with (the ``CXXFLAGS`` / ``FLAGS_<file>`` lines of csrc/Makefile -- NOT the Makefile as a whole: adding an
+unrelated source to ``SRCS`` must not invalidate the counters of kernels that did not change, which is what cost round 3 its ``traffic``).
 
 Counter files under ``profiles/`` are taken in separate ``rocprofv3 --pmc`` passes and committed; each carries the fingerprint of the
 sources it was measured on, written ON THE GPU BOX AT COLLECTION TIME (``tools/collect_evidence.sh`` -> ``stamp.json`` beside the raw
 counters, with the sha-256 of the library that was loaded); the aggregators copy that stamp, they never recompute it.  ``bench.py`` prints a
 counter-derived figure only when the stamp equals the fingerprint of the sources it runs, so a kernel edit can never leave a stale
-``traffic`` in the bench line."""
+``traffic`` in the bench line; ``tests/test_zz_evidence_cpu.py`` fails while the committed stamp of ``EVIDENCE_ROUND`` is stale at HEAD."""
 
 import hashlib
 import json
 import os
+import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-FILES = ("attention.hip", "attention_fwd2.hip", "attn_common.h", "elementwise.hip", "gemm.hip", "norm_rope.hip", "common.h", "Makefile")
+EVIDENCE_ROUND = "r04"  # profiles/<EVIDENCE_ROUND>_* are the counter files bench.py reads
+FILES = ("attention.hip", "attn_common.h", "elementwise.hip", "gemm.hip", "norm_rope.hip", "common.h")
+_FLAG_LINES = re.compile(r"^(CXXFLAGS|ARCH|FLAGS_(?:attention|elementwise|gemm|norm_rope))\s*\??=")
+
+
+def compile_flags():
+    """The Makefile lines that decide how FILES are compiled, in file order (variable name included, whitespace normalised)."""
+    out = []
+    with open(os.path.join(_HERE, "csrc", "Makefile")) as fh:
+        for line in fh:
+            if _FLAG_LINES.match(line):
+                out.append(" ".join(line.split()))
+    return "\n".join(out)
 
 
 def kernel_sources_sha():
@@ -20,6 +35,7 @@ def kernel_sources_sha():
         h.update(n.encode())
         with open(os.path.join(_HERE, "csrc", n), "rb") as fh:
             h.update(fh.read())
+    h.update(compile_flags().encode())
     return h.hexdigest()[:16]
 
 

@@ -443,6 +443,7 @@ def cross_entropy(logits2d, targets, want_grad, grad_scale=None, inplace=True):
 
 
 def ce_finalize(loss_rows, targets):
+    L.require_gpu(loss_rows, targets)
     out3 = torch.empty(3, dtype=F32, device=loss_rows.device)
     L.call("mi355_ce_finalize", loss_rows.numel(), L.ptr(loss_rows), L.ptr(targets), L.ptr(out3))
     return out3

@@ -5,7 +5,6 @@ are allocated with torch (device memory plumbing only), kernels are enqueued on 
 fused projection are passed as 2-D views (unit inner stride, row pitch = the projection's width).
 """
 
-import os
 
 import torch
 
@@ -26,6 +25,7 @@ def _reduce_parts(part, out=None, accumulate=False):
     if out is None:
         out = torch.empty(n, dtype=F32, device=part.device)
         accumulate = False
+    L.require_gpu(part, out)
     L.call("mi355_reduce_rows_f32", parts, n, L.ptr(part), L.ptr(out), L.dt_code(out.dtype), int(accumulate))
     return out
 
@@ -283,33 +283,6 @@ def gated_delta_rule_fwd(q, k, v, beta, alpha, B, S, Hqk, Hv, Dk, Dv, keep=True,
         fin = torch.empty((B, Hv, Dv, Dk), dtype=F32, device=q.device) if want_state else None
     L.call("mi355_gated_delta_rule_fwd", B, S, Hqk, Hv, Dk, Dv, L.ptr(q), L.ptr(k), L.ptr(v), v.stride(0), L.ptr(beta), L.ptr(alpha), L.ptr(o), L.ptr(ck), L.ptr(state), L.ptr(fin))
     return o, ck, fin
-
-
-GDR_CHUNKED_MIN_S = int(os.environ.get("MI355_GDR_CHUNKED_MIN_S", "0"))  # the no-grad forward takes the chunked MFMA form from this length on; 0 (default) = never: measured 409 us against the sequential 363 at B = 8, S = 708
-
-
-def gated_delta_rule_chunked_applies(S, Dk, Dv):
-    return GDR_CHUNKED_MIN_S > 0 and S >= GDR_CHUNKED_MIN_S and Dk == 128 and Dv == 128
-
-
-def gated_delta_rule_chunked_fwd(q, k, v, beta, alpha, B, S, Hqk, Hv, Dk, Dv, want_state=False, state=None):
-    """The forward without checkpoints in the chunked (WY / UT-transform) form on fp32-input MFMA (csrc/gdr_chunk.hip): inference / prefill.
-    Returns (o bf16 [B*S, Hv*Dv], final_state or None); ``state`` fp32 [B, Hv, Dv, Dk] is the carried-in state, updated IN PLACE."""
-    L.require_gpu(q, k, v, beta, alpha)
-    _check_gdr(q, k, v, beta, alpha, B, S, Hqk, Hv, Dk, Dv)
-    o = torch.empty((B * S, Hv * Dv), dtype=BF16, device=q.device)
-    if state is not None:
-        L.require_gpu(state)
-        if not (state.dtype == F32 and state.is_contiguous() and tuple(state.shape) == (B, Hv, Dv, Dk)):
-            raise ValueError("gated_delta_rule_chunked_fwd: state must be contiguous fp32 [B, Hv, Dv, Dk]")
-        fin = state
-    else:
-        fin = torch.empty((B, Hv, Dv, Dk), dtype=F32, device=q.device) if want_state else None
-    need = L.load().mi355_gated_delta_rule_chunked_workspace_bytes(B, S, Hv)
-    ws = torch.empty((need + 3) // 4, dtype=F32, device=q.device)
-    L.call("mi355_gated_delta_rule_chunked_fwd", B, S, Hqk, Hv, Dk, Dv, L.ptr(q), L.ptr(k), L.ptr(v), v.stride(0), L.ptr(beta), L.ptr(alpha), L.ptr(o), L.ptr(state), L.ptr(fin),
-           L.ptr(ws), need)
-    return o, fin
 
 
 def gated_delta_rule_bwd(q, k, v, beta, alpha, ck, do, dv, B, S, Hqk, Hv, Dk, Dv):

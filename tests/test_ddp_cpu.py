@@ -210,10 +210,10 @@ def _split_worker(rank, world, port, out):
     ids = torch.randint(0, V, (T,), generator=g)        # this rank's tokens (ids repeat across and inside ranks)
     rows = torch.randn(T, W, generator=g)
 
-    def step(exchange):
+    def step(exchange, tokens=T):
         for p in list(top.parameters()) + [q for m in owners for q in m.parameters()]:
             p.grad = None
-        sync.begin_step()
+        sync.begin_step(embedding_tokens=tokens)
         ar = arena_for(top)
         ar.grad_target(top.emb)[0].copy_(head_grad)     # first gradient of the backward
         ar.grad_target(top.norm)[0].copy_(norm_grad)
@@ -248,6 +248,18 @@ def _split_worker(rank, world, port, out):
     ok = bool(torch.allclose(emb, want_emb, atol=1e-6)) and bool(torch.allclose(norm, want_norm, atol=1e-6))
     ok &= bool(torch.allclose(blk, torch.full_like(blk, sum(range(1, world + 1)) / world)))
     ok &= ddp.active() is None
+    # the byte rule (ddp.GradSync.split_pays): the 224-byte bucket costs a 2-rank ring 224 bytes per rank, T = 6 rows of 16 + 8 bytes cost the
+    # all-gather 144 -> split (above); 10 T rows would cost 1 440 -> the bucket stays whole and goes out dense in finish_step; no count -> whole
+    ok &= sync.split_pays(T) and not sync.split_pays(10 * T)
+    for hint in (10 * T, None):
+        emb_d, norm_d, _ = step(False, tokens=hint)
+        ok &= bool(torch.allclose(emb_d, want_emb, atol=1e-6)) and bool(torch.allclose(norm_d, want_norm, atol=1e-6))
+    # unequal token counts across ranks are refused before any all-gather can hang
+    try:
+        sync.begin_step(embedding_tokens=T + rank)
+        ok &= world == 1
+    except RuntimeError as exc:
+        ok &= "different embedding token counts" in str(exc)
     # accumulation window: nothing is exchanged, the bucket keeps this rank's own sums
     with sync.no_sync():
         emb_l, _, _ = step(False)

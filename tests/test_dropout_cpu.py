@@ -27,25 +27,30 @@ def test_multipliers_are_reproducible_and_shaped():
     assert OD.threshold(0.0) == 0 and OD.threshold(0.5) == 1 << 31
 
 
-def test_dropout_stream_follows_torch_generator_state():
-    """``nn.Dropout`` restarts its masks when the SAME seed is set again and resumes them from ``set_rng_state``; the (seed, offset) pairs
-    of the HIP dropout sites must do the same (llm_quest_amd/rng.py)."""
+def test_dropout_stream_leaves_the_cpu_generator_alone_and_follows_the_seed():
+    """``nn.Dropout`` on a device tensor consumes the DEVICE generator, never torch's default CPU generator; the (seed, offset) pairs of the
+    HIP dropout sites must do the same (llm_quest_amd/rng.py).  Without a device the offsets come from the module's own generator: a new
+    ``torch.manual_seed`` restarts the stream, ``get_state`` / ``set_state`` resume it.  (On the GPU the pairs follow the device generator,
+    including the same-seed restart: tests/test_dropout_gpu.py.)"""
     import torch
 
     from llm_quest_amd import rng
 
     rng.follow_torch()
     torch.manual_seed(1234)
+    before = torch.get_rng_state().clone()
     a = [rng.draw() for _ in range(4)]
-    torch.manual_seed(1234)
-    b = [rng.draw() for _ in range(4)]
-    assert a == b and len({o for _, o in a}) == 4 and all(s == 1234 for s, _ in a)
-    state = torch.get_rng_state()
+    assert torch.equal(before, torch.get_rng_state())  # shuffles / torch.rand after a dropout-on run see the generator a dropout-off run sees
+    assert len({o for _, o in a}) == 4 and all(s == 1234 for s, _ in a)
+    state = rng.get_state()
     c = [rng.draw() for _ in range(2)]
-    torch.set_rng_state(state)
+    rng.set_state(state)
     assert [rng.draw() for _ in range(2)] == c
     torch.manual_seed(1235)
-    assert rng.draw() != a[0]
+    b = rng.draw()
+    assert b[0] == 1235 and b != a[0]
+    torch.manual_seed(1234)
+    assert [rng.draw() for _ in range(4)] == a  # a new seed re-seeds the stream: back to 1234 restarts it
     rng.manual(7, 5)
     assert [rng.draw(), rng.draw()] == [(7, 5), (7, 6)]
     rng.follow_torch()

@@ -203,3 +203,31 @@ def test_adapter_dropout_given_the_mask():
     yr.backward(g.float().cpu())
     assert rel_l2(y, yr) < 1e-2 and rel_l2(x.grad, xr.grad) < 2e-2
     assert float((ad.eval()(x.detach()) - y).abs().max()) > 0  # eval: no dropout
+
+
+def test_dropout_stream_follows_the_device_generator_and_leaves_the_cpu_generator_alone():
+    """On the GPU the (seed, offset) pairs come from the current device's default generator, as a device ``nn.Dropout`` takes them: the SAME
+    seed set again restarts the masks, ``torch.cuda.get_rng_state`` / ``set_rng_state`` resume them, torch's CPU generator is never consumed
+    (llm_quest_amd/rng.py; reference sites vit_model.py:146, vit_attention.py:79)."""
+    from llm_quest_amd import kernels as K
+    from llm_quest_amd import rng
+
+    torch.cuda.init()
+    rng.follow_torch()
+    torch.manual_seed(1234)
+    cpu_before = torch.get_rng_state().clone()
+    a = [rng.draw() for _ in range(4)]
+    assert torch.equal(cpu_before, torch.get_rng_state())
+    assert all(s == 1234 for s, _ in a) and len({o for _, o in a}) == 4
+    torch.manual_seed(1234)
+    assert [rng.draw() for _ in range(4)] == a
+    st = torch.cuda.get_rng_state()
+    c = [rng.draw() for _ in range(2)]
+    torch.cuda.set_rng_state(st)
+    assert [rng.draw() for _ in range(2)] == c
+    x = torch.ones(1 << 16, device="cuda", dtype=BF16)
+    torch.manual_seed(99)
+    y1 = K.dropout(x, 0.5, *rng.draw())
+    y2 = K.dropout(x, 0.5, *rng.draw())
+    torch.manual_seed(99)
+    assert torch.equal(K.dropout(x, 0.5, *rng.draw()), y1) and not torch.equal(y1, y2)

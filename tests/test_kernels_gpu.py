@@ -594,9 +594,9 @@ def test_attention_fully_masked_rows_follow_reference(K):
     assert rel_l2(o, o_ref) < 4e-3
 
 
-# ---- the lean-softmax forward (csrc/attention.hip, the default) and the one-wave-per-SIMD experiment (csrc/attention_fwd2.hip, ablation bit 13)
+# ---- the lean-softmax forward (csrc/attention.hip, the default) against fp64 and against the first-generation kernel
 def _forward_kernel(K, bit):
-    """Context manager: ablation bit 11 (2048) keeps the first-generation forward kernel, bit 13 (8192) selects the one-wave-per-SIMD experiment."""
+    """Context manager: ablation bit 11 (2048) keeps the first-generation forward kernel (0 = the default lean kernel)."""
     import contextlib
 
     @contextlib.contextmanager
@@ -630,7 +630,7 @@ FWD2_CASES = [
 ]
 
 
-@pytest.mark.parametrize("kernel", ["lean", "one_wave"])
+@pytest.mark.parametrize("kernel", ["lean"])
 @pytest.mark.parametrize("B,S,Hq,Hkv,causal,mask", FWD2_CASES)
 def test_attention_forward_second_generation_matches_fp64(K, B, S, Hq, Hkv, causal, mask, kernel):
     """Output and log-sum-exp against fp64 softmax with the reference's finite mask fill (qwen3_attention.py:130-142), over shapes that walk
@@ -654,7 +654,7 @@ def test_attention_forward_second_generation_matches_fp64(K, B, S, Hq, Hkv, caus
     big = B * Hq * S * S > 3e7  # keep the fp64 reference on the device when the score tensor is large
     rd = (lambda t: t.cuda()) if big else (lambda t: t)
     o_ref, p_ref = _attn_ref(rd(q), rd(k), rd(v), B, S, Hq, Hkv, D, None if km is None else rd(km), causal)
-    with _forward_kernel(K, 8192 if kernel == "one_wave" else 0):
+    with _forward_kernel(K, 0):
         o, lse = K.attn_fwd(dev(q), dev(k), dev(v), B, S, Hq, Hkv, D, key_mask=None if km is None else dev(km), causal=causal)
     assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
     assert rel_l2(o, o_ref) < 4e-3, rel_l2(o, o_ref)
@@ -677,7 +677,7 @@ def test_attention_forward_second_generation_matches_fp64(K, B, S, Hq, Hkv, caus
     assert rel_l2(o, o1) < 5e-3 and float((lse - lse1)[live.to(lse.device)].abs().max()) < 6e-3
 
 
-@pytest.mark.parametrize("kernel", ["lean", "one_wave"])
+@pytest.mark.parametrize("kernel", ["lean"])
 def test_attention_forward_lazy_rescale_branch_is_exercised(K, kernel):
     """The forward rescales O only when a row maximum outgrows its running reference by 2^8 -- a rare, data-dependent branch
     that bounded random data never takes.  Keys aligned with chosen queries make the maximum jump by ~30 log2 units at chosen tiles (first
@@ -692,7 +692,7 @@ def test_attention_forward_lazy_rescale_branch_is_exercised(K, kernel):
         k4[b, key, hq // 2] = (2.0 * q4[b, row, hq].float()).to(BF16)
     o_ref, p_ref = _attn_ref(q, k, v, B, S, Hq, Hkv, D, None, True)
     assert float(p_ref.view(B, Hq, S, S)[0, 0, 600, 400]) > 0.99  # the spike really dominates its row
-    with _forward_kernel(K, 8192 if kernel == "one_wave" else 0):
+    with _forward_kernel(K, 0):
         o, lse = K.attn_fwd(dev(q), dev(k), dev(v), B, S, Hq, Hkv, D, causal=True)
     assert rel_l2(o, o_ref) < 4e-3
     err = (o.float().cpu() - o_ref.float()).view(B, S, Hq * D).norm(dim=-1) / o_ref.float().view(B, S, Hq * D).norm(dim=-1)

@@ -456,40 +456,6 @@ def test_real_width_blocks_vs_oracle(kind):
         assert err <= 3e-2 * float(tg.double().norm()) + 1e-4, f"{name}: |err| {err:.3e} |ref| {float(tg.norm()):.3e}"
 
 
-@pytest.mark.parametrize("s", [708, 130, 65, 64, 17])
-def test_gated_delta_rule_chunked_forward_matches_the_oracle_and_the_sequential_kernel(s):
-    """csrc/gdr_chunk.hip (the WY / UT-transform forward on fp32-input MFMA, head dims 128 x 128; experimental, off by default) against the oracle's
-    sequential recurrence (fp32 torch, reference qwen3_next_attention.py:103-159) and against the sequential HIP kernel: chunk counts 12, 3 (ragged last
-    chunk), 2 (one row in the last chunk), 1, and a single short chunk; value heads sharing q/k heads in pairs; a carried-in state (in place) equals the
-    one-piece run."""
-    from llm_quest_amd import kernels_q35 as Q
-
-    torch.manual_seed(80 + s)
-    b, hqk, hv, dk, dv = 2, 2, 4, 128, 128
-    q = OT.l2_norm(torch.randn(b, hqk, s, dk)).to(BF16)
-    k = OT.l2_norm(torch.randn(b, hqk, s, dk)).to(BF16)
-    v = torch.randn(b, hv, s, dv).to(BF16)
-    beta = torch.rand(b, hv, s)
-    alpha = 0.3 + 0.7 * torch.rand(b, hv, s)
-    ro, rstate = OT.gated_delta_rule(q.float().repeat_interleave(2, 1), k.float().repeat_interleave(2, 1), v.float(), beta, alpha)
-    tm = lambda t: t.permute(0, 2, 1, 3).reshape(b * s, -1).contiguous().cuda()
-    q2, k2, v2 = tm(q), tm(k), tm(v)
-    be, al = beta.permute(0, 2, 1).reshape(b * s, hv).contiguous().cuda(), alpha.permute(0, 2, 1).reshape(b * s, hv).contiguous().cuda()
-    o, fin = Q.gated_delta_rule_chunked_fwd(q2, k2, v2, be, al, b, s, hqk, hv, dk, dv, want_state=True)
-    o4 = o.view(b, s, hv, dv).permute(0, 2, 1, 3)
-    assert rel_l2(o4, ro) < 4e-3 and rel_l2(fin, rstate) < 1e-5, (rel_l2(o4, ro), rel_l2(fin, rstate))
-    o_seq, _, fin_seq = Q.gated_delta_rule_fwd(q2, k2, v2, be, al, b, s, hqk, hv, dk, dv, keep=False, want_state=True)
-    assert rel_l2(o, o_seq) < 2e-4 and rel_l2(fin, fin_seq) < 2e-6, (rel_l2(o, o_seq), rel_l2(fin, fin_seq))
-    if s >= 65:  # two pieces, the second from the first piece's state (updated in place), against one piece
-        cut = 64 if s > 64 else 32
-        cutrows = lambda t, lo, hi: t.view(b, s, -1)[:, lo:hi].reshape(b * (hi - lo), -1).contiguous()
-        o_a, st = Q.gated_delta_rule_chunked_fwd(cutrows(q2, 0, cut), cutrows(k2, 0, cut), cutrows(v2, 0, cut), cutrows(be, 0, cut), cutrows(al, 0, cut), b, cut, hqk, hv, dk, dv, want_state=True)
-        o_b, st2 = Q.gated_delta_rule_chunked_fwd(cutrows(q2, cut, s), cutrows(k2, cut, s), cutrows(v2, cut, s), cutrows(be, cut, s), cutrows(al, cut, s), b, s - cut, hqk, hv, dk, dv, state=st)
-        assert st2 is st and rel_l2(st, fin) < 2e-6
-        both = torch.cat((o_a.view(b, cut, -1), o_b.view(b, s - cut, -1)), 1).reshape(b * s, -1)
-        assert rel_l2(both, o) < 2e-4
-
-
 def test_functional_gated_delta_rule_has_the_reference_signature(golden):
     from llm_quest_amd.qwen.qwen3_next.qwen3_next_attention import gated_delta_rule
 

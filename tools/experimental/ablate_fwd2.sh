@@ -4,8 +4,8 @@
 set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 for abl in "$@"; do
-  touch $R/llm_quest_amd/csrc/attention_fwd2.hip
-  make -C $R/llm_quest_amd/csrc -j8 FLAGS_attention_fwd2="-fno-slp-vectorize -DF2_ABL=$abl" > /tmp/make_f2_$abl.log 2>&1 || { tail -5 /tmp/make_f2_$abl.log; exit 1; }
+  touch $R/tools/experimental/attention_fwd2.hip
+  make -C $R/tools/experimental FLAGS_attention_fwd2="-DF2_ABL=$abl" > /tmp/make_f2_$abl.log 2>&1 || { tail -5 /tmp/make_f2_$abl.log; exit 1; }
   echo "== F2_ABL=$abl"
-  timeout -k 10 120 python3 $R/tools/time_attn_fwd2.py | tail -3
+  timeout -k 10 120 python3 $R/tools/experimental/time_attn_fwd2.py | tail -3
 done

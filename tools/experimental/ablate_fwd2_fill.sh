@@ -5,8 +5,8 @@ set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 for pair in "$@"; do
   set -- $pair
-  touch $R/llm_quest_amd/csrc/attention_fwd2.hip
-  make -C $R/llm_quest_amd/csrc -j8 FLAGS_attention_fwd2="-fno-slp-vectorize -DF2_ABL=${3:-1} -DF2_FILL_PLAIN=$1 -DF2_FILL_EXP=$2" > /tmp/make_f2.log 2>&1 || { tail -5 /tmp/make_f2.log; exit 1; }
+  touch $R/tools/experimental/attention_fwd2.hip
+  make -C $R/tools/experimental FLAGS_attention_fwd2="-DF2_ABL=${3:-1} -DF2_FILL_PLAIN=$1 -DF2_FILL_EXP=$2" > /tmp/make_f2.log 2>&1 || { tail -5 /tmp/make_f2.log; exit 1; }
   echo "== plain $1 exp $2 abl ${3:-1}"
-  timeout -k 10 120 python3 $R/tools/time_attn_fwd2.py | sed -n 4p
+  timeout -k 10 120 python3 $R/tools/experimental/time_attn_fwd2.py | sed -n 4p
 done

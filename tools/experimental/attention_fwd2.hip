@@ -638,3 +638,11 @@ int mi355_attn_fwd2_launch(int B, int S, int Hq, int Hkv, int D, const void* q, 
                        (bf16_t*)o, ldo, lse, key_mask, causal, scale_log2, bpw, (int)nitems);
     return 0;
 }
+
+// C entry of the experiment (tools/experimental/exp.py): arguments of mi355_attn_fwd; -1 = not this kernel's shape
+extern "C" int mi355_exp_attn_fwd2(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                                   void* o, int64_t ldo, float* lse, const uint8_t* key_mask, int causal, float scale, void* stream) {
+    const int rc = mi355_attn_fwd2_launch(B, S, Hq, Hkv, D, q, ldq, k, ldk, v, ldv, o, ldo, lse, key_mask, causal, scale * LOG2E, (hipStream_t)stream);
+    if (rc == 0) MI355_LAUNCH_CHECK("mi355_exp_attn_fwd2");
+    return rc;
+}

@@ -2,7 +2,7 @@
     make -C llm_quest_amd/csrc FLAGS_attention_fwd2="-fno-slp-vectorize -DATTN_ABL=16" && python tools/attn_prof_fwd2.py
 Shares, not lengths: the stamps forbid overlaps the real kernel has."""
 import sys, os, ctypes
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from llm_quest_amd import kernels as K, _lib as L
 B, S, Hq, Hkv, D = 64, 709, 16, 8, 128

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void gdr_chunk_prep_kernel(int B, int S, int H
 // NSPLIT workgroups per (batch row, head) split the Dv columns (state rows are independent); a wave owns NTW 16-column tiles of them.
 template <int NSPLIT>
 __global__ __launch_bounds__(256) void gdr_chunk_scan_kernel(int B, int S, int Hv, const float* __restrict__ ws, int nchunk, bf16_t* __restrict__ o,
-                                                             const float* __restrict__ initial_state, float* __restrict__ final_state) {
+                                                             const float* initial_state, float* final_state) {  // the two may alias (state updated in place): no __restrict__
     constexpr int NTW = (GD / 16) / (4 * NSPLIT);
     __shared__ __attribute__((aligned(16))) float As[GC * LDW];   // nKw
     __shared__ __attribute__((aligned(16))) float Bs[GC * LDW];   // Q'
@@ -281,7 +281,10 @@ extern "C" int mi355_gated_delta_rule_chunked_fwd(int B, int S, int Hqk, int Hv,
     const int nchunk = (S + GC - 1) / GC;
     hipStream_t s = (hipStream_t)stream;
     const float scale = 1.0f / sqrtf((float)Dk);
-    static const int abl = getenv("MI355_GDR_ABL") ? atoi(getenv("MI355_GDR_ABL")) : 0;  // profiling only: 1 no inverse, 2 no K K^T / Q K^T, 4 no T V / T K, 8 no scan
+#ifndef GDR_ABL
+#define GDR_ABL 0  // profiling builds only (make FLAGS_gdr_chunk=-DGDR_ABL=n): 1 no inverse, 2 no K K^T / Q K^T, 4 no T V / T K, 8 no scan (outputs then unwritten)
+#endif
+    constexpr int abl = GDR_ABL;
     hipLaunchKernelGGL(gdr_chunk_prep_kernel, dim3((unsigned)nchunk, (unsigned)Hv, (unsigned)B), dim3(256), 0, s, B, S, Hqk, Hv, (const bf16_t*)q, (const bf16_t*)k,
                        (const bf16_t*)v, ldv, beta, alpha, workspace, nchunk, scale, abl);
     if (abl & 8) {
