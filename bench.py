@@ -155,13 +155,17 @@ def _profile_json(name):
 def pmc_traffic():
     """TCC counters of the dominant kernel, collected with rocprofv3 --pmc in separate passes and committed (PMC cannot be read
     from inside the timed process)."""
-    d, why = _profile_json("r03_pmc_tcc_gemm.json")
+    from llm_quest_amd.fingerprint import EVIDENCE_ROUND
+
+    d, why = _profile_json(f"{EVIDENCE_ROUND}_pmc_tcc_gemm.json")
     return (d["kernels"] if d else None), why
 
 
 def pmc_step_traffic():
-    """Whole-step TCC counters (profiles/r03_pmc_tcc_step.json), collected with rocprofv3 --pmc over this script."""
-    return _profile_json("r03_pmc_tcc_step.json")
+    """Whole-step TCC counters (profiles/<round>_pmc_tcc_step.json), collected with rocprofv3 --pmc over this script."""
+    from llm_quest_amd.fingerprint import EVIDENCE_ROUND
+
+    return _profile_json(f"{EVIDENCE_ROUND}_pmc_tcc_step.json")
 
 
 def dominant_kernel_rate(batch, device):
@@ -378,7 +382,7 @@ def main():
                 line["roofline"]["traffic"] = step_pmc["per_step"]["total_bytes"]
                 line["roofline"]["traffic_note"] = (
                     "memory-side bytes PER STEP (like `achieved`): 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE summed over every kernel of one step, separate "
-                    "rocprofv3 --pmc passes over this bench (profiles/r03_pmc_tcc_step.json, per-kernel table inside; fingerprint of the kernel sources checked); "
+                    "rocprofv3 --pmc passes over this bench (profiles/<round>_pmc_tcc_step.json, per-kernel table inside; fingerprint of the kernel sources checked); "
                     "Infinity-Cache hits are counted in FETCH_SIZE")
             if pmc is not None and pmc_batch == args.batch:
                 line["roofline"]["dominant_kernel"]["pmc_bytes_per_launch"] = {f: pmc[f]["hbm_bytes"] for f in pmc}

@@ -446,6 +446,52 @@ def gen_qwen35_text(out):
     _save(os.path.join(out, "qwen35_text_tiny.safetensors"), t, "Qwen3.5 text stack (tiny hybrid GDN / gated attention) + per-op vectors")
 
 
+def gen_qwen35_vlm(out):
+    """BASELINE config 5 at the wrapper level: the reference's ``Qwen3_5VLM.forward``
+    (qwen3_5_vlm_model.py:178-227) on a tiny model -- fp32 vision tower, bf16 hybrid text stack, two samples with 8 image placeholders each
+    (2 frame pairs x 2x2 merged rows), a padding mask -- logits and EVERY parameter gradient; plus the same step with the text stack in fp32
+    (the bf16 model's weights upcast: a true weight twin, the floor of the 1.5x rule)."""
+    from llm_quest.qwen.qwen3_5.qwen3_5_vlm_model import Qwen3_5VLM
+
+    t = {}
+    cfg = {**TINY_Q35_TEXT, **TINY_Q35_VISION, "llm_d_in": TINY_Q35_TEXT["emb_dim"], "image_token_id": 250}
+    torch.manual_seed(SEED + 17)
+    ids = torch.randint(0, 250, (2, 24))
+    ids[0, 5:13] = 250
+    ids[1, 9:17] = 250
+    pix = torch.randn(2, 3, 4, 32, 32)
+    am = torch.ones(2, 24, dtype=torch.bool)
+    am[1, 21:] = False
+    t["in.ids"], t["in.pixels"], t["in.attn_mask"] = ids, pix, am.to(torch.uint8)
+    torch.manual_seed(SEED + 19)
+    vlm = Qwen3_5VLM({**cfg, "dtype": torch.bfloat16}).train()
+    with torch.no_grad():
+        for n_, p_ in vlm.named_parameters():
+            if n_.endswith("scale") or n_.endswith("post_norm.weight") or n_.endswith("dt_bias") or (n_.startswith("vision_model") and (n_.endswith("bias") or "norm" in n_)):
+                p_.add_((0.1 * torch.randn(p_.shape)).to(p_.dtype))
+    logits = vlm(ids, image_pixels=pix, attn_mask=am)
+    g = torch.randn(logits.shape)
+    (logits.float() * g).sum().backward()
+    t["gout"] = g
+    with torch.no_grad():
+        t["pos3d"] = vlm.compute_3d_position_ids(ids, vlm.get_feeds_3d_shape(pix), image_mask=ids == 250)
+    t["bf16.logits"] = logits.detach()
+    for k_, v_ in vlm.state_dict().items():
+        t["sd." + k_] = v_.to(torch.uint8) if v_.dtype == torch.bool else v_
+    for n_, p_ in vlm.named_parameters():
+        t["bf16.grad." + n_] = p_.grad
+    # the fp32 twin: same weights, text stack in fp32
+    twin = Qwen3_5VLM({**cfg, "dtype": torch.float32}).train()
+    sd = vlm.state_dict()
+    twin.load_state_dict({k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()})
+    lt = twin(ids, image_pixels=pix, attn_mask=am)
+    (lt * g).sum().backward()
+    t["fp32.logits"] = lt.detach()
+    for n_, p_ in twin.named_parameters():
+        t["fp32.grad." + n_] = p_.grad
+    _save(os.path.join(out, "qwen35_vlm_tiny.safetensors"), t, "tiny Qwen3_5VLM.forward (fp32 tower + bf16 hybrid text stack): logits + all gradients, fp32 weight twin")
+
+
 def gen_decode(out):
     """KV-cache decoding: the reference's tiny Qwen3 (weights of qwen3_tiny.safetensors) driven exactly
     as generate_loop_kv_cache does -- prefill with a KVCache, then one-token steps with position_ids -- teacher-forced with seeded
@@ -686,7 +732,7 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
     only = os.environ.get("GOLDEN_ONLY")
-    for fn in (gen_index, gen_ops, gen_qwen, gen_vit, gen_vlm, gen_gpt, gen_qwen35, gen_qwen35_text, gen_pipeline, gen_decode, gen_decode35, gen_signatures, gen_weight_maps, gen_rope_extra):
+    for fn in (gen_index, gen_ops, gen_qwen, gen_vit, gen_vlm, gen_gpt, gen_qwen35, gen_qwen35_text, gen_qwen35_vlm, gen_pipeline, gen_decode, gen_decode35, gen_signatures, gen_weight_maps, gen_rope_extra):
         if only and fn.__name__ != only:
             continue
         fn(args.out)

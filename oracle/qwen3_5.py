@@ -131,3 +131,22 @@ def vision35_forward(sd, cfg, pixels):
     h = h[:, src.reshape(-1)].reshape(b, src.shape[0], m * m * d)
     h = F.gelu(F.linear(h, sd["merge_adapter.lin1.weight"], sd["merge_adapter.lin1.bias"]))
     return F.linear(h, sd["merge_adapter.lin2.weight"], sd["merge_adapter.lin2.bias"])
+
+
+# --------------------------------------------------------------------------- the wrapper
+def vlm35_forward(sd, cfg, input_ids, pixels=None, attn_mask=None):
+    """Qwen3_5VLM.forward (qwen3_5_vlm_model.py:178-227) over one state dict with the reference's key names (``vision_model.*``,
+    ``language_model.*``): token embedding -> vision tower -> masked_scatter at the placeholder positions (vision rows cast to the text
+    dtype) -> 3-D position ids -> hybrid text model.  Returns (logits, position_ids)."""
+    from . import qwen3_5_text as q35t
+
+    txt = {k[len("language_model."):]: v for k, v in sd.items() if k.startswith("language_model.")}
+    emb = torch.nn.functional.embedding(input_ids, txt["emb_dict.weight"])
+    feeds = None
+    if pixels is not None:
+        vis = vision35_forward({k[len("vision_model."):]: v for k, v in sd.items() if k.startswith("vision_model.")}, cfg, pixels)
+        emb = masked_scatter_rows(emb, input_ids == cfg["image_token_id"], vis)
+        t = pixels.shape[2] // cfg["temporal_patch_size"]
+        feeds = [[t, cfg["img_height"] // cfg["patch_size"], cfg["img_width"] // cfg["patch_size"]]] * 1
+    pid = torch.from_numpy(position_ids_3d(input_ids.numpy(), feeds, cfg["image_token_id"], cfg["spatial_merge_size"]))
+    return q35t.text_model_forward(txt, cfg, attn_mask=attn_mask, inputs_embs=emb, position_ids=pid), pid

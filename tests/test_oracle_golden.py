@@ -296,3 +296,44 @@ def test_qwen35_text_tiny(golden, tag):
     with torch.no_grad():
         lo = q35t.text_model_forward(sd, cfg, x=ids)
     assert (lo.float() - t[f"txt.{tag}.logits_text_only"].float()).norm() <= tol * t[f"txt.{tag}.logits_text_only"].float().norm()
+
+
+@pytest.mark.parametrize("tag", ["fp32", "bf16"])
+def test_qwen35_vlm_wrapper_tiny(golden, tag):
+    """oracle/qwen3_5.py::vlm35_forward against the reference's ``Qwen3_5VLM.forward`` (qwen3_5_vlm_model.py:178-227): position ids exact,
+    logits and every gradient (vision tower + text stack) of the bf16 model and of its fp32 weight twin."""
+    from oracle import qwen3_5 as q35
+    from oracle.gen_golden import TINY_Q35_TEXT, TINY_Q35_VISION
+
+    t = golden("qwen35_vlm_tiny")
+    cfg = {**TINY_Q35_TEXT, **TINY_Q35_VISION, "llm_d_in": TINY_Q35_TEXT["emb_dim"], "image_token_id": 250}
+    sd = {}
+    for k, v in sub_dict(t, "sd.").items():
+        if k.endswith("out_head.weight"):
+            continue  # tied to emb_dict.weight
+        if k.endswith(".mask") or k == "language_model.mask":
+            sd[k] = v.bool()
+        elif v.is_floating_point() and not k.endswith((".cos", ".sin")) and k not in ("language_model.cos", "language_model.sin"):
+            w = v.float() if (tag == "fp32" and v.dtype == torch.bfloat16) else v
+            sd[k] = w.clone().requires_grad_(True)
+        else:
+            sd[k] = v
+    logits, pid = q35.vlm35_forward(sd, cfg, t["in.ids"], t["in.pixels"], t["in.attn_mask"].bool())
+    assert torch.equal(pid, t["pos3d"])
+    ref = t[f"{tag}.logits"]
+    assert logits.dtype == ref.dtype
+    tol = 2e-5 if tag == "fp32" else 2e-2
+    assert (logits.float() - ref.float()).norm() <= tol * ref.float().norm()
+    (logits.float() * t["gout"]).sum().backward()
+    grads = sub_dict(t, f"{tag}.grad.")
+    seen = 0
+    for k, g in grads.items():
+        if k.endswith("out_head.weight"):
+            continue
+        got = sd[k].grad
+        if got is None:  # rows of the learned position table beyond the grid, parameters the step does not reach
+            assert float(g.float().abs().max()) == 0.0, k
+            continue
+        seen += 1
+        assert (got.float() - g.float()).norm() <= (2e-4 if tag == "fp32" else 4e-2) * g.float().norm() + 1e-6, k
+    assert seen > 60

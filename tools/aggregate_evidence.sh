@@ -1,18 +1,19 @@
 #!/bin/bash
-# Turn the raw output of tools/collect_evidence.sh (merged back under gpurun_out/r03ev/) into the tracked files under profiles/.
-# Run from the repo root, in the container (no GPU needed).  Every output carries the collection's own stamp (gpurun_out/r03ev/stamp.json).
+# Turn the raw output of tools/collect_evidence.sh (merged back under gpurun_out/${ROUND}ev/) into the tracked files under profiles/.
+# Run from the repo root, in the container (no GPU needed).  Every output carries the collection's own stamp (gpurun_out/${ROUND}ev/stamp.json).
 set -e
-E=${1:-gpurun_out/r03ev}
+ROUND=${ROUND:-r04}
+E=${1:-gpurun_out/${ROUND}ev}
 for d in $E/*/; do n=$(ls $d*/ 2>/dev/null | sed 's/_.*//' | sort -u | wc -l); [ "$n" -le 1 ] || { echo "$d holds files of $n processes: stale collection mixed in"; exit 1; }; done
 B=$(python -c "import json;print(json.load(open('$E/stamp.json'))['per_gpu_batch'])"); M=$((B * 709))
-python tools/pmc_step.py $E/step_fetch $E/step_write 4 profiles/r03_pmc_tcc_step.json $E | tail -1
-python tools/pmc_gemm.py profiles/r03_pmc_tcc_gemm.json $E \
+python tools/pmc_step.py $E/step_fetch $E/step_write 4 profiles/${ROUND}_pmc_tcc_step.json $E | tail -1
+python tools/pmc_gemm.py profiles/${ROUND}_pmc_tcc_gemm.json $E \
   "NT:$E/nt_gateup_fetch:$E/nt_gateup_write:$M:6144:1024:gemm_bf16_kernel NT tile 2, gate-up forward C[$M,6144] = X[$M,1024] W[6144,1024]^T (plain epilogue)" \
   "NT_dgrad:$E/nt_dgrad_fetch:$E/nt_dgrad_write:$M:1024:6144:gemm_bf16_kernel NT tile 2, gate-up dgrad dX[$M,1024] = dY[$M,6144] (W^T)[1024,6144]^T (the step's form)" \
   "TN:$E/tn_wgrad_fetch:$E/tn_wgrad_write:6144:1024:$M:gemm_bf16_kernel TN tile 3, gate-up wgrad dW[6144,1024] = dY[$M,6144]^T X[$M,1024]" | tail -1
-rm -f profiles/r03_pmc_sq_counters.json
-for l in nt_gateup nt_dgrad tn_wgrad attn; do python tools/pmc_sq.py profiles/r03_pmc_sq_counters.json ${l}_b$B $E $E/${l}_sq1 $E/${l}_sq2 > /dev/null; done
-cp $(ls $E/trace/*/*kernel_stats.csv) profiles/r03_kernel_stats_b$B.csv
-python tools/trace_by_shape.py $(ls $E/trace/*/*kernel_trace.csv) 12 60 > profiles/r03_by_shape_b$B.txt
-cp $E/stamp.json profiles/r03_stamp.json
-head -3 profiles/r03_by_shape_b$B.txt
+rm -f profiles/${ROUND}_pmc_sq_counters.json
+for l in nt_gateup nt_dgrad tn_wgrad attn; do python tools/pmc_sq.py profiles/${ROUND}_pmc_sq_counters.json ${l}_b$B $E $E/${l}_sq1 $E/${l}_sq2 > /dev/null; done
+cp $(ls $E/trace/*/*kernel_stats.csv) profiles/${ROUND}_kernel_stats_b$B.csv
+python tools/trace_by_shape.py $(ls $E/trace/*/*kernel_trace.csv) 12 60 > profiles/${ROUND}_by_shape_b$B.txt
+cp $E/stamp.json profiles/${ROUND}_stamp.json
+head -3 profiles/${ROUND}_by_shape_b$B.txt

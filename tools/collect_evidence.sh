@@ -1,9 +1,10 @@
-# Round-3 evidence collection (GPU box, from the repo root):   GIT_SHA=<sha> BATCH=160 bash tools/collect_evidence.sh
-# Writes raw rocprofv3 output under gpurun_out/r03ev/ and a stamp (kernel-source fingerprint, sha-256 of the loaded library, git sha, batch)
-# taken HERE, at collection time; tools/aggregate_evidence.sh turns it into profiles/r03_* in the container and copies the stamp.
+# Evidence collection (GPU box, from the repo root):   ROUND=r04 GIT_SHA=<sha> BATCH=160 bash tools/collect_evidence.sh
+# Writes raw rocprofv3 output under gpurun_out/${ROUND}ev/ and a stamp (kernel-source fingerprint, sha-256 of the loaded library, git sha, batch)
+# taken HERE, at collection time; tools/aggregate_evidence.sh turns it into profiles/${ROUND}_* in the container and copies the stamp.
 set -e
+ROUND=${ROUND:-r04}
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03ev; rm -rf $O; mkdir -p $O  # (in the container: delete gpurun_out/r03ev before the call too -- gpurun MERGES what comes back into what is there)
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${ROUND}ev; rm -rf $O; mkdir -p $O  # (in the container: delete gpurun_out/${ROUND}ev before the call too -- gpurun MERGES what comes back into what is there)
 B=${BATCH:-160}; M=$((B * 709))
 (cd $R && python3 -m llm_quest_amd.fingerprint ${GIT_SHA:-unknown} $B > $O/stamp.json)
 SQ1="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
