@@ -213,12 +213,231 @@ def launch_ranks(n):
     return subprocess.run(cmd, env=env).returncode
 
 
+# ------------------------------------------------------------------------------------------------ the other BASELINE configurations
+# ``--config 2 | 3 | 5`` print the same JSON schema for BASELINE.json's configs[1], configs[2] and configs[4] (inputs, units,
+# algorithmic FLOP per sample).  They are parity-test configurations of the same kernels, not the headline: the default (``--config 4``) is
+# untouched by them.  No counter files are kept for them, so ``roofline.traffic`` is null.
+OTHER_CONFIGS = {
+    2: dict(metric="img/sec fwd+bwd, ViT-Base/16 224x224, bf16 MFMA operands", unit="img/s", flop=105.4e9, batch=256, units_per_sample=1, max_gpus=1,
+            workload="BASELINE configs[1]: ViT-Base/16 (VIT_BASE_CONFIG, num_classes 100), 224x224, forward + cross entropy + backward of every parameter, "
+                     "fp32 master weights / fp32 residual stream / bf16 MFMA operands, no optimizer step"),
+    3: dict(metric="tokens/sec fwd+bwd, Qwen3-0.6B dense text-only, seq 1024, bf16", unit="tok/s", flop=4.023e12, batch=64, units_per_sample=1024, max_gpus=1,
+            workload="BASELINE configs[2]: Qwen3-0.6B (context_length 1024), 1024 random tokens per sequence, forward + global_loss + backward, no optimizer step"),
+    5: dict(metric="frames+tokens/sec fwd+bwd, Qwen3.5-style VLM (Qwen3-ViT 3-D patches 8x224x224 + hybrid GDN / gated-attention 0.8B text stack, MRoPE-I), bf16",
+            unit="frames+tok/s", flop=3.492e12, batch=32, units_per_sample=8 + 512, max_gpus=8,
+            workload="BASELINE configs[4]: Qwen3_5VLM(QWEN3_5_08B_CONFIG, 224x224), 8 frames -> 196 merged vision rows at the placeholders + 512 text tokens "
+                     "(S = 708), targets = shifted ids, forward + loss + backward of both towers, no optimizer step"),
+}
+
+
+def _other_config_step(cfg_id, batch, device, rank):
+    """Builds the model and the synthetic batch of configs 2 / 3 / 5 (seeded as SURVEY 8d says) and returns (step_fn, sync, state_for_cpu)."""
+    from llm_quest_amd import ddp
+
+    torch.manual_seed(123)
+    if cfg_id == 2:
+        from llm_quest_amd.config import VIT_BASE_CONFIG
+        from llm_quest_amd.engine import _cross_entropy
+        from llm_quest_amd.multimodal.vision_transformer.vit_model import ViTModel
+
+        cfg = dict(VIT_BASE_CONFIG, drop_rate=0.0)  # the parity setting; drop_rate 0.1 (as configured upstream) costs 12-13 % (DESIGN.md section 5)
+        with torch.device(device):
+            model = ViTModel(cfg).train()
+        g = torch.Generator().manual_seed(123 + rank)
+        img = torch.randn(batch, 3, 224, 224, generator=g).to(device)
+        y = torch.randint(0, cfg["num_classes"], (batch,), generator=g).to(device)
+
+        def step():
+            model.zero_grad(set_to_none=True)
+            loss = _cross_entropy(model(img), y)
+            loss.backward()
+            return loss
+
+        return step, None, ("vit", cfg, model, (img, y))
+    if cfg_id == 3:
+        from llm_quest_amd.config import qwen3_config_creator
+        from llm_quest_amd.qwen.qwen3.qwen3_model import Qwen3Model
+
+        cfg = dict(qwen3_config_creator("0.6B"), context_length=1024)
+        with torch.device(device):
+            model = Qwen3Model(cfg).train()
+        g = torch.Generator().manual_seed(123 + rank)
+        x = torch.randint(0, VOCAB, (batch, 1024), generator=g).to(device)
+        y = torch.randint(0, VOCAB, (batch, 1024), generator=g).to(device)
+
+        def step():
+            model.zero_grad(set_to_none=True)
+            h = model.forward_hidden(x)  # == global_loss(model(x), y): the head + CE on every position (all 1024 feed the loss), logits written once
+            loss = model.lm_loss(h.reshape(-1, h.shape[-1]), y.reshape(-1))
+            loss.backward()
+            return loss
+
+        return step, None, ("qwen3", cfg, model, (x, y))
+    from llm_quest_amd.config import QWEN3_5_08B_CONFIG
+    from llm_quest_amd.qwen.qwen3_5.qwen3_5_vlm_model import Qwen3_5VLM, fuse_vision_embeddings
+
+    cfg = dict(QWEN3_5_08B_CONFIG, img_width=224, img_height=224, context_length=1024)
+    with torch.device(device):
+        vlm = Qwen3_5VLM(cfg).train()
+    sync = ddp.sync_for_qwen35(vlm)
+    sync.broadcast_parameters([vlm])
+    g = torch.Generator().manual_seed(123 + rank)
+    n_img = (8 // cfg["temporal_patch_size"]) * (14 // cfg["spatial_merge_size"]) ** 2  # 196 merged rows
+    ids = torch.randint(0, 248_000, (batch, 512 + n_img), generator=g)
+    ids[:, 100 : 100 + n_img] = cfg["image_token_id"]
+    pix = torch.randn(batch, 3, 8, 224, 224, generator=g).to(device)
+    ids = ids.to(device)
+    tgt = torch.roll(ids, -1, 1)
+    lm = vlm.language_model
+
+    def step():
+        vlm.zero_grad(set_to_none=True)
+        emb = lm.emb_dict(ids)
+        mask = ids == cfg["image_token_id"]
+        emb = fuse_vision_embeddings(emb, mask, vlm.vision_model(pix))
+        pos = vlm.compute_3d_position_ids(ids, vlm.get_feeds_3d_shape(pix), image_mask=mask)
+        h = lm.forward_hidden(inputs_embs=emb, position_ids=pos)  # Qwen3_5VLM.forward with the head + CE fused behind it (logits written once)
+        loss = lm.lm_loss(h.reshape(-1, h.shape[-1]), tgt.reshape(-1))
+        sync.begin_step()
+        loss.backward()
+        sync.finish_step()
+        return loss
+
+    return step, sync, ("qwen35", cfg, vlm, (ids, pix, tgt))
+
+
+def _other_cpu_worker(kind, cfg, state_path, threads, q):
+    """Child process: the CPU oracle of configs 2 / 3 / 5 on a bounded sample of the same workload, forward + backward."""
+    torch.set_num_threads(threads)
+    import torch.nn.functional as F
+
+    from oracle import models, ops
+    from oracle import qwen3_5 as q35
+
+    st = torch.load(state_path)
+    sd = {k: (v.requires_grad_(True) if v.is_floating_point() and not k.endswith(("cos", "sin")) else v) for k, v in st["sd"].items()}
+    t0 = time.perf_counter()
+    if kind == "vit":
+        img, y = st["batch"]
+        loss = F.cross_entropy(models.vit_forward(sd, cfg, img).float(), y)
+        units = img.shape[0]
+    elif kind == "qwen3":
+        x, y = st["batch"]
+        sd["out_head.weight"] = sd["emb_dict.weight"]
+        loss = ops.lm_loss(models.qwen3_forward(sd, cfg, x), y)
+        units = x.numel()
+    else:
+        ids, pix, tgt = st["batch"]
+        logits, _ = q35.vlm35_forward(sd, cfg, ids, pix)
+        loss = ops.lm_loss(logits, tgt)
+        units = ids.shape[0] * (8 + 512)
+    loss.backward()
+    q.put((time.perf_counter() - t0, float(loss.detach()), units))
+
+
+def _other_cpu_baseline(state, n_samples, unit, budget_s=300):
+    import tempfile
+
+    import torch.multiprocessing as mp
+
+    kind, cfg, model, batch = state
+    cores = min(usable_cores(), 32)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items() if k not in ("mask", "out_head.weight") and not k.endswith("language_model.out_head.weight")}
+    for k in list(sd):
+        if k.endswith("mask"):
+            sd[k] = sd[k].bool()
+    small = tuple(t[:n_samples].detach().cpu() for t in batch)
+    cfg = {k: v for k, v in cfg.items()}
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "state.pt")
+        torch.save({"sd": sd, "batch": small}, path)
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        proc = ctx.Process(target=_other_cpu_worker, args=(kind, cfg, path, cores, q))
+        proc.start()
+        proc.join(budget_s)
+        if proc.is_alive():
+            proc.kill()
+            proc.join()
+            return {"value": None, "unit": unit, "cores": cores, "kind": "port", "sample": f"{n_samples} full-size sample(s) fwd+bwd did not finish within the {budget_s} s budget on {cores} threads"}
+        dt, loss, units = q.get(timeout=10)
+    return {"value": round(units / dt, 3), "unit": unit, "cores": cores, "kind": "port",
+            "sample": f"{n_samples} full-size sample(s) forward + backward through the CPU oracle in {dt:.1f} s on {cores} threads, torch {torch.__version__} CPU, oracle loss {loss:.4f}"}
+
+
+def run_other_config(args):
+    from llm_quest_amd import _lib, ddp
+
+    spec = OTHER_CONFIGS[args.config]
+    if args.gpus > spec["max_gpus"]:
+        raise SystemExit(f"--config {args.config} is specified on {spec['max_gpus']} MI355X (BASELINE.json): --gpus {args.gpus} is not a configuration of it")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible")
+        raise SystemExit(launch_ranks(args.gpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}")
+    rank, world, local = ddp.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    _lib.load()
+    batch = args.batch if args.batch_given else spec["batch"]
+    step, sync, state = _other_config_step(args.config, batch, device, rank)
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        loss = step()
+    ev1.record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t)
+    if rank == 0:
+        achieved = spec["flop"] * batch / (elapsed / args.steps) / 1e12
+        line = {
+            "metric": spec["metric"], "value": round(world * batch * spec["units_per_sample"] * args.steps / elapsed, 1), "unit": spec["unit"], "n_gpus": world,
+            "rccl_ranks": world if world > 1 else 0, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": spec["workload"], "per_gpu_batch": batch, "global_batch": batch * world, "parallelism": f"dp{world}", "units_per_sample": spec["units_per_sample"]},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "traffic_note": "no counter passes are kept for this configuration (the headline's are: --config 4)",
+                         "basis": f"algorithmic {spec['flop'] / 1e9:.1f} GFLOP/sample (SURVEY 8d) x per-GPU batch / step time; device-side (HIP events) {dev_ms / args.steps:.3f} ms/step"},
+            "loss": round(float(loss.detach()), 5), "peak_memory_gib": round(torch.cuda.max_memory_allocated(device) / 2**30, 1),
+        }
+        if world == 1 and args.cpu_baseline == "auto":
+            try:
+                line["cpu_baseline"] = _other_cpu_baseline(state, {2: 8, 3: 2, 5: 1}[args.config], spec["unit"])
+            except Exception as exc:  # the baseline is a reported number, never the measured path
+                line["cpu_baseline"] = {"value": None, "unit": spec["unit"], "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {exc!r}"}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=160, help="per-GPU micro-batch (samples).  160 x 709 tokens keep 165 GiB of the 288 GB of HBM live; same-box pairs: 64 -> 34.2 / 34.1 %%, "
+    ap.add_argument("--config", type=int, choices=[2, 3, 4, 5], default=4, help="BASELINE.json configuration (1-based, as SURVEY.md numbers them): 4 = the headline VLM early-fusion step "
+                    "(default; everything below describes it), 2 = ViT-B/16, 3 = Qwen3-0.6B text-only at S = 1024, 5 = Qwen3.5-style VLM -- the same JSON schema for each")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU micro-batch (samples); default 160 for the headline (--config 2 / 3 / 5: 256 / 64 / 32).  Headline: 160 x 709 tokens keep 165 GiB of the 288 GB of HBM live; same-box pairs: 64 -> 34.2 / 34.1 %%, "
                     "128 -> +1.4 %%, 160 -> 35.0 / 34.9 %%, 192 -> level with 160 (202 GiB).  More rounds of tiles per launch amortise every launch's fill and tail.  (92 -- every "
                     "launch a whole number of rounds at batch ~64 -- measured the same as 64: the tail tiles of a partial round run faster, the chip is power-limited)")
     ap.add_argument("--cpu-baseline", choices=["auto", "off"], default="auto")
@@ -226,9 +445,14 @@ def main():
     ap.add_argument("--optimizer", choices=["on", "off"], default="on", help="also time the same steps with clip + AdamW (reported beside the fwd+bwd metric)")
     ap.add_argument("--vision-ahead", choices=["on", "off"], default="on", help="frozen ViT of the next step's batch on a second stream (vlm_engine.VisionAhead), as the training loop runs it")
     args = ap.parse_args()
+    args.batch_given = args.batch is not None
+    if args.batch is None:
+        args.batch = 160
 
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.config != 4:
+        return run_other_config(args)
     # MI355_DDP_REHEARSAL=1 (one-GPU boxes only): the N ranks share the visible GPUs round-robin and exchange over gloo -- every line of the N > 1 path
     # (rank start-up, broadcast, bucketed exchange on the communication stream, split tied-weight bucket, barriers, max-over-ranks timing, the one
     # JSON line) runs except RCCL itself.  The line it prints carries "rehearsal": true and is no measurement.

@@ -5,6 +5,8 @@ Tolerances follow SURVEY.md section 8c: the scalar loss within 1e-3 relative of 
 against the reference's OWN bf16 noise floor, measured as reference-bf16 vs its fp32 twin ("1.5x rule").
 """
 
+import math
+
 import pytest
 import torch
 
@@ -386,6 +388,65 @@ def test_lm_training_eval_loop_equals_its_steps_written_out(golden):
     assert step == 3
     for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         assert n1 == n2 and torch.equal(p1, p2), n1
+
+
+def test_timing_loop_runs_on_the_gpu_and_reports_tokens_per_second(golden, capsys):
+    """training_eval_loop_simple_timing (reference engine.py:270-374): HIP-event timed intervals around optimizer steps of the HIP Qwen3, the first
+    interval left out of the running average, evaluation after every interval, memory lines per epoch -- executed, its printed protocol and its
+    effect on the weights (equal to the same steps written out) checked."""
+    from llm_quest_amd.engine import global_loss, training_eval_loop_simple_timing
+
+    t = golden("qwen3_tiny")
+    g = torch.Generator().manual_seed(5)
+    data = [(torch.randint(0, 512, (2, 24), generator=g), torch.randint(0, 512, (2, 24), generator=g)) for _ in range(4)]
+    dev = torch.device("cuda")
+    m1 = make_qwen(t)
+    opt1 = torch.optim.AdamW(m1.parameters(), lr=1e-3)
+    tr, va, _ = training_eval_loop_simple_timing(data, data[:2], m1, opt1, 2, eval_freq=2, eval_iter=1, device=dev)
+    out = capsys.readouterr().out
+    assert len(tr) == len(va) == 4 and all(math.isfinite(x) for x in tr + va)
+    assert tr[-1] < tr[0], "eight optimizer steps on four repeated batches must lower the training loss"
+    lines = [ln for ln in out.splitlines() if "Step tok/sec" in ln]
+    assert len(lines) == 4 and all("Avg tok/sec" in ln for ln in lines)
+    rates = [int(ln.split("Step tok/sec:")[1].split(",")[0]) for ln in lines]
+    assert all(r > 0 for r in rates)
+    assert out.count("Allocated memory:") == 2 and out.count("Reserved memory:") == 2
+    m2 = make_qwen(t)
+    opt2 = torch.optim.AdamW(m2.parameters(), lr=1e-3)
+    for _ in range(2):
+        for X, y in data:
+            logits = m2(X.to(dev))
+            opt2.zero_grad()
+            global_loss(logits, y.to(dev), model=m2).backward()
+            opt2.step()
+    for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2), n1
+
+
+@pytest.mark.timeout(600)
+def test_profile_loop_traces_the_hip_training_steps(golden, tmp_path, capsys):
+    """profile_training_eval_loop (reference engine.py:499-640) with the HIP Qwen3 under torch.profiler: inline warm-up / cosine schedule, one clipped
+    optimizer step per batch, evaluation every eval_freq steps, early stop once wait + warmup + active steps were traced, a trace file on disk."""
+    import os
+
+    from llm_quest_amd.engine import profile_training_eval_loop
+
+    t = golden("qwen3_tiny")
+    g = torch.Generator().manual_seed(6)
+    data = [(torch.randint(0, 512, (2, 24), generator=g), torch.randint(0, 512, (2, 24), generator=g)) for _ in range(8)]
+    m = make_qwen(t)
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
+    logdir = str(tmp_path / "prof")
+    tr, va = profile_training_eval_loop(data, data[:2], m, opt, 2, warmup_percent=0.25, init_lr=1e-5, peak_lr=1e-3, min_lr=1e-4, eval_freq=2, eval_iter=1,
+                                        device=torch.device("cuda"), profile_dir=logdir, wait=1, warmup=1, active=2, repeat=1)
+    out = capsys.readouterr().out
+    assert "Profiling complete" in out
+    # budget = 4: the loop breaks at the first step whose count has reached it, i.e. after 5 steps (0..4), evaluated at steps 0, 2, 4
+    assert len(tr) == len(va) == 3 and all(math.isfinite(x) for x in tr + va)
+    assert any(f.endswith(".json") or f.endswith(".json.gz") for f in os.listdir(logdir)), os.listdir(logdir)
+    assert abs(opt.param_groups[0]["lr"] - (1e-4 + (1e-3 - 1e-4) * 0.5 * (1 + math.cos(math.pi * (4 - 4) / (16 - 4))))) < 1e-12  # step 4 = first cosine step
+    assert any(not torch.equal(p.detach(), before[n]) for n, p in m.named_parameters())
 
 
 def test_rccl_gradsync_single_rank(golden):

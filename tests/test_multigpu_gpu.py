@@ -116,3 +116,31 @@ def test_bench_refuses_more_ranks_than_gpus():
     env = dict(os.environ, WORLD_SIZE="3", RANK="0")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env)
     assert res.returncode != 0 and "WORLD_SIZE=3" in (res.stderr + res.stdout)
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_rank_rehearsal_runs_the_whole_n_gt_1_path_on_one_gpu():
+    """``MI355_DDP_REHEARSAL=1 python bench.py --gpus 2`` as a fresh child process on a one-GPU box: the bench starts its own two ranks
+    (torch.distributed.run), they share the GPU and exchange over gloo -- rank start-up, parameter broadcast, every block bucket on the
+    communication stream, the tied head / embedding bucket (dense or in two parts, by bytes), barriers, max-over-ranks timing and the ONE JSON
+    line all execute; only RCCL itself does not.  The line must say it is a rehearsal, and rank 0's loss must equal the one-rank run's
+    (same weights by broadcast, rank 0's shard = the one-rank batch: seeds 123 + rank)."""
+    import json
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    env = dict(os.environ, MI355_DDP_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--batch", "4", "--steps", "2", "--warmup", "1", "--cpu-baseline", "off", "--optimizer", "off"]
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, env=env, capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, two.stderr[-3000:]
+    lines = [ln for ln in two.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, two.stdout[-2000:]
+    d2 = json.loads(lines[0])
+    assert d2["rehearsal"] is True and d2["n_gpus"] == 2 and d2["rccl_ranks"] == 0 and d2["config"]["global_batch"] == 8 and d2["scaling"] == "weak"
+    assert d2["value"] > 0 and d2["steps"] == 2
+    env1 = {k: v for k, v in os.environ.items() if k != "MI355_DDP_REHEARSAL"}
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, env=env1, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-3000:]
+    d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
+    assert "rehearsal" not in d1 and d1["n_gpus"] == 1
+    assert d1["loss"] == d2["loss"], (d1["loss"], d2["loss"])
