@@ -210,7 +210,8 @@ def test_full_size_step_matches_the_cpu_oracle():
     img, ids, mask = bench.synthetic_batch(2, "cpu", seed=11, ragged=True)
     loss = vlm_step_loss(vit, llm, ad, img.to(dev), ids.to(dev), mask.to(dev), hf_vit_model=False)
     loss.backward()
-    picks = {"llm": ["trf_blocks.0.att.w_queries.weight", "trf_blocks.27.att.w_queries.weight", "trf_blocks.13.ffn.lin2.weight", "final_norm.weight"],
+    picks = {"llm": ["trf_blocks.0.att.w_queries.weight", "trf_blocks.27.att.w_queries.weight", "trf_blocks.13.ffn.lin2.weight", "final_norm.weight",
+                     "emb_dict.weight", "trf_blocks.13.norm2.weight", "trf_blocks.20.att.k_norm.weight"],
              "ad": ["adapter.0.weight", "adapter.3.weight"]}
     mine = {}
     for key, mod in (("llm", llm), ("ad", ad)):
@@ -238,7 +239,15 @@ def test_full_size_step_matches_the_cpu_oracle():
     for name, twin in g_fp32.items():
         floor = float((g_bf16[name].double() - twin.double()).norm() / twin.double().norm())
         err = float((mine[name].double() - twin.double()).norm() / twin.double().norm())
-        assert err <= 1.5 * floor + 2e-3, f"{name}: vs fp32 oracle {err:.3e}, bf16 oracle floor {floor:.3e}"
+        print(f"{name}: mine {err:.3e} floor {floor:.3e}")
+        assert err <= _tol(floor), f"{name}: vs fp32 oracle {err:.3e}, bf16 oracle floor {floor:.3e}"
+
+
+def _tol(floor, factor=1.5):
+    """The 1.5x rule: distance to the fp32 twin <= 1.5 x the reference arithmetic's own distance to it.  Where that floor is itself below 1e-2
+    (a gradient the low-precision run reproduces almost exactly) 2e-3 of absolute slack covers the different summation orders of two correct
+    implementations; at floors >= 1e-2 nothing is added."""
+    return factor * floor + (0.0 if floor >= 1e-2 else 2e-3)
 
 
 def _oracle_compare(mine, l_mine, oracle_run):
@@ -249,7 +258,8 @@ def _oracle_compare(mine, l_mine, oracle_run):
     for name, twin in g_fp32.items():
         floor = float((g_low[name].double() - twin.double()).norm() / twin.double().norm())
         err = float((mine[name].double() - twin.double()).norm() / twin.double().norm())
-        assert err <= 1.5 * floor + 2e-3, f"{name}: vs fp32 oracle {err:.3e}, low-precision oracle floor {floor:.3e}"
+        print(f"{name}: mine {err:.3e} floor {floor:.3e}")
+        assert err <= _tol(floor), f"{name}: vs fp32 oracle {err:.3e}, low-precision oracle floor {floor:.3e}"
 
 
 def test_full_size_qwen3_text_step_matches_the_cpu_oracle():
@@ -284,6 +294,64 @@ def test_full_size_qwen3_text_step_matches_the_cpu_oracle():
         sd = {k: v.detach().cpu().to(dtype).requires_grad_(True) for k, v in m.state_dict().items() if k not in skip}
         sd["out_head.weight"] = sd["emb_dict.weight"]
         logits = models.qwen3_forward(sd, dict(cfg, dtype=dtype), ids)
+        l32 = ops.lm_loss(logits.float(), tgt)
+        l32.backward()
+        return float(l32), {n: sd[n].grad.float() for n in picks}
+
+    _oracle_compare(mine, float(loss), oracle_run)
+
+
+def test_full_width_reduced_depth_qwen35_step_matches_the_cpu_oracle():
+    """BASELINE configs[4] (Qwen3.5-style VLM) at FULL WIDTH and reduced depth against the CPU oracle: emb 1024, GDN 16 x 128 heads, gated attention
+    8 x 256 heads over 2 kv groups, ffn 3584, V = 248 320, 4 text layers (3 GatedDeltaNet + 1 gated attention: one period of the hybrid pattern), a
+    2-layer 768-wide vision tower on 8 x 224 x 224 frames, S = 708 = 512 text tokens + 196 merged vision rows, B = 1, MRoPE-I position ids.  The
+    oracle -- pinned to the reference's ``Qwen3_5VLM.forward`` by tests/golden/qwen35_vlm_tiny -- runs the same weights twice, text stack in bf16
+    (the reference's arithmetic) and in fp32 (the twin); loss within 1e-3, picked gradients of both towers under the 1.5x rule."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import bench
+    from llm_quest_amd.config import QWEN3_5_08B_CONFIG
+    from llm_quest_amd.engine import global_loss
+    from llm_quest_amd.qwen.qwen3_5.qwen3_5_vlm_model import Qwen3_5VLM
+    from oracle import ops
+    from oracle import qwen3_5 as q35
+
+    torch.set_num_threads(min(16, bench.usable_cores()))
+    cfg = dict(QWEN3_5_08B_CONFIG, img_width=224, img_height=224, context_length=1024, n_layers=4, vision_n_layers=2)
+    torch.manual_seed(9)
+    with torch.device("cuda"):
+        vlm = Qwen3_5VLM(cfg).train()
+    with torch.no_grad():  # zero-centred scales, post norms and dt biases start at trivial values: move them so their gradients carry signal
+        for n_, p_ in vlm.named_parameters():
+            if n_.endswith("scale") or n_.endswith("post_norm.weight") or n_.endswith("dt_bias"):
+                p_.add_((0.1 * torch.randn(p_.shape, device=p_.device)).to(p_.dtype))
+    g = torch.Generator().manual_seed(23)
+    n_img = 4 * 7 * 7
+    ids = torch.randint(0, 248_000, (1, 512 + n_img), generator=g)
+    ids[:, 100 : 100 + n_img] = cfg["image_token_id"]
+    pix = torch.randn(1, 3, 8, 224, 224, generator=g)
+    tgt = torch.roll(ids, -1, 1)
+    loss = global_loss(vlm(ids.cuda(), image_pixels=pix.cuda()), tgt.cuda(), vlm.language_model)
+    loss.backward()
+    lm = "language_model.trf_blocks."
+    picks = [lm + "0.att.w_qkv.weight", lm + "0.att.conv1d.weight", lm + "2.att.out_proj.weight", lm + "1.ffn.lin2.weight", lm + "3.att.w_queries_gate.weight",
+             lm + "3.att.w_keys.weight", lm + "2.norm1.scale", "language_model.emb_dict.weight", "vision_model.blocks.1.att.qkv.weight", "vision_model.merge_adapter.lin2.weight"]
+    named = dict(vlm.named_parameters())
+    mine = {n: named[n].grad.float().cpu() for n in picks}
+
+    def oracle_run(low):
+        sd = {}
+        for k, v in vlm.state_dict().items():
+            if k.endswith("out_head.weight"):
+                continue
+            v = v.detach().cpu()
+            if k.endswith("mask"):
+                sd[k] = v.bool()
+            elif v.is_floating_point() and not k.endswith(("cos", "sin")):
+                sd[k] = (v.float() if (not low and v.dtype == BF16) else v.clone()).requires_grad_(True)
+            else:
+                sd[k] = v
+        logits, _ = q35.vlm35_forward(sd, cfg, ids, pix)
         l32 = ops.lm_loss(logits.float(), tgt)
         l32.backward()
         return float(l32), {n: sd[n].grad.float() for n in picks}

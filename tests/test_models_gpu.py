@@ -83,7 +83,7 @@ def test_qwen3_tiny_forward_backward(golden):
         twin = t["twin.grad." + name]
         floor = rel_l2(ref_grads[name], twin)
         mine = rel_l2(dict(m.named_parameters())[name].grad, twin)
-        assert mine <= 1.5 * floor + 2e-3, f"{name}: vs fp32 twin {mine:.3e}, reference floor {floor:.3e}"
+        assert mine <= 1.5 * floor + (0.0 if floor >= 1e-2 else 2e-3), f"{name}: vs fp32 twin {mine:.3e}, reference floor {floor:.3e}"  # no additive slack at floors >= 1e-2
     # no-mask forward
     with torch.no_grad():
         lg2 = m(ids)
@@ -261,7 +261,7 @@ def test_vlm_tiny_step_matches_reference(golden):
             twin = t["twin.grad." + pre + name]
             floor = rel_l2(t["grad." + pre + name], twin)
             mine = rel_l2(p.grad, twin)
-            assert mine <= 1.5 * floor + 2e-3, f"{pre}{name}: vs fp32 twin {mine:.3e}, reference floor {floor:.3e}"
+            assert mine <= 1.5 * floor + (0.0 if floor >= 1e-2 else 2e-3), f"{pre}{name}: vs fp32 twin {mine:.3e}, reference floor {floor:.3e}"
     assert abs(float(loss) - float(t["twin.loss"])) / float(t["twin.loss"]) < 1e-3
     assert all(p.grad is None for p in vit.parameters())
     # early-fusion gather is a bit-exact copy

@@ -388,7 +388,7 @@ def test_tiny_hybrid_model_forward_backward_vs_reference(golden):
         # softplus / sigmoid in both implementations; their noise is not averaged over many elements, hence the wider factor
         factor = 2.5 if ref.numel() <= 256 and ("log_A" in name or "dt_bias" in name or "w_alpha" in name or "w_beta" in name) else 1.5
         report.append(f"{name}: mine {mine_g:.3e} floor {floor_g:.3e}")
-        if mine_g > factor * floor_g + 4e-3:
+        if mine_g > factor * floor_g + (0.0 if floor_g >= 1e-2 else 2e-3):  # no additive slack where the reference's own noise is >= 1e-2
             bad.append(report[-1])
     print("\n".join(report))
     assert not bad, bad
@@ -448,12 +448,20 @@ def test_real_width_blocks_vs_oracle(kind):
     floor = rel_l2(want, ref32)
     assert rel_l2(y, ref32) <= 1.5 * floor + 1e-3, (rel_l2(y, ref32), floor)
     y.backward(g.cuda())
-    assert rel_l2(xd.grad, xf.grad) < 2e-2
+    # gradients on the floor rule: the oracle's bf16 run (the reference's arithmetic) against its fp32 twin sets the bar for every tensor
+    low = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    xl = x.clone().requires_grad_(True)
+    OT.block(low, "trf_blocks.0.", ocfg, 0, xl, allow, cos, sin, pid, am).backward(g)
+    floor_x = rel_l2(xl.grad, xf.grad)
+    assert rel_l2(xd.grad, xf.grad) <= 1.5 * floor_x + (0.0 if floor_x >= 1e-2 else 2e-3), (rel_l2(xd.grad, xf.grad), floor_x)
     for name, p in blk.named_parameters():
         tg = tw["trf_blocks.0." + name].grad
         assert p.grad is not None, name
-        err = float((p.grad.double().cpu() - tg.double()).norm())
-        assert err <= 3e-2 * float(tg.double().norm()) + 1e-4, f"{name}: |err| {err:.3e} |ref| {float(tg.norm()):.3e}"
+        floor_g = rel_l2(low["trf_blocks.0." + name].grad, tg)
+        mine_g = rel_l2(p.grad, tg)
+        # the handful-of-elements gate parameters carry un-averaged bf16 rounding of softplus / sigmoid in both implementations (see the tiny-model test)
+        few = tg.numel() <= 256 and any(s_ in name for s_ in ("log_A", "dt_bias"))
+        assert mine_g <= (2.5 if few else 1.5) * floor_g + (0.0 if floor_g >= 1e-2 else 2e-3), f"{name}: mine {mine_g:.3e}, oracle bf16 floor {floor_g:.3e}"
 
 
 def test_functional_gated_delta_rule_has_the_reference_signature(golden):
