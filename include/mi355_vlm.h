@@ -55,6 +55,8 @@ extern "C" {
  * Both pairs are bit-identical to GEMM + mi355_gelu_fwd / mi355_gelu_bwd. */
 #define MI355_EPI_GELU_BWD_ERF 6
 #define MI355_EPI_GELU_BWD_TANH 7
+/* internal to mi355_gemm_bf16_attn_delta (not accepted by mi355_gemm_bf16) */
+#define MI355_EPI_ATTN_DELTA 8
 
 const char* mi355_last_error(void);
 int mi355_abi_version(void);
@@ -88,6 +90,19 @@ typedef struct mi355_gemm_problem {
     const void* residual; int64_t ldr;
 } mi355_gemm_problem;
 int mi355_gemm_bf16_grouped(int form, int count, const mi355_gemm_problem* problems, int out_dtype, int tile_hint, void* stream);
+
+/* The out-projection's dgrad of an attention block with the attention backward's row constants as its epilogue (replaces the GEMM + the delta pass
+ * of mi355_attn_bwd*; reference: autograd of ctx @ out_proj.weight^T followed by the softmax backward's row sums, qwen3_attention.py:123-146):
+ *   C[M, N] = A[M, K] B[N, K]^T          (NT: A = d(out), B = the out-projection's weight TRANSPOSED, i.e. [Hq*D, d_model]; C = d(ctx), bf16)
+ *   delta[b, h, s]         = sum_d C[b*S + s, h*D + d] * ctx[b*S + s, h*D + d]     (on the ROUNDED bf16 C, as the stand-alone delta pass reads it)
+ *   neg_delta[b, h, s]     = -delta
+ *   neg_lse_log2e[b, h, s] = -lse[b, h, s] * log2(e)
+ * D = 128, N = Hq * D, M = B * S >= 256; ctx bf16 [M, N] pitch ldctx; lse / delta / neg_* fp32 [B, Hq, S].  neg_lse_log2e and neg_delta are the two
+ * arrays inside the attention-backward workspace at mi355_attn_bwd_workspace_rowconst_offset(B, S, Hq, D, 0 / 1) bytes; pass
+ * `causal | MI355_ATTN_DELTA_READY` to mi355_attn_bwd_ws / mi355_attn_bwd_qnorm afterwards and they skip their delta pass. */
+int mi355_gemm_bf16_attn_delta(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                               const void* ctx, int64_t ldctx, int S, int Hq, int D, const float* lse, float* delta, float* neg_lse_log2e,
+                               float* neg_delta, void* stream);
 
 /* column sums: out[n] (+)= sum_m X[m,n]  (bias / cls-token / pos-embedding gradients).  X bf16 or fp32 [M,N] ld=ldx,
  * out fp32 [N]. */
@@ -146,6 +161,10 @@ int mi355_attn_bwd(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t 
  * shape has no such form and workspace may be NULL): the dK/dV pass leaves dS there in bf16 and dQ = scale * dS K is one product over
  * it, instead of a pass that recomputes the scores.  Same results contract as mi355_attn_bwd; the scratch holds nothing afterwards. */
 int64_t mi355_attn_bwd_workspace_bytes(int B, int S, int Hq, int D);
+/* byte offset, inside that workspace, of the fp32 [B, Hq, S] array -lse * log2(e) (which = 0) or -delta (which = 1); -1 = no workspace form */
+int64_t mi355_attn_bwd_workspace_rowconst_offset(int B, int S, int Hq, int D, int which);
+/* OR into `causal` of mi355_attn_bwd_ws / mi355_attn_bwd_qnorm: delta and both row-constant arrays are already filled (mi355_gemm_bf16_attn_delta) */
+#define MI355_ATTN_DELTA_READY 0x1000000
 int mi355_attn_bwd_ws(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk,
                       const void* v, int64_t ldv, const void* o, int64_t ldo, const void* d_o, int64_t lddo,
                       const float* lse, float* delta, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv,

@@ -18,6 +18,7 @@ DT_BF16, DT_F32 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_SWIGLU_BWD, EPI_SWIGLU_FWD = 0, 1, 2, 3
 EPI_GELU_DUAL_ERF, EPI_GELU_DUAL_TANH, EPI_GELU_BWD_ERF, EPI_GELU_BWD_TANH = 4, 5, 6, 7
+ATTN_DELTA_READY = 0x1000000  # MI355_ATTN_DELTA_READY
 
 _c = ctypes
 _P, _I, _L, _F, _U = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_uint64
@@ -26,6 +27,7 @@ _P, _I, _L, _F, _U = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_uint64
 SIGNATURES = {
     "mi355_gemm_bf16": [_I, _L, _L, _L, _P, _L, _P, _L, _P, _L, _I, _P, _P, _L, _I, _P, _L, _I, _P],
     "mi355_gemm_bf16_grouped": [_I, _I, _P, _I, _I, _P],
+    "mi355_gemm_bf16_attn_delta": [_L, _L, _L, _P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P],
     "mi355_adamw": [_L, _P, _I, _P, _I, _P, _P, _F, _F, _F, _F, _F, _I, _P, _F, _P],
     "mi355_colsum": [_L, _L, _P, _I, _L, _P, _I, _P],
     "mi355_rmsnorm_fwd": [_L, _I, _P, _P, _P, _P, _F, _P],
@@ -102,6 +104,7 @@ QUERIES = {
     "mi355_gated_delta_rule_chunk": ([], _I),
     "mi355_gated_delta_rule_bwd_workspace_bytes": ([_I, _I, _I, _I, _I], _L),
     "mi355_attn_bwd_workspace_bytes": ([_I, _I, _I, _I], _L),
+    "mi355_attn_bwd_workspace_rowconst_offset": ([_I, _I, _I, _I, _I], _L),
     "mi355_attn_bwd_qnorm_partials": ([_I, _I, _I], _L),
     "mi355_embedding_bwd_sorted_workspace_bytes": ([_L, _I], _L),
 }

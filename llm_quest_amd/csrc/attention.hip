@@ -1185,6 +1185,9 @@ __device__ __forceinline__ void unpack4(const u32x2 v, float (&o)[4]) {
 }
 __device__ __forceinline__ float round_bf(float x) { return bf2f(f2bf(x)); }
 
+#ifndef DQ_ABL
+#define DQ_ABL 0  // profiling builds only: 1 = dS pieces fetched for the first tile only, 2 = K tiles fetched for the first tile only, 4 = no MFMAs / fragment reads, 8 = no write-out
+#endif
 template <int D, bool FUSE>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_spill_kernel(int B, int S, int Hq, int Hkv, const bf16_t* __restrict__ k, int64_t ldk,
                                                                    const bf16_t* __restrict__ ds, bf16_t* __restrict__ dq, int64_t lddq,
@@ -1217,11 +1220,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_spill_kernel(int B, int S,
     auto fetched = [&](int kgrp) { return !(causal && kgrp * 32 > qw + 31) && kgrp * 32 < S; };
     auto issue = [&](int kt) {
         char* st_ = smem + (kt % NST) * STAGE;
-        dma_tile<D, IMG_TR>(kbase + (int64_t)kt * 64 * ldk, ldk, S - kt * 64, st_, wave, lane);
+        if (!((DQ_ABL & 2) && kt > 0)) dma_tile<D, IMG_TR>(kbase + (int64_t)kt * 64 * ldk, ldk, S - kt * 64, st_, wave, lane);
         char* mine = st_ + C::TILE + wave * DSW;
 #pragma unroll
         for (int half = 0; half < 2; ++half)
-            if (fetched(2 * kt + half)) {
+            if (fetched(2 * kt + half) && !((DQ_ABL & 1) && kt > 0)) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, LDS_PTR(mine + half * 2048), 16, (unsigned)((2 * kt + half) * 2048) + unit, 0, 0, 0);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, LDS_PTR(mine + half * 2048 + 1024), 16, (unsigned)((2 * kt + half) * 2048 + 1024) + unit, 0, 0, 0);
             }
@@ -1244,6 +1247,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_spill_kernel(int B, int S,
         static_for<2>([&](auto hc) {
             constexpr int half = hc.value;
             if (!fetched(2 * kt + half)) return;
+            if constexpr (DQ_ABL & 4) return;
             // the half's two 16-key k-steps: B = dS^T fragment of this wave's 32 queries, A = K^T fragments of the DT column groups;
             // all reads from asm (a compiler-visible LDS read behind the DMA above would be guarded by vmcnt(0))
             TrHalves bs[2], ak[2][DT];
@@ -1263,6 +1267,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_spill_kernel(int B, int S,
                 });
             });
         });
+    }
+    if constexpr (DQ_ABL & 8) {
+        if (acc[0][0] == 12345.678f) f.dwp[0] = acc[1][1] + acc[2][2] + acc[3][3];  // keeps the loop alive
+        return;
     }
     if constexpr (!FUSE) {
         if (qg < S) {
@@ -1492,6 +1500,10 @@ static int attn_bwd_impl(int B, int S, int Hq, int Hkv, int D, const void* q, in
                          int64_t lddv, const uint8_t* key_mask, int causal, float scale, void* workspace, int64_t workspace_bytes,
                          void* stream, const QkFuse* fuse) {
     if (check_common("mi355_attn_bwd", B, S, Hq, Hkv, D)) return 1;
+    // MI355_ATTN_DELTA_READY: delta and the two row-constant arrays of the workspace were written by mi355_gemm_bf16_attn_delta (the epilogue of the
+    // out-projection's dgrad): the delta kernel is skipped
+    const bool delta_ready = (causal & MI355_ATTN_DELTA_READY) != 0;
+    causal &= ~MI355_ATTN_DELTA_READY;
     if (fuse) {  // dQ never exists as a matrix: the dQ pass writes d(qkv) rows
         dq = const_cast<void*>(q);
         lddq = ldq;
@@ -1520,11 +1532,13 @@ static int attn_bwd_impl(int B, int S, int Hq, int Hkv, int D, const void* q, in
                       (long long)workspace_bytes, (long long)mi355_attn_bwd_workspace_bytes(B, S, Hq, D));
         MI355_REQUIRE(((uintptr_t)workspace & 15) == 0, "mi355_attn_bwd_ws: workspace must be 16-byte aligned");
     }
+    MI355_REQUIRE(!delta_ready || spill, "mi355_attn_bwd: MI355_ATTN_DELTA_READY needs the workspace form (head_dim 128)");
     bf16_t* ds_ws = spill ? (bf16_t*)workspace : nullptr;
     float* nl2 = spill ? (float*)((char*)workspace + attn_bwd_ds_bytes(B, S, Hq)) : nullptr;
     float* ndl = spill ? (float*)((char*)nl2 + (((int64_t)B * Hq * S * 4 + 15) & ~(int64_t)15)) : nullptr;
 #define BWD_LAUNCH(DD)                                                                                                              \
-    hipLaunchKernelGGL(attn_delta_kernel<DD>, dim3(dgrid), dim3(256), 0, s, B, S, Hq, (const bf16_t*)o, ldo, (const bf16_t*)d_o, lddo, delta, lse, nl2, ndl); \
+    if (!delta_ready)                                                                                                               \
+        hipLaunchKernelGGL(attn_delta_kernel<DD>, dim3(dgrid), dim3(256), 0, s, B, S, Hq, (const bf16_t*)o, ldo, (const bf16_t*)d_o, lddo, delta, lse, nl2, ndl); \
     if (spill && DD == 128)                                                                                                         \
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, true>), dim3((unsigned)gk), dim3(256), 0, s, B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, \
                            (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, nl2, ndl, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, key_mask, causal, scale, sl2, bpw_k, ds_ws); \
@@ -1548,6 +1562,12 @@ static int attn_bwd_impl(int B, int S, int Hq, int Hkv, int D, const void* q, in
 #undef BWD_LAUNCH
     MI355_LAUNCH_CHECK("mi355_attn_bwd");
     return 0;
+}
+
+extern "C" int64_t mi355_attn_bwd_workspace_rowconst_offset(int B, int S, int Hq, int D, int which) {
+    if (D != 128 || B <= 0 || S <= 0 || Hq <= 0 || which < 0 || which > 1) return -1;
+    const int64_t first = attn_bwd_ds_bytes(B, S, Hq);
+    return which == 0 ? first : first + (((int64_t)B * Hq * S * 4 + 15) & ~(int64_t)15);
 }
 
 extern "C" int mi355_attn_bwd_ws(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk,

@@ -89,6 +89,13 @@ struct GemmParams {
     int ksplit;  // > 1: K is split over ksplit workgroups per tile, each writes an fp32 slab into ws
     float* ws;   // [ksplit][M][N] fp32
     int ablate;  // profiling only (tile_hint >> 8): 1 = no DMA after the prologue, 2 = no fragment reads after the first, 4 = no barrier
+    // MI355_EPI_ATTN_DELTA (mi355_gemm_bf16_attn_delta): C = d(ctx) of an attention block, R = the forward's ctx; the epilogue also leaves the
+    // attention backward's row constants delta[b, h, s] = sum_d dctx * ctx, -delta and -lse * log2(e), each fp32 [B, Hq, S]
+    const float* ad_lse;
+    float* ad_delta;
+    float* ad_nl2;
+    float* ad_ndl;
+    int ad_S, ad_Hq;
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -719,7 +726,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
         // paid once per tile instead of in every store pass (measured: +7.6 us per 256x256 tile on eight waves, +17 us on four).  NT only:
         // that is where the step's residual adds are (out-projection, down-projection); in the NN / TN kernels the 38 extra registers of the
         // look-ahead changed the main loop's allocation and cost 1.2 ms/step each in the per-kernel profile, for a path they never take.
-        constexpr bool RES_AHEAD = KSEL == MI355_EPI_NONE && OUT_DT == MI355_DT_BF16 && !A_TR && !B_TR;
+        constexpr bool RES_AHEAD = (KSEL == MI355_EPI_NONE || KSEL == MI355_EPI_ATTN_DELTA) && OUT_DT == MI355_DT_BF16 && !A_TR && !B_TR;
         constexpr int SUBS_N = T::WTN / 64, SUBS = (T::WTM / 64) * SUBS_N;
         const bool res_ahead = RES_AHEAD && p.R != nullptr && aligned_io && p.ksplit == 1;
         [[maybe_unused]] u32x4 rnext[8];
@@ -905,6 +912,26 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
                                     *reinterpret_cast<u32x4*>(c + p.N) = o1;
                                     continue;
                                 }
+                                if constexpr (KSEL == MI355_EPI_ATTN_DELTA) {
+                                    // acc = d(ctx); R = the forward's ctx: besides the plain store, the row's dot product over this sub-block's 64 columns
+                                    // (half a 128-wide head) of the ROUNDED d(ctx) with ctx -- the eight lanes of a row group fold it, lane 0 of the group parks
+                                    // it in the staging row's padding column `sm` (columns 64..67 are never staged into)
+                                    u32x4 o, cv;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) o[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+                                    if constexpr (FULL && RES_AHEAD) cv = rcur[tpass];
+                                    else cv = *reinterpret_cast<const u32x4*>(r);
+                                    float dsum = 0.f;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e)
+                                        dsum += __uint_as_float(o[e] << 16) * __uint_as_float(cv[e] << 16) + __uint_as_float(o[e] & 0xffff0000u) * __uint_as_float(cv[e] & 0xffff0000u);
+                                    *reinterpret_cast<u32x4*>(c) = o;
+                                    dsum += __shfl_xor(dsum, 1, 64);
+                                    dsum += __shfl_xor(dsum, 2, 64);
+                                    dsum += __shfl_xor(dsum, 4, 64);
+                                    if ((lane & 7) == 0) stg[row * EPI_LD + 64 + sm] = dsum;
+                                    continue;
+                                }
                                 if (vec_ok) {
                                     if (r) {
                                         u32x4 rv;
@@ -950,13 +977,35 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
                 __builtin_amdgcn_wave_barrier();  // the staging area is rewritten by the next 64x64 sub-block
             }
         }
+        if constexpr (KSEL == MI355_EPI_ATTN_DELTA) {
+            // every wave has parked 128 half-head row sums; a head's two halves sit in two neighbouring waves: one thread per (row, head) adds them
+            // in a fixed order and writes the three row-constant arrays of the attention backward
+            static_assert(T::NTHREADS == 512 && T::BM == 256 && T::BN == 256 && T::WN == 4 && T::WTN == 64, "delta write-out: 2 x 4 waves of 128 x 64 on a 256 x 256 tile");
+            __syncthreads();
+            const int t_ = threadIdx.x, row = t_ & 255, hsel = t_ >> 8;
+            const float* fs = reinterpret_cast<const float*>(smem);
+            const int w0 = (row >> 7) * 4 + 2 * hsel, r64 = row & 63, smi = (row >> 6) & 1;
+            const float sum = fs[(w0 * 64 + r64) * EPI_LD + 64 + smi] + fs[((w0 + 1) * 64 + r64) * EPI_LD + 64 + smi];
+            const int64_t gm = m0 + row;
+            const int64_t head = (n0 >> 7) + hsel;
+            if (gm < p.M && head < p.ad_Hq) {
+                const int64_t bb = gm / p.ad_S, sq = gm - bb * p.ad_S;
+                const int64_t di = (bb * p.ad_Hq + head) * p.ad_S + sq;
+                p.ad_delta[di] = sum;
+                p.ad_ndl[di] = -sum;
+                p.ad_nl2[di] = -p.ad_lse[di] * 1.4426950408889634f;
+            }
+        }
     };
     // a third copy of the passes for the SwiGLU-forward form (231.9 vs 233.6 ms/step); not on the 4-wave tile, where a third copy of its four
     // sub-blocks stops the unroller and the accumulators land in scratch
     constexpr bool SWIGLU_FWD_COPY = !A_TR && !B_TR && OUT_DT == MI355_DT_BF16 && T::NW == 8;
     constexpr bool SWIGLU_BWD_COPY = !A_TR && OUT_DT == MI355_DT_BF16 && T::NW == 8;  // the down-projection's dgrad (NT on W^T in the step, NN otherwise)
+    constexpr bool DELTA_COPY = !A_TR && !B_TR && OUT_DT == MI355_DT_BF16 && T::NW == 8 && T::BK == 64;  // the out-projection's dgrad (NT on W^T), tile 2 only
     if (p.epilogue == MI355_EPI_NONE) {
         run_epilogue(std::integral_constant<int, MI355_EPI_NONE>{});
+    } else if (DELTA_COPY && p.epilogue == MI355_EPI_ATTN_DELTA) {
+        if constexpr (DELTA_COPY) run_epilogue(std::integral_constant<int, MI355_EPI_ATTN_DELTA>{});
     } else if (SWIGLU_FWD_COPY && p.epilogue == MI355_EPI_SWIGLU_FWD) {
         if constexpr (SWIGLU_FWD_COPY) run_epilogue(std::integral_constant<int, MI355_EPI_SWIGLU_FWD>{});  // the step's largest forward GEMM
     } else if (SWIGLU_BWD_COPY && p.epilogue == MI355_EPI_SWIGLU_BWD) {
@@ -1213,6 +1262,7 @@ extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const 
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.bias = bias; p.R = residual;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
     p.epilogue = epilogue; p.tiles_m = p.tiles_n = 0; p.ksplit = 1; p.ws = nullptr; p.ablate = ablate;
+    p.ad_lse = nullptr; p.ad_delta = p.ad_nl2 = p.ad_ndl = nullptr; p.ad_S = p.ad_Hq = 0;
     hipStream_t s = (hipStream_t)stream;
     int cfg = tile_hint;
     if (cfg == 0) {
@@ -1242,6 +1292,24 @@ extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const 
     }
 }
 
+extern "C" int mi355_gemm_bf16_attn_delta(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                                          const void* ctx, int64_t ldctx, int S, int Hq, int D, const float* lse, float* delta, float* neg_lse_log2e,
+                                          float* neg_delta, void* stream) {
+    if (int rc = check_operands("mi355_gemm_bf16_attn_delta", MI355_GEMM_NT, M, N, K, A, lda, B, ldb, C)) return rc;
+    MI355_REQUIRE(D == 128 && S > 0 && Hq > 0 && N == (int64_t)Hq * D && M % S == 0, "mi355_gemm_bf16_attn_delta: C is d(ctx) [B*S, Hq*128] (got N = %ld, Hq = %d, D = %d, M = %ld, S = %d)",
+                  (long)N, Hq, D, (long)M, S);
+    MI355_REQUIRE(M >= 256, "mi355_gemm_bf16_attn_delta: at least 256 token rows (256 x 256 tiles)");
+    MI355_REQUIRE(ctx && lse && delta && neg_lse_log2e && neg_delta, "mi355_gemm_bf16_attn_delta: null pointer");
+    MI355_REQUIRE((ldc & 7) == 0 && (ldctx & 7) == 0 && ldc >= N && ldctx >= N && (((uintptr_t)ctx | (uintptr_t)C) & 15) == 0,
+                  "mi355_gemm_bf16_attn_delta: ctx / C rows must be 16-byte aligned and hold N columns");
+    GemmParams p;
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.bias = nullptr; p.R = ctx;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldctx;
+    p.epilogue = MI355_EPI_ATTN_DELTA; p.tiles_m = p.tiles_n = 0; p.ksplit = 1; p.ws = nullptr; p.ablate = 0;
+    p.ad_lse = lse; p.ad_delta = delta; p.ad_nl2 = neg_lse_log2e; p.ad_ndl = neg_delta; p.ad_S = S; p.ad_Hq = Hq;
+    return mi355_gemm_part2(MI355_GEMM_NT, &p, MI355_DT_BF16, nullptr, 0, (hipStream_t)stream);
+}
+
 extern "C" int mi355_gemm_bf16_grouped(int form, int count, const mi355_gemm_problem* problems, int out_dtype, int tile_hint,
                                        void* stream) {
     MI355_REQUIRE(form >= 0 && form <= 2, "mi355_gemm_bf16_grouped: bad form %d", form);
@@ -1259,6 +1327,7 @@ extern "C" int mi355_gemm_bf16_grouped(int form, int count, const mi355_gemm_pro
         p.A = (const bf16_t*)q.A; p.B = (const bf16_t*)q.B; p.C = q.C; p.bias = nullptr; p.R = q.residual;
         p.M = q.M; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc; p.ldr = q.ldr;
         p.epilogue = MI355_EPI_NONE; p.tiles_m = p.tiles_n = 0; p.ksplit = 1; p.ws = nullptr; p.ablate = 0;
+        p.ad_lse = nullptr; p.ad_delta = p.ad_nl2 = p.ad_ndl = nullptr; p.ad_S = p.ad_Hq = 0;
         tiles256 += ((q.M + 255) / 256) * ((q.N + 255) / 256);
         small |= q.M < 256 || q.N < 256;
     }

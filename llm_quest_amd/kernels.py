@@ -384,7 +384,41 @@ def attn_bwd(q, k, v, o, do, lse, B, S, Hq, Hkv, D, dq, dk, dv, key_mask=None, c
 FUSE_QNORM_BWD = os.environ.get("MI355_FUSE_QNORM_BWD", "1") != "0"  # A/B knob: 0 = dQ matrix + the separate QK-norm / RoPE backward for every head
 
 
-def attn_bwd_qnorm(q, k, v, o, do, lse, B, S, Hq, Hkv, D, dk, dv, qkv, qw, cos, sin, pos, rstd, dqkv, key_mask=None, causal=True, scale=None):
+FUSE_ATTN_DELTA = os.environ.get("MI355_FUSE_ATTN_DELTA", "1") != "0"  # A/B knob: 0 = plain out-projection dgrad + the delta pass inside the attention backward
+
+
+def dgrad_attn_delta(dy, w, ctx, lse, B, S, Hq, D):
+    """d(ctx) = dy @ w (the out-projection's dgrad, NT on the transposed weight) whose epilogue also leaves the attention backward's row constants
+    (delta = rowsum(d(ctx) * ctx) per head, -delta, -lse * log2 e) in the backward's scratch: the stand-alone delta pass (1 read of ctx + 1 of
+    d(ctx)) disappears.  Returns (dctx, delta) -- pass ``delta`` on to ``attn_bwd_qnorm`` -- or None when the form does not apply (head_dim != 128,
+    few rows, no scratch, knob off): the caller then runs ``dgrad``."""
+    M = dy.shape[0]
+    if not (FUSE_ATTN_DELTA and FUSE_QNORM_BWD and _ATTN_DS_SPILL and DGRAD_NT and D == 128 and M == B * S and M >= max(256, DGRAD_NT_MIN_ROWS)):
+        return None
+    L.require_gpu(dy, w, ctx, lse)
+    _rowmajor(dy, "dY")
+    _rowmajor(w, "W")
+    _rowmajor(ctx, "ctx")
+    N, Kd = Hq * D, dy.shape[1]
+    if not (dy.dtype == BF16 and w.dtype == BF16 and ctx.dtype == BF16 and tuple(w.shape) == (Kd, N) and tuple(ctx.shape) == (M, N) and (Kd & 7) == 0
+            and lse.dtype == F32 and lse.is_contiguous() and tuple(lse.shape) == (B, Hq, S)):
+        raise ValueError("dgrad_attn_delta: dY bf16 [B*S, d], W bf16 [d, Hq*D], ctx bf16 [B*S, Hq*D], lse contiguous fp32 [B, Hq, S]")
+    lib = L.load()
+    need = lib.mi355_attn_bwd_workspace_bytes(B, S, Hq, D)
+    ws = _attn_scratch(dy.device, need) if need else None
+    if ws is None:
+        return None
+    off0, off1 = (lib.mi355_attn_bwd_workspace_rowconst_offset(B, S, Hq, D, i) for i in (0, 1))
+    wt = transpose(w)  # [Hq*D, d]
+    L.require_gpu(dy, wt, ctx, lse)
+    out = torch.empty((M, N), dtype=BF16, device=dy.device)
+    delta = torch.empty_like(lse)
+    L.call("mi355_gemm_bf16_attn_delta", M, N, Kd, L.ptr(dy), dy.stride(0), L.ptr(wt), wt.stride(0), L.ptr(out), out.stride(0), L.ptr(ctx), ctx.stride(0),
+           S, Hq, D, L.ptr(lse), L.ptr(delta), ws.data_ptr() + off0, ws.data_ptr() + off1)
+    return out, delta
+
+
+def attn_bwd_qnorm(q, k, v, o, do, lse, B, S, Hq, Hkv, D, dk, dv, qkv, qw, cos, sin, pos, rstd, dqkv, key_mask=None, causal=True, scale=None, delta=None):
     """attn_bwd whose dQ pass ends in the backward of the QK-norm + RoPE of the query heads: writes d(qkv)[:, :Hq*D] into ``dqkv`` (dQ never exists
     as a matrix) and returns the fp32 [D] gradient of the query norm weight -- or None when this form does not apply (head_dim != 128, no scratch
     for the one-product dQ pass, knob off): the caller then runs attn_bwd + qknorm_rope_bwd."""
@@ -405,13 +439,20 @@ def attn_bwd_qnorm(q, k, v, o, do, lse, B, S, Hq, Hkv, D, dk, dv, qkv, qw, cos, 
     if ws is None:
         return None
     attn_bwd_form["spill"] += 1
-    delta = torch.empty_like(lse)
+    ready = 0
+    if delta is not None:  # written, with the scratch's two row-constant arrays, by dgrad_attn_delta: the delta pass is skipped
+        if not (delta.dtype == F32 and delta.is_contiguous() and delta.shape == lse.shape):
+            raise ValueError("attn_bwd_qnorm: delta must be contiguous fp32 [B,Hq,S]")
+        L.require_gpu(q, delta)
+        ready = L.ATTN_DELTA_READY
+    else:
+        delta = torch.empty_like(lse)
     scale = D ** -0.5 if scale is None else scale
     parts = L.load().mi355_attn_bwd_qnorm_partials(B, S, Hq)
     part = torch.empty((parts, D), dtype=F32, device=q.device)
     L.call(
         "mi355_attn_bwd_qnorm", B, S, Hq, Hkv, D, L.ptr(q), q.stride(0), L.ptr(k), k.stride(0), L.ptr(v), v.stride(0), L.ptr(o), o.stride(0),
-        L.ptr(do), do.stride(0), L.ptr(lse), L.ptr(delta), L.ptr(dk), dk.stride(0), L.ptr(dv), dv.stride(0), L.ptr(key_mask), int(causal) | _ATTN_ABLATE, scale,
+        L.ptr(do), do.stride(0), L.ptr(lse), L.ptr(delta), L.ptr(dk), dk.stride(0), L.ptr(dv), dv.stride(0), L.ptr(key_mask), int(causal) | _ATTN_ABLATE | ready, scale,
         L.ptr(ws), need, L.ptr(qkv), qkv.stride(0), L.ptr(qw), L.ptr(cos), L.ptr(sin), L.ptr(pos), L.ptr(rstd), H, L.ptr(dqkv), dqkv.stride(0), L.ptr(part),
     )
     # one partial row per workgroup: summed in two fixed-order levels (a single launch over thousands of rows runs on two workgroups)

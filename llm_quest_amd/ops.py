@@ -113,8 +113,9 @@ def attention_forward(att, arena, h1, rt):
     return ctx, (qkv, q, k, rstd, lse)
 
 
-def attention_backward(att, arena, h1, ctx, saved, dctx, rt, defer=None):
-    """Returns dh1 [M,d]; writes the QKV / QK-norm weight gradients."""
+def attention_backward(att, arena, h1, ctx, saved, dctx, rt, defer=None, delta=None):
+    """Returns dh1 [M,d]; writes the QKV / QK-norm weight gradients.  ``delta``: the softmax backward's row sums when the out-projection's
+    dgrad already left them (kernels.dgrad_attn_delta)."""
     Hq, Hkv, D = att.num_heads, att.num_kv_groups, att.head_dim
     qkv, q, k, rstd, lse = saved
     v = qkv[:, (Hq + Hkv) * D :]
@@ -122,7 +123,7 @@ def attention_backward(att, arena, h1, ctx, saved, dctx, rt, defer=None):
     dk = torch.empty_like(k)
     # the dQ pass ends in the QK-norm + RoPE backward of the query heads when it can (head_dim 128, scratch for the one-product form) ...
     dqw = K.attn_bwd_qnorm(q, k, v, ctx, dctx, lse, rt.B, rt.S, Hq, Hkv, D, dk, dqkv[:, (Hq + Hkv) * D :], qkv, att.q_norm.weight, rt.cos, rt.sin, rt.pos, rstd, dqkv,
-                           key_mask=rt.key_mask, causal=True, scale=att.att_scaling)
+                           key_mask=rt.key_mask, causal=True, scale=att.att_scaling, delta=delta)
     if dqw is not None:
         _, dkw = K.qknorm_rope_bwd(qkv, att.q_norm.weight, att.k_norm.weight, rt.cos, rt.sin, rt.pos, rstd, None, dk, dqkv, Hq, Hkv, D)
     else:  # ... otherwise dQ is a matrix and one kernel handles every head
@@ -176,9 +177,11 @@ def block_backward(blk, saved, dx3, rt):
     gview, gacc = _vecgrad(arena, blk.norm2.weight)
     dx2, _ = K.rmsnorm_bwd(x2, blk.norm2.weight, rstd2, dh2, dres=dx3, dw_out=gview, dw_accumulate=gacc)
     # ---- attention half
-    dctx = K.dgrad(dx2, att.out_proj.weight)
+    # the softmax backward's row sums (delta) are the epilogue of the out-projection's dgrad when the shape allows
+    fused = K.dgrad_attn_delta(dx2, att.out_proj.weight, ctx, att_saved[4], rt.B, rt.S, att.num_heads, att.head_dim)
+    dctx, delta = fused if fused is not None else (K.dgrad(dx2, att.out_proj.weight), None)
     _wgrad(arena, att.out_proj.weight, None, dx2, ctx, wg)
-    dh1 = attention_backward(att, arena, h1, ctx, att_saved, dctx, rt, wg)
+    dh1 = attention_backward(att, arena, h1, ctx, att_saved, dctx, rt, wg, delta)
     gview, gacc = _vecgrad(arena, blk.norm1.weight)
     dx, _ = K.rmsnorm_bwd(x, blk.norm1.weight, rstd1, dh1, dres=dx2, dw_out=gview, dw_accumulate=gacc)
     _flush_wgrads(wg)

@@ -567,6 +567,57 @@ def test_attention_backward_with_the_query_norm_backward_as_its_write_out(K, B, 
     assert torch.isfinite(dqkv1.float()).all() and torch.isfinite(dqw1).all()
 
 
+@pytest.mark.parametrize("B,S,Hq,Hkv", [(6, 709, 4, 2), (9, 500, 3, 1)])
+def test_out_projection_dgrad_leaves_the_attention_backwards_row_constants(K, B, S, Hq, Hkv):
+    """mi355_gemm_bf16_attn_delta: d(ctx) bit-identical to the plain dgrad; delta[b, h, s] = sum_d d(ctx) * ctx on the ROUNDED d(ctx) (what the
+    stand-alone delta pass reads; fp32 sums in another order: 1e-5), -delta and -lse * log2(e) exact in the backward's scratch; an odd head count
+    (the last 256-column tile holds one head) and a row count that is no multiple of 256; and the attention backward that skips its delta pass
+    (MI355_ATTN_DELTA_READY) gives the gradients of the one that runs it, to the rounding of delta."""
+    from llm_quest_amd import _lib as L
+    from oracle import ops
+
+    D, d_model = 128, 512
+    qkv, qw, kw = _qkv_case(B, S, Hq, Hkv, D, 41)
+    cos, sin = ops.rope_tables(1_000_000, D, 1024)
+    pos = torch.arange(S, dtype=torch.int32).repeat(B)
+    qkv_d, qw_d, kw_d, cos_d, sin_d, pos_d = dev(qkv), dev(qw), dev(kw), dev(cos), dev(sin), dev(pos)
+    q, k, rstd = K.qknorm_rope_fwd(qkv_d, qw_d, kw_d, cos_d, sin_d, pos_d, Hq, Hkv, D)
+    v = qkv_d[:, (Hq + Hkv) * D :]
+    ctx, lse = K.attn_fwd(q, k, v, B, S, Hq, Hkv, D, causal=True)
+    g = torch.Generator().manual_seed(42)
+    dy = dev((0.05 * torch.randn(B * S, d_model, generator=g)).to(BF16))
+    w = dev((0.05 * torch.randn(d_model, Hq * D, generator=g)).to(BF16))  # out_proj.weight [d_model, Hq*D]
+    plain = K.dgrad(dy, w)
+    fused = K.dgrad_attn_delta(dy, w, ctx, lse, B, S, Hq, D)
+    assert fused is not None, "the fused form must apply at head_dim 128 with >= 4096 rows and the scratch available"
+    dctx, delta = fused
+    assert torch.equal(dctx, plain)
+    want = (plain.float() * ctx.float()).view(B, S, Hq, D).sum(-1).permute(0, 2, 1).contiguous()
+    assert rel_l2(delta, want) < 1e-5 and delta.shape == lse.shape
+    lib = L.load()
+    need = lib.mi355_attn_bwd_workspace_bytes(B, S, Hq, D)
+    ws = K._attn_scratch(dy.device, need)
+    n = B * Hq * S
+    offs = [lib.mi355_attn_bwd_workspace_rowconst_offset(B, S, Hq, D, i) for i in (0, 1)]
+    assert offs[0] > 0 and offs[1] >= offs[0] + 4 * n and offs[1] + 4 * n <= need
+    nl2 = ws[offs[0] : offs[0] + 4 * n].view(torch.float32).view(B, Hq, S)
+    ndl = ws[offs[1] : offs[1] + 4 * n].view(torch.float32).view(B, Hq, S)
+    assert torch.equal(ndl, -delta) and torch.equal(nl2, -lse * torch.tensor(1.4426950408889634, dtype=torch.float32, device=lse.device))
+    # the backward with and without its own delta pass
+    dk0, dqkv0 = torch.empty_like(k), torch.zeros_like(qkv_d)
+    dqw0 = K.attn_bwd_qnorm(q, k, v, ctx, plain, lse, B, S, Hq, Hkv, D, dk0, dqkv0[:, (Hq + Hkv) * D :], qkv_d, qw_d, cos_d, sin_d, pos_d, rstd, dqkv0, causal=True)
+    fused2 = K.dgrad_attn_delta(dy, w, ctx, lse, B, S, Hq, D)  # the scratch was emptied by the backward above: fill it again
+    dk1, dqkv1 = torch.empty_like(k), torch.zeros_like(qkv_d)
+    dqw1 = K.attn_bwd_qnorm(q, k, v, ctx, fused2[0], lse, B, S, Hq, Hkv, D, dk1, dqkv1[:, (Hq + Hkv) * D :], qkv_d, qw_d, cos_d, sin_d, pos_d, rstd, dqkv1, causal=True,
+                            delta=fused2[1])
+    assert torch.equal(fused2[1], delta), "bit-reproducible"
+    nq = Hq * D
+    assert rel_l2(dk1, dk0) < 1e-3 and rel_l2(dqkv1[:, :nq], dqkv0[:, :nq]) < 1e-3 and rel_l2(dqw1, dqw0) < 1e-3
+    assert torch.equal(dqkv1[:, (Hq + Hkv) * D :], dqkv0[:, (Hq + Hkv) * D :]), "dV does not depend on delta"
+    # shapes the form does not take fall back (None): few rows
+    assert K.dgrad_attn_delta(dy[: 2 * S], w, ctx[: 2 * S], lse[:2].contiguous(), 2, S, Hq, D) is None
+
+
 def test_attention_strided_views(K):
     """k/v read in place from the fused QKV projection buffer (row pitch = (Hq+2Hkv)*D)."""
     B, S, Hq, Hkv, D = 1, 100, 4, 2, 128
