@@ -175,13 +175,16 @@ int mi355_attn_bwd_ws(int B, int S, int Hq, int Hkv, int D, const void* q, int64
  * ldqkv), q_weight bf16 [D], cos / sin fp32 [positions, D], pos int32 [B*S], rstd fp32 [B*S, rstd_heads] as mi355_qknorm_rope_fwd left them;
  * d(qkv) rows of the query heads go to dqkv (pitch lddqkv); dqw_partial fp32 [mi355_attn_bwd_qnorm_partials(B,S,Hq), D]: one row per
  * workgroup, summed by the caller (mi355_reduce_rows_f32) into the norm-weight gradient.  The key heads: mi355_qknorm_rope_bwd with dq = NULL.
+ * rope_cs16 (optional, NULL = read cos / sin): bf16 [positions][cos[:, :D/2] | sin[:, :D/2]], 16-byte aligned -- pass it ONLY when cos[:, D/2:] ==
+ * cos[:, :D/2] and sin[:, D/2:] == sin[:, :D/2] (plain RoPE tables, common/rope.py:38-96); the coefficients are rounded to bf16 before use in
+ * either form (as the forward applies them), so the results are identical bits from a quarter of the coefficient loads.
  * Reference: GroupedQueryAttention.forward, llm_quest/qwen/qwen3/qwen3_attention.py:103-160 (q_norm, RoPE, SDPA) under autograd. */
 int64_t mi355_attn_bwd_qnorm_partials(int B, int S, int Hq);
 int mi355_attn_bwd_qnorm(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                          const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* lse, float* delta, void* dk, int64_t lddk,
                          void* dv, int64_t lddv, const uint8_t* key_mask, int causal, float scale, void* workspace, int64_t workspace_bytes,
                          const void* qkv, int64_t ldqkv, const void* q_weight, const float* cos, const float* sin, const int32_t* pos,
-                         const float* rstd, int rstd_heads, void* dqkv, int64_t lddqkv, float* dqw_partial, void* stream);
+                         const float* rstd, int rstd_heads, void* dqkv, int64_t lddqkv, float* dqw_partial, const void* rope_cs16, void* stream);
 
 /* Row-wise cross entropy on bf16 logits with ignore_index=-100 (engine.py:45,60; vlm_engine.py:39).
  * logits [rows, V] ld=ldl.  loss_rows fp32 [rows] (0 for ignored).  If dlogits != NULL writes

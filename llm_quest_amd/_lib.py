@@ -41,7 +41,7 @@ SIGNATURES = {
     "mi355_attn_bwd": [_I, _I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _L, _P, _L, _P, _L, _P, _I, _F, _P],
     "mi355_attn_bwd_ws": [_I, _I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _L, _P, _L, _P, _L, _P, _I, _F, _P, _L, _P],
     "mi355_attn_bwd_qnorm": [_I, _I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _L, _P, _L, _P, _I, _F, _P, _L,
-                             _P, _L, _P, _P, _P, _P, _P, _I, _P, _L, _P, _P],
+                             _P, _L, _P, _P, _P, _P, _P, _I, _P, _L, _P, _P, _P],
     "mi355_cross_entropy": [_L, _L, _P, _L, _P, _P, _P, _P, _P],
     "mi355_ce_finalize": [_L, _P, _P, _P, _P],
     "mi355_embedding_fwd": [_L, _I, _L, _P, _P, _P, _L, _P],

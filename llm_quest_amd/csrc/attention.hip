@@ -1176,6 +1176,8 @@ struct QkFuse {
     bf16_t* dqkv;        // d(qkv) [tokens, lddqkv]
     int64_t lddqkv;
     float* dwp;          // [gridDim.x, D]
+    const bf16_t* cs16;  // optional: [positions][cos (D/2) | sin (D/2)] bf16, valid when both halves of the fp32 tables are equal (plain RoPE): the
+                         // coefficients are rounded to bf16 before use anyway, so the results are the same bits from a quarter of the loads
 };
 __device__ __forceinline__ void unpack4(const u32x2 v, float (&o)[4]) {
     o[0] = __uint_as_float(v[0] << 16);
@@ -1289,6 +1291,127 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_spill_kernel(int B, int S,
         // the write-out's own operands (four rows per thread: row slot + 32 it) are requested first -- rows 0 and 1 here, under the transposition,
         // rows 2 and 3 under the arithmetic of rows 0 and 1 -- so the pass pays two memory latencies, not eight
         const int sub = threadIdx.x >> 3, i = (threadIdx.x & 7) * 8;
+        if (f.cs16 != nullptr) {
+            // ---- compact coefficient table: five loads per row (two of the pre-norm row, cos, sin, rstd), so all four rows of a thread are requested
+            // here, in front of the transposition, and the pass pays ONE memory latency
+            struct RowC {
+                u32x4 xa, xb, c, sn;
+                float r;
+                int64_t tok;
+                bool live;
+            };
+            RowC in[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int qrow = q0 + sub + 32 * it;
+                in[it].live = qrow < S;
+                in[it].tok = (int64_t)b * S + (in[it].live ? qrow : S - 1);
+            }
+            int pp[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) pp[it] = f.pos[in[it].tok];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const bf16_t* xr = f.qkv + in[it].tok * f.ldqkv + (int64_t)hq * D + i;
+                in[it].xa = *reinterpret_cast<const u32x4*>(xr);
+                in[it].xb = *reinterpret_cast<const u32x4*>(xr + D / 2);
+                in[it].r = f.rstd[in[it].tok * f.rstd_heads + hq];
+                const bf16_t* cr = f.cs16 + (int64_t)pp[it] * D + i;
+                in[it].c = *reinterpret_cast<const u32x4*>(cr);
+                in[it].sn = *reinterpret_cast<const u32x4*>(cr + D / 2);
+            }
+            __syncthreads();  // every wave is past its last tile: the stages become the transposition buffer
+            float* xs = reinterpret_cast<float*>(smem);
+            {
+                const int row = wave * 32 + (lane & 31), hb = lane >> 5;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int chunk = dt * 8 + 2 * g4 + hb;
+                        const f32x4 val = {acc[dt][4 * g4] * scale, acc[dt][4 * g4 + 1] * scale, acc[dt][4 * g4 + 2] * scale, acc[dt][4 * g4 + 3] * scale};
+                        *reinterpret_cast<f32x4*>(xs + row * D + 4 * (chunk ^ (row & 31))) = val;
+                    }
+            }
+            __syncthreads();
+            float w1[8], w2[8], dw1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dw2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            {
+                const u32x4 a = *reinterpret_cast<const u32x4*>(f.qw + i), bq = *reinterpret_cast<const u32x4*>(f.qw + D / 2 + i);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    w1[2 * e] = __uint_as_float(a[e] << 16);
+                    w1[2 * e + 1] = __uint_as_float(a[e] & 0xffff0000u);
+                    w2[2 * e] = __uint_as_float(bq[e] << 16);
+                    w2[2 * e + 1] = __uint_as_float(bq[e] & 0xffff0000u);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = sub + 32 * it;
+                const float r = in[it].r;
+                float g1[8], g2[8];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int ch = (i >> 2) + hh;
+                    const f32x4 ga = *reinterpret_cast<const f32x4*>(xs + row * D + 4 * (ch ^ (row & 31)));
+                    const f32x4 gb = *reinterpret_cast<const f32x4*>(xs + row * D + 4 * ((ch + 16) ^ (row & 31)));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        g1[4 * hh + e] = ga[e];
+                        g2[4 * hh + e] = gb[e];
+                    }
+                }
+                float dn1[8], dn2[8], xh1[8], xh2[8];
+                float dot = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float x1 = (e & 1) ? __uint_as_float(in[it].xa[e >> 1] & 0xffff0000u) : __uint_as_float(in[it].xa[e >> 1] << 16);
+                    const float x2 = (e & 1) ? __uint_as_float(in[it].xb[e >> 1] & 0xffff0000u) : __uint_as_float(in[it].xb[e >> 1] << 16);
+                    const float cc = (e & 1) ? __uint_as_float(in[it].c[e >> 1] & 0xffff0000u) : __uint_as_float(in[it].c[e >> 1] << 16);   // cos of d and of d + 64
+                    const float ss = (e & 1) ? __uint_as_float(in[it].sn[e >> 1] & 0xffff0000u) : __uint_as_float(in[it].sn[e >> 1] << 16);
+                    // y1 = c n1 - s n2, y2 = c n2 + s n1
+                    dn1[e] = cc * g1[e] + ss * g2[e];
+                    dn2[e] = cc * g2[e] - ss * g1[e];
+                    xh1[e] = x1 * r;
+                    xh2[e] = x2 * r;
+                    dot += dn1[e] * w1[e] * xh1[e] + dn2[e] * w2[e] * xh2[e];
+                }
+                dot += __shfl_xor(dot, 4, 64);
+                dot += __shfl_xor(dot, 2, 64);
+                dot += __shfl_xor(dot, 1, 64);
+                dot *= 1.0f / (float)D;
+                if (in[it].live) {
+                    u32x4 o1, o2;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o1[e] = pack_bf2(r * (dn1[2 * e] * w1[2 * e] - xh1[2 * e] * dot), r * (dn1[2 * e + 1] * w1[2 * e + 1] - xh1[2 * e + 1] * dot));
+                        o2[e] = pack_bf2(r * (dn2[2 * e] * w2[2 * e] - xh2[2 * e] * dot), r * (dn2[2 * e + 1] * w2[2 * e + 1] - xh2[2 * e + 1] * dot));
+                    }
+                    bf16_t* orow = f.dqkv + in[it].tok * f.lddqkv + (int64_t)hq * D + i;
+                    *reinterpret_cast<u32x4*>(orow) = o1;
+                    *reinterpret_cast<u32x4*>(orow + D / 2) = o2;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        dw1[e] += dn1[e] * xh1[e];
+                        dw2[e] += dn2[e] * xh2[e];
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                xs[sub * D + i + e] = dw1[e];
+                xs[sub * D + D / 2 + i + e] = dw2[e];
+            }
+            __syncthreads();
+            if (threadIdx.x < D) {
+                float sum = 0.f;
+#pragma unroll
+                for (int rgn = 0; rgn < 32; ++rgn) sum += xs[rgn * D + threadIdx.x];
+                f.dwp[(int64_t)blockIdx.x * D + threadIdx.x] = sum;
+            }
+            return;
+        }
         struct RowIn {
             u32x4 xa, xb;
             f32x4 c[4], sn[4];  // cos / sin of features i..i+3, i+4..i+7, 64+i.., 64+i+4..
@@ -1585,14 +1708,15 @@ extern "C" int mi355_attn_bwd_qnorm(int B, int S, int Hq, int Hkv, int D, const 
                                     const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* lse, float* delta, void* dk, int64_t lddk,
                                     void* dv, int64_t lddv, const uint8_t* key_mask, int causal, float scale, void* workspace, int64_t workspace_bytes,
                                     const void* qkv, int64_t ldqkv, const void* q_weight, const float* cos, const float* sin, const int32_t* pos,
-                                    const float* rstd, int rstd_heads, void* dqkv, int64_t lddqkv, float* dqw_partial, void* stream) {
+                                    const float* rstd, int rstd_heads, void* dqkv, int64_t lddqkv, float* dqw_partial, const void* rope_cs16, void* stream) {
     MI355_REQUIRE(D == 128, "mi355_attn_bwd_qnorm: head_dim must be 128 (got %d)", D);
     MI355_REQUIRE(qkv && q_weight && cos && sin && pos && rstd && dqkv && dqw_partial && workspace, "mi355_attn_bwd_qnorm: null pointer");
     MI355_REQUIRE(rstd_heads >= Hq && ldqkv >= (int64_t)Hq * D && lddqkv >= (int64_t)Hq * D && ((ldqkv | lddqkv) & 3) == 0,
                   "mi355_attn_bwd_qnorm: qkv / dqkv rows must hold the query heads (8-byte aligned pitches), rstd one column per head");
     MI355_REQUIRE((((uintptr_t)qkv | (uintptr_t)dqkv | (uintptr_t)q_weight) & 7) == 0 && (((uintptr_t)cos | (uintptr_t)sin) & 15) == 0,
                   "mi355_attn_bwd_qnorm: qkv / dqkv / weight 8-byte aligned, cos / sin 16-byte aligned");
-    const QkFuse f{(const bf16_t*)qkv, ldqkv, (const bf16_t*)q_weight, cos, sin, pos, rstd, rstd_heads, (bf16_t*)dqkv, lddqkv, dqw_partial};
+    MI355_REQUIRE(!rope_cs16 || ((uintptr_t)rope_cs16 & 15) == 0, "mi355_attn_bwd_qnorm: rope_cs16 must be 16-byte aligned");
+    const QkFuse f{(const bf16_t*)qkv, ldqkv, (const bf16_t*)q_weight, cos, sin, pos, rstd, rstd_heads, (bf16_t*)dqkv, lddqkv, dqw_partial, (const bf16_t*)rope_cs16};
     return attn_bwd_impl(B, S, Hq, Hkv, D, q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo, lse, delta, nullptr, 0, dk, lddk, dv, lddv, key_mask, causal, scale, workspace,
                          workspace_bytes, stream, &f);
 }

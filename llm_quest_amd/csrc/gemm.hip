@@ -458,12 +458,58 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
+        // Weight gradients (both operands K-strided): the same schedule with every fragment requested from asm (two ds_read_b64_tr_b16 per fragment;
+        // the intrinsic form makes hipcc drain the DMA ring with vmcnt(0) in front of each, see frag_tr_issue) and joined behind a wait that names
+        // the halves.  Phase 0's four reads are joined at the barrier, phase 1's twelve at the end of the tile: both sit under 32 MFMAs.
+        [[maybe_unused]] TrHalves h_a1[HM], h_b[T::FN], h_a0[HM];
+        auto body_tr = [&](auto par, int t) {
+            constexpr int CUR = decltype(par)::value;
+            const char* sA = smem + ((t - t0) & 3) * T::STAGE;
+            const char* nA = smem + ((t + 1 - t0) & 3) * T::STAGE;
+            const int nst = (t + 3 - t0) & 3;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mma(acc[g >> 1][(g & 1) * 4 + q], a0[g >> 1], b[CUR][(g & 1) * 4 + q]);
+                issue_piece(t + 3, nst, g);
+                if (g < HM) frag_tr_issue<T::BM>(h_a1[g], sA, wr0 + (HM + g) * 16, 0, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : TRH(h_a1[0]), TRH(h_a1[1]), TRH(h_a1[2]), TRH(h_a1[3])::"memory");
+#pragma unroll
+            for (int i = 0; i < HM; ++i) a1[i] = tr_join(h_a1[i]);
+            wait_vmcnt<16>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) mma(acc[HM + (g >> 2)][(g & 3) * 2 + q], a1[g >> 2], b[CUR][(g & 3) * 2 + q]);
+                if (g < T::FN) frag_tr_issue<T::BN>(h_b[g], nA + T::A_BYTES, wc0 + g * 16, 0, lane);
+                else if (g < T::FN + HM) frag_tr_issue<T::BM>(h_a0[g - T::FN], nA, wr0 + (g - T::FN) * 16, 0, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : TRH(h_b[0]), TRH(h_b[1]), TRH(h_b[2]), TRH(h_b[3]), TRH(h_b[4]), TRH(h_b[5]), TRH(h_b[6]), TRH(h_b[7]),
+                         TRH(h_a0[0]), TRH(h_a0[1]), TRH(h_a0[2]), TRH(h_a0[3])::"memory");
+#pragma unroll
+            for (int j = 0; j < T::FN; ++j) b[CUR ^ 1][j] = tr_join(h_b[j]);
+#pragma unroll
+            for (int i = 0; i < HM; ++i) a0[i] = tr_join(h_a0[i]);
+        };
         int t = t0;
-        for (; t + 1 < nt; t += 2) {
-            body(std::integral_constant<int, 0>{}, t);
-            body(std::integral_constant<int, 1>{}, t + 1);
+        if constexpr (A_TR && B_TR) {
+            for (; t + 1 < nt; t += 2) {
+                body_tr(std::integral_constant<int, 0>{}, t);
+                body_tr(std::integral_constant<int, 1>{}, t + 1);
+            }
+            if (t < nt) body_tr(std::integral_constant<int, 0>{}, t);
+        } else {
+            for (; t + 1 < nt; t += 2) {
+                body(std::integral_constant<int, 0>{}, t);
+                body(std::integral_constant<int, 1>{}, t + 1);
+            }
+            if (t < nt) body(std::integral_constant<int, 0>{}, t);
         }
-        if (t < nt) body(std::integral_constant<int, 0>{}, t);
         wait_vmcnt<0>();  // the zero-fill DMAs past the last tile must not land in the epilogue's staging
     } else if constexpr (T::BK == 32) {
         // ---- alternating-group loop (8 waves, BK = 32, NS-stage ring).  Waves 4-7 run ONE barrier behind waves 0-3, so on
@@ -1279,7 +1325,9 @@ extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const 
         const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
         if (M < 256 || N < 256) cfg = 1;
         else if (form != MI355_GEMM_TN && tiles256 < 128) cfg = 1;  // measured: 92 tiles -> 128x128 wins (+2.8 % on the config-5 step), 180 tiles -> 256x256 wins
-        else if (form == MI355_GEMM_TN) cfg = (M * N > 5 * 1024 * 1024) ? 3 : 1;
+        // weight gradients: the 4-wave loop (128x128 per wave: a third fewer transposing reads per MFMA than the 8-wave tiles, every read issued from asm).  Round 4, batch 160:
+        // the block's grouped launch 3 327 -> 3 028 us, the LM head's 25.9 -> 22.7 ms in isolation; in the step 469.0 / 468.9 -> 456.9 / 458.0 ms (same box, bit-identical)
+        else if (form == MI355_GEMM_TN) cfg = (M * N > 5 * 1024 * 1024) ? 5 : 1;
         else if (form == MI355_GEMM_NT) cfg = 2;
         else cfg = 3;
     }
@@ -1315,7 +1363,7 @@ extern "C" int mi355_gemm_bf16_grouped(int form, int count, const mi355_gemm_pro
     MI355_REQUIRE(form >= 0 && form <= 2, "mi355_gemm_bf16_grouped: bad form %d", form);
     MI355_REQUIRE(count >= 1 && count <= MAX_GROUP && problems, "mi355_gemm_bf16_grouped: count must be 1..%d", MAX_GROUP);
     MI355_REQUIRE(out_dtype == MI355_DT_BF16 || out_dtype == MI355_DT_F32, "mi355_gemm_bf16_grouped: bad out_dtype");
-    MI355_REQUIRE(tile_hint == 0 || tile_hint == 1 || tile_hint == 3 || tile_hint == 4, "mi355_gemm_bf16_grouped: tile_hint must be 0 (auto), 1 (128x128), 3 or 4 (256x256)");
+    MI355_REQUIRE(tile_hint == 0 || tile_hint == 1 || tile_hint == 3 || tile_hint == 4 || tile_hint == 5, "mi355_gemm_bf16_grouped: tile_hint must be 0 (auto), 1 (128x128), 3, 4 or 5 (256x256)");
     GroupTable tbl;
     tbl.count = count;
     int64_t tiles256 = 0;
@@ -1333,8 +1381,9 @@ extern "C" int mi355_gemm_bf16_grouped(int form, int count, const mi355_gemm_pro
     }
     for (int i = count; i < MAX_GROUP; ++i) tbl.g[i] = tbl.g[0];
     // 256x256 tiles (one workgroup per CU) once they cover most of the chip; otherwise 128x128 (two per CU, 4x the tiles)
-    const int cfg = tile_hint ? tile_hint : ((small || tiles256 < 160) ? 1 : 3);
+    const int cfg = tile_hint ? tile_hint : ((small || tiles256 < 160) ? 1 : (form == MI355_GEMM_TN ? 5 : 3));
     hipStream_t s = (hipStream_t)stream;
+    if (cfg == 5) return mi355_gemm_grouped_part5(form, &tbl, out_dtype, s);
     if (cfg == 4) return mi355_gemm_grouped_part4(form, &tbl, out_dtype, s);
     if (cfg == 3) return mi355_gemm_grouped_part3(form, &tbl, out_dtype, s);
     return mi355_gemm_grouped_part1(form, &tbl, out_dtype, s);

@@ -25,6 +25,7 @@ import os
 
 _TILE_OVERRIDE = int(os.environ.get("MI355_GEMM_TILE", "0"))  # profiling knob: force a GEMM tile configuration
 _TILE_BY_FORM = {f: int(os.environ.get("MI355_GEMM_TILE_" + n, "0")) for f, n in ((L.GEMM_NT, "NT"), (L.GEMM_NN, "NN"), (L.GEMM_TN, "TN"))}
+_TILE_NT_PLAIN = int(os.environ.get("MI355_GEMM_TILE_NT_PLAIN", "0"))  # profiling knob: tile of NT launches with the plain epilogue only (the fused forms keep theirs)
 DGRAD_NT = os.environ.get("MI355_DGRAD_NT", "1") != "0"  # 0: dgrad GEMMs in the NN form on the weight as stored (A/B measurements)
 DGRAD_NT_MIN_ROWS = 4096  # below this the transpose pass is not paid back
 _WS = {}
@@ -75,7 +76,8 @@ def gemm(form, a, b, out=None, out_dtype=BF16, bias=None, residual=None, gelu=Fa
     L.call(
         "mi355_gemm_bf16", form, M, N, K, L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), L.ptr(out), out.stride(0),
         L.dt_code(out.dtype), L.ptr(bias), L.ptr(residual), ldr, L.EPI_GELU if gelu else L.EPI_NONE,
-        L.ptr(_workspace(a.device)) if allow_split_k else None, WS_BYTES if allow_split_k else 0, tile or _TILE_BY_FORM[form] or _TILE_OVERRIDE,
+        L.ptr(_workspace(a.device)) if allow_split_k else None, WS_BYTES if allow_split_k else 0,
+        tile or (_TILE_NT_PLAIN if (form == L.GEMM_NT and not gelu and M >= 4096) else 0) or _TILE_BY_FORM[form] or _TILE_OVERRIDE,
     )
     return out
 
@@ -116,7 +118,7 @@ def gemm_grouped(form, problems, tile=0):
             if residual.dtype != odt or tuple(residual.shape) != (M, N):
                 raise ValueError("gemm_grouped: residual must match the output's shape and dtype")
             q.residual, q.ldr = residual.data_ptr(), residual.stride(0)
-    L.call("mi355_gemm_bf16_grouped", form, len(problems), _c.cast(table, _c.c_void_p), L.dt_code(odt), tile or _TILE_BY_FORM[form] or (_TILE_OVERRIDE if _TILE_OVERRIDE in (1, 3, 4) else 0))
+    L.call("mi355_gemm_bf16_grouped", form, len(problems), _c.cast(table, _c.c_void_p), L.dt_code(odt), tile or _TILE_BY_FORM[form] or (_TILE_OVERRIDE if _TILE_OVERRIDE in (1, 3, 4, 5) else 0))
 
 
 # Measured (ViT-B/16 training step, B = 256, same box): fused 65.5 ms, separate kernels 64.1 ms -- erf / tanh in the epilogue sit on the tile's critical
@@ -384,6 +386,28 @@ def attn_bwd(q, k, v, o, do, lse, B, S, Hq, Hkv, D, dq, dk, dv, key_mask=None, c
 FUSE_QNORM_BWD = os.environ.get("MI355_FUSE_QNORM_BWD", "1") != "0"  # A/B knob: 0 = dQ matrix + the separate QK-norm / RoPE backward for every head
 
 
+_ROPE_CS16 = {}  # (cos.data_ptr, sin.data_ptr, version counters) -> compact bf16 table, or None when the table's halves differ
+ROPE_CS16 = os.environ.get("MI355_ROPE_CS16", "1") != "0"  # A/B knob: 0 = the dQ write-out reads the fp32 cos / sin tables
+
+
+def rope_cs16(cos, sin):
+    """[positions][cos[:, :D/2] | sin[:, :D/2]] in bf16 for the fused dQ write-out, or None when the fp32 tables' halves are not identical
+    (checked once per table on the device; the result is cached per table storage and version)."""
+    if not ROPE_CS16:
+        return None
+    key = (cos.data_ptr(), sin.data_ptr(), cos._version, sin._version, tuple(cos.shape))
+    hit = _ROPE_CS16.get(key, False)
+    if hit is not False:
+        return hit
+    h = cos.shape[-1] // 2
+    same = bool(torch.equal(cos[..., :h], cos[..., h:]) and torch.equal(sin[..., :h], sin[..., h:]))  # one host sync per table, at first use
+    tab = torch.cat((cos[..., :h], sin[..., :h]), dim=-1).to(BF16).contiguous() if same else None
+    if len(_ROPE_CS16) > 16:
+        _ROPE_CS16.clear()
+    _ROPE_CS16[key] = tab
+    return tab
+
+
 FUSE_ATTN_DELTA = os.environ.get("MI355_FUSE_ATTN_DELTA", "1") != "0"  # A/B knob: 0 = plain out-projection dgrad + the delta pass inside the attention backward
 
 
@@ -448,12 +472,15 @@ def attn_bwd_qnorm(q, k, v, o, do, lse, B, S, Hq, Hkv, D, dk, dv, qkv, qw, cos, 
     else:
         delta = torch.empty_like(lse)
     scale = D ** -0.5 if scale is None else scale
+    cs16 = rope_cs16(cos, sin)  # plain RoPE tables: compact bf16 coefficients for the write-out (same bits, a quarter of the loads)
+    L.require_gpu(q, cs16)
     parts = L.load().mi355_attn_bwd_qnorm_partials(B, S, Hq)
     part = torch.empty((parts, D), dtype=F32, device=q.device)
     L.call(
         "mi355_attn_bwd_qnorm", B, S, Hq, Hkv, D, L.ptr(q), q.stride(0), L.ptr(k), k.stride(0), L.ptr(v), v.stride(0), L.ptr(o), o.stride(0),
         L.ptr(do), do.stride(0), L.ptr(lse), L.ptr(delta), L.ptr(dk), dk.stride(0), L.ptr(dv), dv.stride(0), L.ptr(key_mask), int(causal) | _ATTN_ABLATE | ready, scale,
         L.ptr(ws), need, L.ptr(qkv), qkv.stride(0), L.ptr(qw), L.ptr(cos), L.ptr(sin), L.ptr(pos), L.ptr(rstd), H, L.ptr(dqkv), dqkv.stride(0), L.ptr(part),
+        L.ptr(cs16),
     )
     # one partial row per workgroup: summed in two fixed-order levels (a single launch over thousands of rows runs on two workgroups)
     dw = torch.empty(D, dtype=F32, device=q.device)

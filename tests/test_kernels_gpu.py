@@ -565,6 +565,19 @@ def test_attention_backward_with_the_query_norm_backward_as_its_write_out(K, B, 
     dqw2 = K.attn_bwd_qnorm(q, k, v, o, do, lse, B, S, Hq, Hkv, D, dk2, dqkv2[:, (Hq + Hkv) * D :], qkv_d, qw_d, cos_d, sin_d, pos_d, rstd, dqkv2, key_mask=km, causal=True)
     assert torch.equal(dqw1, dqw2) and torch.equal(dqkv1[:, :nq], dqkv2[:, :nq])
     assert torch.isfinite(dqkv1.float()).all() and torch.isfinite(dqw1).all()
+    # the compact bf16 coefficient table (plain RoPE: both halves of cos / sin equal) and the fp32 tables give the same bits
+    assert K.rope_cs16(cos_d, sin_d) is not None
+    keep, K.ROPE_CS16 = K.ROPE_CS16, False
+    try:
+        assert K.rope_cs16(cos_d, sin_d) is None
+        dk3, dqkv3 = torch.empty_like(k), torch.zeros_like(qkv_d)
+        dqw3 = K.attn_bwd_qnorm(q, k, v, o, do, lse, B, S, Hq, Hkv, D, dk3, dqkv3[:, (Hq + Hkv) * D :], qkv_d, qw_d, cos_d, sin_d, pos_d, rstd, dqkv3, key_mask=km, causal=True)
+    finally:
+        K.ROPE_CS16 = keep
+    assert torch.equal(dqw1, dqw3) and torch.equal(dqkv1[:, :nq], dqkv3[:, :nq])
+    skew = cos_d.clone()
+    skew[:, D // 2 :] += 1e-3
+    assert K.rope_cs16(skew, sin_d) is None, "tables whose halves differ must take the fp32 path"
 
 
 @pytest.mark.parametrize("B,S,Hq,Hkv", [(6, 709, 4, 2), (9, 500, 3, 1)])
