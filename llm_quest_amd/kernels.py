@@ -25,6 +25,8 @@ import os
 
 _TILE_OVERRIDE = int(os.environ.get("MI355_GEMM_TILE", "0"))  # profiling knob: force a GEMM tile configuration
 _TILE_BY_FORM = {f: int(os.environ.get("MI355_GEMM_TILE_" + n, "0")) for f, n in ((L.GEMM_NT, "NT"), (L.GEMM_NN, "NN"), (L.GEMM_TN, "TN"))}
+_TILE_SWIGLU_FWD = int(os.environ.get("MI355_GEMM_TILE_SWIGLU_FWD", "0"))  # profiling knobs: tile of the two fused SwiGLU GEMMs
+_TILE_SWIGLU_BWD = int(os.environ.get("MI355_GEMM_TILE_SWIGLU_BWD", "0"))
 _TILE_NT_PLAIN = int(os.environ.get("MI355_GEMM_TILE_NT_PLAIN", "0"))  # profiling knob: tile of NT launches with the plain epilogue only (the fused forms keep theirs)
 DGRAD_NT = os.environ.get("MI355_DGRAD_NT", "1") != "0"  # 0: dgrad GEMMs in the NN form on the weight as stored (A/B measurements)
 DGRAD_NT_MIN_ROWS = 4096  # below this the transpose pass is not paid back
@@ -177,7 +179,7 @@ def gemm_gateup_swiglu(x, w_fused, tile=0):
     gu = torch.empty((M, N), dtype=BF16, device=x.device)
     a = torch.empty((M, N // 2), dtype=BF16, device=x.device)
     L.call("mi355_gemm_bf16", L.GEMM_NT, M, N, Kd, L.ptr(x), x.stride(0), L.ptr(w_fused), w_fused.stride(0), L.ptr(gu), gu.stride(0), L.DT_BF16, None,
-           L.ptr(a), a.stride(0), L.EPI_SWIGLU_FWD, None, 0, tile or _TILE_BY_FORM[L.GEMM_NT] or _TILE_OVERRIDE)
+           L.ptr(a), a.stride(0), L.EPI_SWIGLU_FWD, None, 0, tile or _TILE_SWIGLU_FWD or _TILE_BY_FORM[L.GEMM_NT] or _TILE_OVERRIDE)
     return gu, a
 
 
@@ -195,7 +197,7 @@ def gemm_dgrad_swiglu_bwd(dy, w, gu, tile=0):
     if DGRAD_NT and M >= DGRAD_NT_MIN_ROWS:
         wt = transpose(w)  # [F, N_out]: the same product in the K-contiguous form
         L.call("mi355_gemm_bf16", L.GEMM_NT, M, F, Kd, L.ptr(dy), dy.stride(0), L.ptr(wt), wt.stride(0), L.ptr(out), out.stride(0), L.DT_BF16, None,
-               L.ptr(gu), gu.stride(0), L.EPI_SWIGLU_BWD, None, 0, tile or _TILE_BY_FORM[L.GEMM_NT] or _TILE_OVERRIDE)
+               L.ptr(gu), gu.stride(0), L.EPI_SWIGLU_BWD, None, 0, tile or _TILE_SWIGLU_BWD or _TILE_BY_FORM[L.GEMM_NT] or _TILE_OVERRIDE)
         return out
     L.call("mi355_gemm_bf16", L.GEMM_NN, M, F, Kd, L.ptr(dy), dy.stride(0), L.ptr(w), w.stride(0), L.ptr(out), out.stride(0), L.DT_BF16, None,
            L.ptr(gu), gu.stride(0), L.EPI_SWIGLU_BWD, None, 0, tile or _TILE_BY_FORM[L.GEMM_NN] or _TILE_OVERRIDE)
