@@ -1210,23 +1210,54 @@ int check_operands(const char* who, int form, int64_t M, int64_t N, int64_t K, c
 }
 
 // ---------------------------------------------------------------------------------------------- colsum
+// Column sums (bias gradients): a workgroup owns 512 columns x `rows_per_block` rows; a thread keeps 8 adjacent columns, a wave reads one kilobyte
+// of a row per instruction (16-byte loads, whole lines), the four waves take rows r, r+1, r+2, r+3; partial sums meet in LDS and leave as one
+// fp32 atomic per column and workgroup.  (Round 4: the first version read one 2-byte element per thread -- 128-byte row segments -- and ran at
+// 1.8 TB/s: 4.7 ms of the 53-ms ViT-B/16 training step.)
 template <int DT>
 __global__ __launch_bounds__(256) void colsum_kernel(int64_t M, int64_t N, const void* Xv, int64_t ldx, float* out, int rows_per_block) {
-    // block = 256 threads = 64 columns x 4 row-lanes; grid.x over column groups, grid.y over row slabs
-    __shared__ float red[4][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int rl = threadIdx.x >> 6;
+    __shared__ float red[4][512];
+    const int chunk = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int64_t col = (int64_t)blockIdx.x * 512 + chunk * 8;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     const int64_t r1 = min(M, r0 + rows_per_block);
-    float s = 0.f;
-    if (col < N)
-        for (int64_t r = r0 + rl; r < r1; r += 4)
-            s += DT == MI355_DT_BF16 ? bf2f(reinterpret_cast<const bf16_t*>(Xv)[r * ldx + col]) : reinterpret_cast<const float*>(Xv)[r * ldx + col];
-    red[rl][threadIdx.x & 63] = s;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool vec = col + 8 <= N && (ldx & 7) == 0 && ((uintptr_t)Xv & 15) == 0;
+    if (col < N) {
+        for (int64_t r = r0 + rl; r < r1; r += 4) {
+            if constexpr (DT == MI355_DT_BF16) {
+                const bf16_t* px = reinterpret_cast<const bf16_t*>(Xv) + r * ldx + col;
+                if (vec) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(px);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s[2 * e] += __uint_as_float(v[e] << 16);
+                        s[2 * e + 1] += __uint_as_float(v[e] & 0xffff0000u);
+                    }
+                } else {
+                    for (int e = 0; e < 8 && col + e < N; ++e) s[e] += bf2f(px[e]);
+                }
+            } else {
+                const float* px = reinterpret_cast<const float*>(Xv) + r * ldx + col;
+                if (vec) {
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(px), v1 = *reinterpret_cast<const f32x4*>(px + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s[e] += v0[e];
+                        s[4 + e] += v1[e];
+                    }
+                } else {
+                    for (int e = 0; e < 8 && col + e < N; ++e) s[e] += px[e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rl][chunk * 8 + e] = s[e];
     __syncthreads();
-    if (rl == 0 && col < N) {
-        s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        atomicAdd(out + col, s);
+    for (int c = threadIdx.x; c < 512; c += 256) {
+        const int64_t gc = (int64_t)blockIdx.x * 512 + c;
+        if (gc < N) atomicAdd(out + gc, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
     }
 }
 
@@ -1399,8 +1430,10 @@ extern "C" int mi355_colsum(int64_t M, int64_t N, const void* X, int x_dtype, in
             return 2;
         }
     }
-    const int rows_per_block = 512;
-    dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + rows_per_block - 1) / rows_per_block));
+    const int64_t col_blocks = (N + 511) / 512;
+    int rows_per_block = 512;  // enough workgroups to fill the chip a few times over, at least 32 rows each
+    while (rows_per_block > 32 && col_blocks * ((M + rows_per_block - 1) / rows_per_block) < 2048) rows_per_block >>= 1;
+    dim3 grid((unsigned)col_blocks, (unsigned)((M + rows_per_block - 1) / rows_per_block));
     if (x_dtype == MI355_DT_BF16)
         hipLaunchKernelGGL(colsum_kernel<MI355_DT_BF16>, grid, dim3(256), 0, s, M, N, X, ldx, out, rows_per_block);
     else

@@ -152,7 +152,7 @@ def gemm_gelu_dual(x, w, bias=None, tanh=False, tile=0):
 def gemm_dgrad_gelu_bwd(dy, w, y1, tanh=False, tile=0):
     """d(y1) = (dy @ w) * gelu'(y1) in ONE launch (replaces the dgrad gemm + gelu_bwd); w = the following Linear's weight [N_out, F]."""
     if not _FUSE_GELU:
-        return gelu_bwd(y1, gemm(L.GEMM_NN, dy, w, tile=tile), tanh=tanh)
+        return gelu_bwd(y1, dgrad(dy, w) if not tile else gemm(L.GEMM_NN, dy, w, tile=tile), tanh=tanh)  # (dgrad: the NT form on W^T above 4 096 rows, same bits)
     L.require_gpu(dy, w, y1)
     _rowmajor(dy, "dY")
     _rowmajor(w, "W")

@@ -217,11 +217,21 @@ def test_transpose_and_nt_dgrad_match_nn_form(K):
     assert torch.equal(fused, two_step)
 
 
-def test_colsum(K):
+@pytest.mark.parametrize("M,N,dtype", [(1500, 200, BF16), (50432, 768, BF16), (4100, 3075, BF16), (777, 1032, F32), (33, 8, F32)])
+def test_colsum(K, M, N, dtype):
+    """Bias-gradient column sums (mi355_colsum): 16-byte loads on aligned column groups, the scalar tail on the last columns of a width that is no
+    multiple of 8, a row-strided view (the QKV bias reads a slice of a wider matrix), accumulation into an existing gradient."""
     g = torch.Generator().manual_seed(9)
-    x = torch.randn(1500, 200, generator=g).to(BF16)
+    x = torch.randn(M, N, generator=g).to(dtype)
+    want = x.double().sum(0)
     out = K.colsum(dev(x))
-    assert rel_l2(out, x.float().sum(0)) < 1e-5
+    assert rel_l2(out, want) < 2e-6 * math.sqrt(M) + 1e-6
+    K.colsum(dev(x), out=out, accumulate=True)
+    assert rel_l2(out, 2 * want) < 2e-6 * math.sqrt(M) + 1e-6
+    if N >= 64:
+        wide = dev(torch.cat([x, x], dim=1))
+        view = wide[:, N // 2 : N // 2 + (N // 8) * 8 // 2]  # a column slice: pitch != width, start not on a 16-byte boundary when N // 2 is odd
+        assert rel_l2(K.colsum(view), view.double().sum(0)) < 2e-6 * math.sqrt(M) + 1e-6
 
 
 # ----------------------------------------------------------------------------------------------- norms / rope
