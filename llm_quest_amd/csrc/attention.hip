@@ -1190,17 +1190,28 @@ __device__ __forceinline__ float round_bf(float x) { return bf2f(f2bf(x)); }
 #ifndef DQ_ABL
 #define DQ_ABL 0  // profiling builds only: 1 = dS pieces fetched for the first tile only, 2 = K tiles fetched for the first tile only, 4 = no MFMAs / fragment reads, 8 = no write-out
 #endif
+#if DQ_ABL & 16
+__device__ unsigned long long g_dq_prof[32];
+#define DQ_T() __builtin_readcyclecounter()
+#define DQ_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); dqp[i] += now_ - dq_t; dq_t = now_; } while (0)
+#else
+#define DQ_T() 0ull
+#define DQ_MARK(i) do { } while (0)
+#endif
 template <int D, bool FUSE>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_spill_kernel(int B, int S, int Hq, int Hkv, const bf16_t* __restrict__ k, int64_t ldk,
                                                                    const bf16_t* __restrict__ ds, bf16_t* __restrict__ dq, int64_t lddq,
                                                                    int causal, float scale, QkFuse f) {
     using C = Cfg<D>;
-    constexpr int DT = C::DT, DSW = 4096, STAGE = C::TILE + 4 * DSW;  // a wave's dS bytes per 64-key tile: 2 key groups x 2 KiB
-    // Two stages and two workgroups per CU: one workgroup's LDS-DMA issue (~100 cycles per piece and wave when four waves issue together) runs under
-    // the other's MFMAs.  Four stages with one workgroup per CU were slower (249 us against 205 at the headline shape): the loop is bound by that issue
-    // cost and the LDS reads, not by the bytes in flight.
-    constexpr int NST = 2;
-    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
+    constexpr int DT = C::DT, DSW = 4096;  // a wave's dS bytes per 64-key tile: 2 key groups x 2 KiB
+    // Two workgroups per CU (one's LDS-DMA issue and write-out run under the other's tiles) and TWO rings: the K tiles (shared by the four waves, served
+    // by L2: the workgroups of a head read the same rows) two stages deep, the dS blocks (private per wave, straight from HBM, written once by the
+    // dK/dV pass) THREE.  Round-4 stamps (tools/ablate_dq.py on a -DDQ_ABL=16 build) of the two-stage form: a third of a workgroup's cycles waiting
+    // for the dS piece requested one tile (1.8k cycles) earlier -- the loaded HBM latency is twice that.  With two dS tiles in flight the wait is
+    // covered; 2 x 16 + 3 x 16 KiB = 80 KiB per workgroup, i.e. all 160 KiB for the two.  (Four whole stages with one workgroup per CU: 249 us against
+    // 205 at the round-3 headline shape -- the second workgroup is worth more than the depth.)
+    constexpr int KST = 2, DST = 3, DS_BASE = KST * C::TILE, DS_STAGE = 4 * DSW;
+    __shared__ __attribute__((aligned(16))) char smem[KST * C::TILE + DST * DS_STAGE];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nqb = (S + 127) / 128;
@@ -1220,32 +1231,56 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_spill_kernel(int B, int S,
     auto srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(sblk), 0, 0x7fffffff, 0x00020000);
     const unsigned unit = (unsigned)(lane ^ ((lane >> 5) << 2)) * 16;
     auto fetched = [&](int kgrp) { return !(causal && kgrp * 32 > qw + 31) && kgrp * 32 < S; };
-    auto issue = [&](int kt) {
-        char* st_ = smem + (kt % NST) * STAGE;
-        if (!((DQ_ABL & 2) && kt > 0)) dma_tile<D, IMG_TR>(kbase + (int64_t)kt * 64 * ldk, ldk, S - kt * 64, st_, wave, lane);
-        char* mine = st_ + C::TILE + wave * DSW;
+    auto issue_k = [&](int kt) {  // 4 pieces per wave
+        if (!((DQ_ABL & 2) && kt > 0)) dma_tile<D, IMG_TR>(kbase + (int64_t)kt * 64 * ldk, ldk, S - kt * 64, smem + (kt % KST) * C::TILE, wave, lane);
+    };
+    auto issue_ds = [&](int kt) {  // ALWAYS 4 pieces per wave (a key group the dK/dV pass did not write is requested out of range: zero fill, no traffic), so the
+        char* mine = smem + DS_BASE + (kt % DST) * DS_STAGE + wave * DSW;  // counted vmcnt in front of the tile is one constant
 #pragma unroll
-        for (int half = 0; half < 2; ++half)
-            if (fetched(2 * kt + half) && !((DQ_ABL & 1) && kt > 0)) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, LDS_PTR(mine + half * 2048), 16, (unsigned)((2 * kt + half) * 2048) + unit, 0, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, LDS_PTR(mine + half * 2048 + 1024), 16, (unsigned)((2 * kt + half) * 2048 + 1024) + unit, 0, 0, 0);
-            }
+        for (int half = 0; half < 2; ++half) {
+            const bool live = fetched(2 * kt + half) && kt < ntiles && !((DQ_ABL & 1) && kt > 0);
+            const unsigned o0 = live ? (unsigned)((2 * kt + half) * 2048) + unit : OOB;
+            const unsigned o1 = live ? (unsigned)((2 * kt + half) * 2048 + 1024) + unit : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, LDS_PTR(mine + half * 2048), 16, o0, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, LDS_PTR(mine + half * 2048 + 1024), 16, o1, 0, 0, 0);
+        }
     };
     const LaneOff<D> lok = lane_offsets<D>(lane);
     const int g = lane >> 4, q4 = (lane >> 2) & 3, p = lane & 3;
-    const unsigned scol = (unsigned)((g & 1) * 1024 + ((((p & 1) * 32 + 4 * (g >> 1) + q4) ^ ((p & 1) << 2)) * 16) + (p >> 1) * 8) + C::TILE + wave * DSW;
+    const unsigned scol = (unsigned)((g & 1) * 1024 + ((((p & 1) * 32 + 4 * (g >> 1) + q4) ^ ((p & 1) << 2)) * 16) + (p >> 1) * 8) + DS_BASE + wave * DSW;
     const unsigned lds0 = (unsigned)(unsigned long long)LDS_PTR(smem);
     f32x16 acc[DT];
 #pragma unroll
     for (int i = 0; i < DT; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-    for (int t = 0; t < NST - 1 && t < ntiles; ++t) issue(t);
+    [[maybe_unused]] unsigned long long dqp[8] = {};
+    [[maybe_unused]] unsigned long long dq_t = DQ_T();
+    [[maybe_unused]] const unsigned long long dq_t0 = dq_t;
+    // the write-out's coefficient rows are addressed by pos[token]: requested here, a whole main loop ahead (the stamps charged the dependent load ~2.5k cycles)
+    [[maybe_unused]] int pos_pre[4] = {0, 0, 0, 0};
+    if constexpr (FUSE) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int qrow = q0 + (int)(threadIdx.x >> 3) + 32 * it;
+            pos_pre[it] = f.pos[(int64_t)b * S + (qrow < S ? qrow : S - 1)];
+        }
+    }
+    // request order: dS(0) K(0) dS(1) | per tile kt: K(kt+1) dS(kt+2).  In front of tile kt the youngest four requests are dS(kt+1): vmcnt(4) leaves
+    // exactly them in flight (dS(kt) and K(kt) are older and have landed); the last tile has nothing younger
+    issue_ds(0);
+    issue_k(0);
+    issue_ds(1);
     for (int kt = 0; kt < ntiles; ++kt) {
-        wait_vmcnt<0>();               // this wave's pieces of tile kt (the next tile is requested below) ...
-        __builtin_amdgcn_s_barrier();  // ... and everybody's K pieces; the stage refilled next was read one iteration ago
-        if (kt + NST - 1 < ntiles) issue(kt + NST - 1);
-        const unsigned kimg = lds0 + (kt % NST) * STAGE, simg = kimg + scol;
+        wait_vmcnt<4>();               // this wave's pieces of tile kt; the next dS block stays in flight ...
+        DQ_MARK(0);                    // [0] waiting for this wave's DMA
+        __builtin_amdgcn_s_barrier();  // ... and everybody's K pieces; the K stage refilled next was read one iteration ago
+        DQ_MARK(1);                    // [1] per-tile barrier
+        if (kt + 1 < ntiles) issue_k(kt + 1);
+        else issue_ds(ntiles);         // keeps the request count per iteration constant (out of range: zero fill into a dS stage nobody reads again)
+        issue_ds(kt + 2);
+        DQ_MARK(2);                    // [2] DMA issue
+        const unsigned kimg = lds0 + (kt % KST) * C::TILE, simg = lds0 + (kt % DST) * DS_STAGE + scol;
         static_for<2>([&](auto hc) {
             constexpr int half = hc.value;
             if (!fetched(2 * kt + half)) return;
@@ -1269,6 +1304,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_spill_kernel(int B, int S,
                 });
             });
         });
+        DQ_MARK(3);                    // [3] fragment reads + MFMAs
     }
     if constexpr (DQ_ABL & 8) {
         if (acc[0][0] == 12345.678f) f.dwp[0] = acc[1][1] + acc[2][2] + acc[3][3];  // keeps the loop alive
@@ -1287,7 +1323,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_spill_kernel(int B, int S,
                 }
         }
     } else {
-        static_assert(D == 128 && NST * STAGE >= 128 * D * 4, "fused write-out: head_dim 128, the tile stages hold the workgroup's [128][D] fp32 block");
+        static_assert(D == 128 && KST * C::TILE + DST * DS_STAGE >= 128 * D * 4, "fused write-out: head_dim 128, the rings hold the workgroup's [128][D] fp32 block");
+        wait_vmcnt<0>();  // the zero-fill requests behind the last tile must have landed before the rings become the transposition buffer
         // the write-out's own operands (four rows per thread: row slot + 32 it) are requested first -- rows 0 and 1 here, under the transposition,
         // rows 2 and 3 under the arithmetic of rows 0 and 1 -- so the pass pays two memory latencies, not eight
         const int sub = threadIdx.x >> 3, i = (threadIdx.x & 7) * 8;
@@ -1307,20 +1344,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_spill_kernel(int B, int S,
                 in[it].live = qrow < S;
                 in[it].tok = (int64_t)b * S + (in[it].live ? qrow : S - 1);
             }
-            int pp[4];
-#pragma unroll
-            for (int it = 0; it < 4; ++it) pp[it] = f.pos[in[it].tok];
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const bf16_t* xr = f.qkv + in[it].tok * f.ldqkv + (int64_t)hq * D + i;
                 in[it].xa = *reinterpret_cast<const u32x4*>(xr);
                 in[it].xb = *reinterpret_cast<const u32x4*>(xr + D / 2);
                 in[it].r = f.rstd[in[it].tok * f.rstd_heads + hq];
-                const bf16_t* cr = f.cs16 + (int64_t)pp[it] * D + i;
+                const bf16_t* cr = f.cs16 + (int64_t)pos_pre[it] * D + i;
                 in[it].c = *reinterpret_cast<const u32x4*>(cr);
                 in[it].sn = *reinterpret_cast<const u32x4*>(cr + D / 2);
             }
+            DQ_MARK(4);       // [4] write-out operand requests
             __syncthreads();  // every wave is past its last tile: the stages become the transposition buffer
+            DQ_MARK(5);       // [5] waiting for the slowest wave
             float* xs = reinterpret_cast<float*>(smem);
             {
                 const int row = wave * 32 + (lane & 31), hb = lane >> 5;
@@ -1334,6 +1370,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_spill_kernel(int B, int S,
                     }
             }
             __syncthreads();
+            DQ_MARK(6);       // [6] transposition through LDS
             float w1[8], w2[8], dw1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dw2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             {
                 const u32x4 a = *reinterpret_cast<const u32x4*>(f.qw + i), bq = *reinterpret_cast<const u32x4*>(f.qw + D / 2 + i);
@@ -1410,6 +1447,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_spill_kernel(int B, int S,
                 for (int rgn = 0; rgn < 32; ++rgn) sum += xs[rgn * D + threadIdx.x];
                 f.dwp[(int64_t)blockIdx.x * D + threadIdx.x] = sum;
             }
+#if DQ_ABL & 16
+            DQ_MARK(7);       // [7] arithmetic, stores, weight-gradient partial
+            if ((threadIdx.x & 63) == 0 && (wave == 0 || wave == 3) && (blockIdx.x & 15) == 5) {
+                const int o = wave == 0 ? 0 : 16;
+                for (int k = 0; k < 8; ++k) atomicAdd(&g_dq_prof[o + k], dqp[k]);
+                atomicAdd(&g_dq_prof[o + 8], __builtin_readcyclecounter() - dq_t0);
+                atomicAdd(&g_dq_prof[o + 9], 1ull);
+                atomicAdd(&g_dq_prof[o + 10], (unsigned long long)ntiles);
+            }
+#endif
             return;
         }
         struct RowIn {
@@ -1426,7 +1473,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_spill_kernel(int B, int S,
             const int qrow = q0 + sub + 32 * it;
             in[it].live = qrow < S;
             in[it].tok = (int64_t)b * S + (in[it].live ? qrow : S - 1);
-            pp[it] = f.pos[in[it].tok];
+            pp[it] = pos_pre[it];
         }
         auto fetch = [&](int it) {
             const bf16_t* xr = f.qkv + in[it].tok * f.ldqkv + (int64_t)hq * D + i;
@@ -1553,6 +1600,17 @@ int check_common(const char* name, int B, int S, int Hq, int Hkv, int D) {
 
 }  // namespace
 
+#if DQ_ABL & 16
+extern "C" int mi355_debug_dq_prof(unsigned long long* out, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dq_prof), sizeof(unsigned long long) * 32) != hipSuccess) return 2;
+    if (reset) {
+        unsigned long long z[32] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_dq_prof), z, sizeof(z)) != hipSuccess) return 3;
+    }
+    return 0;
+}
+#endif
 #if ATTN_ABL & 16
 extern "C" int mi355_debug_prof(unsigned long long* out, int reset) {
     if (hipDeviceSynchronize() != hipSuccess) return 1;

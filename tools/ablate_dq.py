@@ -41,3 +41,18 @@ def timed(fn, n):
 
 ts = [timed(fused, 20) for _ in range(3)]
 print(f"{os.environ.get('MI355_LIB_PATH', 'default')}: attention backward (delta + dK/dV + dQ/qnorm) B={B}: " + " / ".join(f"{t:.0f}" for t in ts) + " us", flush=True)
+
+if "dqprof" in os.environ.get("MI355_LIB_PATH", ""):
+    import ctypes
+    from llm_quest_amd import _lib as L
+    lib = L.load()
+    out = (ctypes.c_ulonglong * 32)()
+    lib.mi355_debug_dq_prof(out, 1)
+    fused()
+    lib.mi355_debug_dq_prof(out, 0)
+    names = ["DMA wait", "tile barrier", "DMA issue", "reads + MFMA", "write-out requests", "wait for slowest wave", "transposition", "arithmetic + stores + dw"]
+    for w, o in (("wave 0", 0), ("wave 3", 16)):
+        n = max(out[o + 9], 1)
+        print(f"{w}: {n} workgroups sampled, {out[o + 10] / n:.1f} tiles each, {out[o + 8] / n:.0f} cycles per workgroup")
+        for k, nm in enumerate(names):
+            print(f"    {nm:28s} {out[o + k] / n:9.0f} cycles  ({100.0 * out[o + k] / max(out[o + 8], 1):5.1f} %)")
