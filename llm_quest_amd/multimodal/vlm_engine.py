@@ -8,6 +8,8 @@ Qwen3-0.6B as the language model.  Both work here:
   * any other model (the GPT-2 plumbing model on the CPU) takes the generic path, line for line the reference's math.
 """
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -70,6 +72,9 @@ class _FuseFn(torch.autograd.Function):
         K.copy2d(g.view(B, S * d)[:, : nv * d], gv.view(B, nv * d))
         K.copy2d(g.view(B, S * d)[:, nv * d :], gt.view(B, (S - nv) * d))
         return gv, gt
+
+
+KEEP_LOSS_ROWS = os.environ.get("MI355_KEEP_LOSS_ROWS", "1") != "0"  # A/B knob: 0 = every block on the whole sequence, rows gathered behind the final norm
 
 
 class _RowsFn(torch.autograd.Function):
@@ -151,9 +156,12 @@ def vlm_step_loss(vit_model, vlm_model, adapter, images, input_ids, text_attenti
         text_emb = vlm_model.emb_dict(input_ids)
         fused = _FuseFn.apply(vision_emb.to(text_emb.dtype), text_emb)
         mask = torch.cat([torch.ones(B, nv, dtype=torch.bool, device=fused.device), text_attention_mask.to(torch.bool)], dim=1)
-        hidden = vlm_model.forward_hidden(fused, attn_mask=mask, input_embedded=True)
         T = input_ids.shape[1]
-        rows = _RowsFn.apply(hidden, nv - 1, nv - 1 + T)  # the last vision token predicts the first text token
+        if KEEP_LOSS_ROWS:  # the last block's FFN half and the final norm run on the rows the loss reads (the last vision token predicts the first text token)
+            rows = vlm_model.forward_hidden(fused, attn_mask=mask, input_embedded=True, keep_rows=(nv - 1, nv - 1 + T))
+        else:
+            hidden = vlm_model.forward_hidden(fused, attn_mask=mask, input_embedded=True)
+            rows = _RowsFn.apply(hidden, nv - 1, nv - 1 + T)
         targets = input_ids.masked_fill(text_attention_mask == 0, -100)
         return vlm_model.lm_loss(rows.reshape(B * T, -1), targets.reshape(-1))
     text_emb = get_embeddings(input_ids, vlm_model)

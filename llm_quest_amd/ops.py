@@ -141,13 +141,37 @@ def attention_backward(att, arena, h1, ctx, saved, dctx, rt, defer=None, delta=N
 
 
 # ----------------------------------------------------------------------------------------------- Qwen3 block
-def block_forward(blk, x, rt, keep):
+def _take_rows(x2d, B, S, rows):
+    """Rows [lo, hi) of every sample of a token-major [B*S, d] matrix as a contiguous [B*(hi-lo), d] one (one strided device copy)."""
+    lo, hi = rows
+    d = x2d.shape[1]
+    out = torch.empty((B * (hi - lo), d), dtype=x2d.dtype, device=x2d.device)
+    K.copy2d(x2d.view(B, S * d)[:, lo * d : hi * d], out.view(B, (hi - lo) * d))
+    return out
+
+
+def _put_rows(g2d, B, S, rows):
+    """The adjoint: a zero [B*S, d] matrix with ``g2d`` in rows [lo, hi) of every sample."""
+    lo, hi = rows
+    d = g2d.shape[1]
+    full = torch.zeros((B * S, d), dtype=g2d.dtype, device=g2d.device)
+    K.copy2d(g2d.view(B, (hi - lo) * d), full.view(B, S * d)[:, lo * d : hi * d])
+    return full
+
+
+def block_forward(blk, x, rt, keep, rows=None):
+    """``rows`` = (lo, hi): only these rows of every sample are needed downstream (the decoder's LAST block in the early-fusion step: the loss reads the
+    512 rows that predict text tokens, so the 197 others feed nothing once their keys and values have been used).  The attention half runs on the
+    whole sequence, the FFN half -- 60 % of the block's arithmetic -- on the kept rows only, and the block returns [B*(hi-lo), d].  Same results on
+    the kept rows, bit for bit: every kernel of the FFN half works row by row."""
     arena = arena_for(blk)
     att, ffn = blk.att, blk.ffn
     F_ = ffn.lin1.weight.shape[0]
     h1, rstd1 = K.rmsnorm_fwd(x, blk.norm1.weight)
     ctx, att_saved = attention_forward(att, arena, h1, rt)
     x2 = K.gemm(L.GEMM_NT, ctx, att.out_proj.weight, residual=x)
+    if rows is not None:
+        x2 = _take_rows(x2, rt.B, rt.S, rows)
     h2, rstd2 = K.rmsnorm_fwd(x2, blk.norm2.weight)
     if FUSE_SWIGLU_FWD and F_ % 32 == 0:  # the activation is the projection's epilogue (gu is still written: the backward needs it)
         gu, a = K.gemm_gateup_swiglu(h2, arena.fused(ffn.lin1.weight, ffn.lin_gate.weight))
@@ -159,7 +183,7 @@ def block_forward(blk, x, rt, keep):
     return x3, saved
 
 
-def block_backward(blk, saved, dx3, rt):
+def block_backward(blk, saved, dx3, rt, rows=None):
     arena = arena_for(blk)
     att, ffn = blk.att, blk.ffn
     F_ = ffn.lin1.weight.shape[0]
@@ -176,6 +200,8 @@ def block_backward(blk, saved, dx3, rt):
     _wgrad(arena, ffn.lin1.weight, ffn.lin_gate.weight, dgu, h2, wg)
     gview, gacc = _vecgrad(arena, blk.norm2.weight)
     dx2, _ = K.rmsnorm_bwd(x2, blk.norm2.weight, rstd2, dh2, dres=dx3, dw_out=gview, dw_accumulate=gacc)
+    if rows is not None:  # the FFN half ran on the kept rows: the others receive no gradient from it
+        dx2 = _put_rows(dx2, rt.B, rt.S, rows)
     # ---- attention half
     # the softmax backward's row sums (delta) are the epilogue of the out-projection's dgrad when the shape allows
     fused = K.dgrad_attn_delta(dx2, att.out_proj.weight, ctx, att_saved[4], rt.B, rt.S, att.num_heads, att.head_dim)
@@ -198,31 +224,31 @@ class Qwen3BlockFn(torch.autograd.Function):
     it needs; False = inference."""
 
     @staticmethod
-    def forward(ctx, x, blk, rt, keep, *params):
+    def forward(ctx, x, blk, rt, keep, rows, *params):
         B, S, d = x.shape
         x2 = x.reshape(B * S, d)
-        y, saved = block_forward(blk, x2, rt, keep is True)
-        ctx.blk, ctx.rt, ctx.saved, ctx.shape = blk, rt, saved, (B, S, d)
+        y, saved = block_forward(blk, x2, rt, keep is True, rows)
+        ctx.blk, ctx.rt, ctx.saved, ctx.shape, ctx.rows = blk, rt, saved, (B, S, d), rows
         ctx.x_in = x2 if keep == "recompute" else None
-        return y.view(B, S, d)
+        return y.view(B, S if rows is None else rows[1] - rows[0], d)
 
     @staticmethod
     def backward(ctx, dy):
         B, S, d = ctx.shape
         saved = ctx.saved
         if saved is None and ctx.x_in is not None:
-            _, saved = block_forward(ctx.blk, ctx.x_in, ctx.rt, True)
+            _, saved = block_forward(ctx.blk, ctx.x_in, ctx.rt, True, ctx.rows)
             ctx.x_in = None
         if saved is None:
             raise RuntimeError("Qwen3BlockFn: backward through a forward that ran without grad mode")
-        dy2 = dy.reshape(B * S, d)
+        dy2 = dy.reshape(-1, d)
         dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
-        dx = block_backward(ctx.blk, saved, dy2, ctx.rt)
+        dx = block_backward(ctx.blk, saved, dy2, ctx.rt, ctx.rows)
         ctx.saved = None
-        return (dx.view(B, S, d), None, None, None) + (None,) * len(ctx.blk._param_list)
+        return (dx.view(B, S, d), None, None, None, None) + (None,) * len(ctx.blk._param_list)
 
 
-def run_block(blk, x, rt, recompute=False):
+def run_block(blk, x, rt, recompute=False, rows=None):
     if not hasattr(blk, "_param_list"):
         object.__setattr__(blk, "_param_list", list(blk.parameters()))
     L.require_gpu(x)
@@ -231,7 +257,9 @@ def run_block(blk, x, rt, recompute=False):
     keep = torch.is_grad_enabled()
     if keep and recompute:
         keep = "recompute"
-    return Qwen3BlockFn.apply(x, blk, rt, keep, *blk._param_list)
+    if rows is not None and not (0 <= rows[0] < rows[1] <= x.shape[1]):
+        raise ValueError(f"run_block: rows {rows} outside the sequence of length {x.shape[1]}")
+    return Qwen3BlockFn.apply(x, blk, rt, keep, rows, *blk._param_list)
 
 
 # ----------------------------------------------------------------------------------------------- generic pieces

@@ -82,8 +82,10 @@ class Qwen3Model(nn.Module):
         return [blk._arena for blk in reversed(self.trf_blocks)] + [self._top_arena]
 
     # ------------------------------------------------------------------ forward paths
-    def forward_hidden(self, x, attn_mask=None, position_ids=None, input_embedded=False):
-        """Blocks + final norm: (b, s) ids or (b, s, emb) embeddings -> (b, s, emb)."""
+    def forward_hidden(self, x, attn_mask=None, position_ids=None, input_embedded=False, keep_rows=None):
+        """Blocks + final norm: (b, s) ids or (b, s, emb) embeddings -> (b, s, emb).  ``keep_rows`` = (lo, hi): the caller reads only rows
+        [lo, hi) of every sample (the early-fusion loss: the 512 rows that predict text tokens) -- the LAST block then runs its FFN half on those
+        rows only and (b, hi - lo, emb) comes back; the kept rows are the same bits (ops.block_forward)."""
         self._build_arenas()
         L.require_gpu(x)
         if not input_embedded:
@@ -93,8 +95,13 @@ class Qwen3Model(nn.Module):
         B, S, _ = x.shape
         rt = ops.make_runtime(B, S, x.device, self.cos, self.sin, attn_mask, position_ids)
         use_ckpt = self.gradient_checkpointing and self.training and torch.is_grad_enabled()
-        for blk in self.trf_blocks:
-            if use_ckpt:  # activation recomputation inside the block's own autograd node (ops.Qwen3BlockFn)
+        if keep_rows is not None and tuple(keep_rows) == (0, S):
+            keep_rows = None
+        last = len(self.trf_blocks) - 1
+        for i, blk in enumerate(self.trf_blocks):
+            if keep_rows is not None and i == last:
+                x = ops.run_block(blk, x, rt, recompute=use_ckpt, rows=(int(keep_rows[0]), int(keep_rows[1])))
+            elif use_ckpt:  # activation recomputation inside the block's own autograd node (ops.Qwen3BlockFn)
                 x = ops.run_block(blk, x, rt, recompute=True)
             else:
                 x = blk(x, self.mask, self.cos, self.sin, attn_mask, None, position_ids, _runtime=rt)

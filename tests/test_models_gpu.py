@@ -449,6 +449,46 @@ def test_profile_loop_traces_the_hip_training_steps(golden, tmp_path, capsys):
     assert any(not torch.equal(p.detach(), before[n]) for n, p in m.named_parameters())
 
 
+def test_last_block_runs_its_ffn_on_the_rows_the_loss_reads(golden):
+    """``Qwen3Model.forward_hidden(keep_rows=(lo, hi))`` (the early-fusion step: vlm_engine.vlm_step_loss): the last block's FFN half and the final
+    norm run on the kept rows only.  Kept rows of the hidden states: the same bits as the full forward.  Gradients: the other rows contributed
+    exact zeros to every sum, so parameter and input gradients agree to the rounding of a different summation order; with gradient checkpointing too."""
+    t = golden("qwen3_tiny")
+    g = torch.Generator().manual_seed(8)
+    ids = torch.randint(0, 512, (3, 24), generator=g).cuda()
+    am = torch.ones(3, 24, dtype=torch.bool)
+    am[1, 19:] = False
+    am = am.cuda()
+    tgt = torch.randint(0, 512, (3, 13), generator=g).cuda()
+    lo, hi = 6, 19
+
+    def run(keep, ckpt=False):
+        m = make_qwen(t)
+        m.gradient_checkpointing = ckpt
+        emb = m.emb_dict(ids).detach().requires_grad_(True)
+        if keep:
+            rows = m.forward_hidden(emb, attn_mask=am, input_embedded=True, keep_rows=(lo, hi))
+        else:
+            rows = m.forward_hidden(emb, attn_mask=am, input_embedded=True)[:, lo:hi]
+        assert tuple(rows.shape) == (3, hi - lo, emb.shape[-1])
+        loss = m.lm_loss(rows.reshape(-1, rows.shape[-1]), tgt.reshape(-1))
+        loss.backward()
+        return rows.detach().clone(), loss.detach().clone(), emb.grad.clone(), {n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    r0, l0, e0, g0 = run(False)
+    for ckpt in (False, True):
+        r1, l1, e1, g1 = run(True, ckpt)
+        assert torch.equal(r1, r0) and torch.equal(l1, l0)
+        assert rel_l2(e1, e0) < 2e-3
+        assert set(g1) == set(g0)
+        for n in g0:
+            assert rel_l2(g1[n], g0[n]) < 4e-3, (n, rel_l2(g1[n], g0[n]))
+    # the whole-sequence request is the ordinary path
+    m = make_qwen(t)
+    with torch.no_grad():
+        assert torch.equal(m.forward_hidden(ids, keep_rows=(0, 24)), m.forward_hidden(ids))
+
+
 def test_rccl_gradsync_single_rank(golden):
     """The real RCCL path on one GPU: a 1-rank 'nccl' process group, GradSync forced on, so every bucket goes through
     all_reduce(AVG) on the communication stream with the event ordering used at N>1.  Gradients must be unchanged."""
