@@ -218,7 +218,8 @@ def launch_ranks(n):
 # algorithmic FLOP per sample).  They are parity-test configurations of the same kernels, not the headline: the default (``--config 4``) is
 # untouched by them.  No counter files are kept for them, so ``roofline.traffic`` is null.
 OTHER_CONFIGS = {
-    2: dict(metric="img/sec fwd+bwd, ViT-Base/16 224x224, bf16 MFMA operands", unit="img/s", flop=105.4e9, batch=256, units_per_sample=1, max_gpus=1,
+    # batch 332: 65 404 tokens = 255.5 row tiles of 256, so the N = 768 outputs are 768 tiles = three whole rounds of the chip (at 256 images: 591 tiles = 2.3 rounds; 21.9 -> 23.1 %, same box)
+    2: dict(metric="img/sec fwd+bwd, ViT-Base/16 224x224, bf16 MFMA operands", unit="img/s", flop=105.4e9, batch=332, units_per_sample=1, max_gpus=1,
             workload="BASELINE configs[1]: ViT-Base/16 (VIT_BASE_CONFIG, num_classes 100), 224x224, forward + cross entropy + backward of every parameter, "
                      "fp32 master weights / fp32 residual stream / bf16 MFMA operands, no optimizer step"),
     3: dict(metric="tokens/sec fwd+bwd, Qwen3-0.6B dense text-only, seq 1024, bf16", unit="tok/s", flop=4.023e12, batch=64, units_per_sample=1024, max_gpus=1,
@@ -437,7 +438,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, choices=[2, 3, 4, 5], default=4, help="BASELINE.json configuration (1-based, as SURVEY.md numbers them): 4 = the headline VLM early-fusion step "
                     "(default; everything below describes it), 2 = ViT-B/16, 3 = Qwen3-0.6B text-only at S = 1024, 5 = Qwen3.5-style VLM -- the same JSON schema for each")
-    ap.add_argument("--batch", type=int, default=None, help="per-GPU micro-batch (samples); default 160 for the headline (--config 2 / 3 / 5: 256 / 64 / 32).  Headline: 160 x 709 tokens keep 165 GiB of the 288 GB of HBM live; same-box pairs: 64 -> 34.2 / 34.1 %%, "
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU micro-batch (samples); default 160 for the headline (--config 2 / 3 / 5: 332 / 64 / 32).  Headline: 160 x 709 tokens keep 165 GiB of the 288 GB of HBM live; same-box pairs: 64 -> 34.2 / 34.1 %%, "
                     "128 -> +1.4 %%, 160 -> 35.0 / 34.9 %%, 192 -> level with 160 (202 GiB).  More rounds of tiles per launch amortise every launch's fill and tail.  (92 -- every "
                     "launch a whole number of rounds at batch ~64 -- measured the same as 64: the tail tiles of a partial round run faster, the chip is power-limited)")
     ap.add_argument("--cpu-baseline", choices=["auto", "off"], default="auto")

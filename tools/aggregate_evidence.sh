@@ -10,7 +10,7 @@ python tools/pmc_step.py $E/step_fetch $E/step_write 4 profiles/${ROUND}_pmc_tcc
 python tools/pmc_gemm.py profiles/${ROUND}_pmc_tcc_gemm.json $E \
   "NT:$E/nt_gateup_fetch:$E/nt_gateup_write:$M:6144:1024:gemm_bf16_kernel NT tile 2, gate-up forward C[$M,6144] = X[$M,1024] W[6144,1024]^T (plain epilogue)" \
   "NT_dgrad:$E/nt_dgrad_fetch:$E/nt_dgrad_write:$M:1024:6144:gemm_bf16_kernel NT tile 2, gate-up dgrad dX[$M,1024] = dY[$M,6144] (W^T)[1024,6144]^T (the step's form)" \
-  "TN:$E/tn_wgrad_fetch:$E/tn_wgrad_write:6144:1024:$M:gemm_bf16_kernel TN tile 3, gate-up wgrad dW[6144,1024] = dY[$M,6144]^T X[$M,1024]" | tail -1
+  "TN:$E/tn_wgrad_fetch:$E/tn_wgrad_write:6144:1024:$M:gemm_bf16_kernel TN tile 5 (four waves of 128x128), gate-up wgrad dW[6144,1024] = dY[$M,6144]^T X[$M,1024]" | tail -1
 rm -f profiles/${ROUND}_pmc_sq_counters.json
 for l in nt_gateup nt_dgrad tn_wgrad attn; do python tools/pmc_sq.py profiles/${ROUND}_pmc_sq_counters.json ${l}_b$B $E $E/${l}_sq1 $E/${l}_sq2 > /dev/null; done
 cp $(ls $E/trace/*/*kernel_stats.csv) profiles/${ROUND}_kernel_stats_b$B.csv

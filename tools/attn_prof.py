@@ -3,7 +3,7 @@ import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from llm_quest_amd import kernels as K, _lib as L
-B, S, Hq, Hkv, D = 64, 709, 16, 8, 128
+B, S, Hq, Hkv, D = int(sys.argv[1]) if len(sys.argv) > 1 else 64, 709, 16, 8, 128
 r = lambda *s: torch.randn(*s, device="cuda").to(torch.bfloat16)
 qkv = r(B * S, (Hq + 2 * Hkv) * D)
 q, k, v = r(B * S, Hq * D), r(B * S, Hkv * D), qkv[:, (Hq + Hkv) * D:]
