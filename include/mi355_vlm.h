@@ -355,7 +355,11 @@ int mi355_gated_delta_rule_fwd(int B, int S, int Hqk, int Hv, int Dk, int Dv, co
 int64_t mi355_gated_delta_rule_bwd_workspace_bytes(int B, int S, int Hv, int Dk, int Dv);
 int mi355_gated_delta_rule_bwd(int B, int S, int Hqk, int Hv, int Dk, int Dv, const void* q, const void* k, const void* v, int64_t ldv,
                                const float* beta, const float* alpha, const float* checkpoints, const void* d_o, void* dq, void* dk, void* dv,
-                               int64_t lddv, float* dbeta, float* dalpha, void* workspace, int64_t workspace_bytes, void* stream);
+                               int64_t lddv, float* dbeta, float* dalpha, void* workspace, int64_t workspace_bytes, const float* d_final_state,
+                               float* d_initial_state, void* stream);
+/* d_final_state / d_initial_state (optional, fp32 [B, Hv, Dv, Dk], may be the same buffer): the gradient arriving at the forward's final_state
+ * (the state gradient's starting value) and where d(loss) / d(initial_state) is left -- training through a carried recurrent state
+ * (gated_delta_rule(..., prev_state), qwen3_next_attention.py:103-159).  The forward must have run with that initial_state and checkpoints. */
 
 /* out = bf16(silu(float(gate)) * RMSNorm_fp32(float(o)))  (post_norm + output gate, qwen3_5_text_model.py:181-187): o bf16
  * [tokens, H*D], w fp32 [D], gate bf16 at gate[t*ldg + h*D]. */

@@ -81,7 +81,7 @@ SIGNATURES = {
     "mi355_l2norm_bwd": [_L, _I, _I, _P, _L, _P, _P, _L, _P],
     "mi355_gated_delta_rule_fwd": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P],
     "mi355_causal_conv_silu_step": [_I, _I, _I, _P, _L, _P, _P, _P, _P],
-    "mi355_gated_delta_rule_bwd": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _P],
+    "mi355_gated_delta_rule_bwd": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _P, _P, _P],
     "mi355_gated_rmsnorm_fwd": [_L, _I, _I, _P, _P, _P, _L, _P, _P, _F, _P],
     "mi355_gated_rmsnorm_bwd": [_L, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _L, _P, _I, _P],
     # input pipeline (csrc/pipeline.hip)

@@ -744,7 +744,10 @@ __global__ __launch_bounds__(256) void gdr_bwd_kernel(int B, int S, int Hqk, int
                                                       const float* __restrict__ beta, const float* __restrict__ alpha,
                                                       const float* __restrict__ ckpt, int nchunk, const bf16_t* __restrict__ d_o,
                                                       bf16_t* __restrict__ dv, int64_t lddv, float* __restrict__ pdq,
-                                                      float* __restrict__ pdk, float* __restrict__ pdb, float* __restrict__ pda, float qscale) {
+                                                      float* __restrict__ pdk, float* __restrict__ pdb, float* __restrict__ pda, float qscale,
+                                                      const float* d_final_state, float* d_initial_state) {
+    // d_final_state (optional): gradient arriving at the returned last state -- the starting value of the state gradient; d_initial_state (optional):
+    // where the state gradient is left after step 0, i.e. d(loss) / d(carried-in state).  Both fp32 [B, Hv, Dv, DK]; they may be the same buffer.
     constexpr int DK = 16 * CPL, NS = 4 * CPL;
     __shared__ f32x4 park[4][GDR_SUB][CPL][64];  // [wave][step][vector of the lane's 4*CPL state floats][lane]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -770,6 +773,13 @@ __global__ __launch_bounds__(256) void gdr_bwd_kernel(int B, int S, int Hqk, int
     float dS[NS];
 #pragma unroll
     for (int e = 0; e < NS; ++e) dS[e] = 0.f;
+    const int64_t st_off = (((int64_t)b * Hv + h) * Dv + row) * DK + col;  // this lane's 4 x CPL slice of a [B, Hv, Dv, DK] state
+    if (d_final_state) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) dS[r * CPL + j] = d_final_state[st_off + r * DK + j];
+    }
 
     GdrOps<CPL> cur[GDR_SUB], nxt[GDR_SUB];
     float sub[GDR_NSUB][NS], ckN[NS];
@@ -975,6 +985,12 @@ __global__ __launch_bounds__(256) void gdr_bwd_kernel(int B, int S, int Hqk, int
         }
 #pragma unroll
         for (int e = 0; e < NS; ++e) sub[0][e] = ckN[e];
+    }
+    if (d_initial_state) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) d_initial_state[st_off + r * DK + j] = dS[r * CPL + j];
     }
 }
 
@@ -1283,7 +1299,7 @@ extern "C" int64_t mi355_gated_delta_rule_bwd_workspace_bytes(int B, int S, int 
 extern "C" int mi355_gated_delta_rule_bwd(int B, int S, int Hqk, int Hv, int Dk, int Dv, const void* q, const void* k, const void* v, int64_t ldv,
                                           const float* beta, const float* alpha, const float* checkpoints, const void* d_o, void* dq, void* dk,
                                           void* dv, int64_t lddv, float* dbeta, float* dalpha, void* workspace, int64_t workspace_bytes,
-                                          void* stream) {
+                                          const float* d_final_state, float* d_initial_state, void* stream) {
     if (check_gdr(B, S, Hqk, Hv, Dk, Dv)) return 1;
     MI355_REQUIRE(q && k && v && beta && alpha && checkpoints && d_o && dq && dk && dv && dbeta && dalpha && workspace, "gated_delta_rule_bwd: null pointer");
     MI355_REQUIRE(ldv >= (int64_t)Hv * Dv && lddv >= (int64_t)Hv * Dv, "gated_delta_rule_bwd: ld too small");
@@ -1297,9 +1313,9 @@ extern "C" int mi355_gated_delta_rule_bwd(int B, int S, int Hqk, int Hv, int Dk,
     dim3 grid((RG + 3) / 4, Hv, B);
     const float qs = 1.0f / sqrtf((float)Dk);
     if (Dk == 128)
-        gdr_bwd_kernel<8><<<grid, 256, 0, ST(stream)>>>(B, S, Hqk, Hv, Dv, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldv, beta, alpha, checkpoints, nchunk, (const bf16_t*)d_o, (bf16_t*)dv, lddv, pdq, pdk, pdb, pda, qs);
+        gdr_bwd_kernel<8><<<grid, 256, 0, ST(stream)>>>(B, S, Hqk, Hv, Dv, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldv, beta, alpha, checkpoints, nchunk, (const bf16_t*)d_o, (bf16_t*)dv, lddv, pdq, pdk, pdb, pda, qs, d_final_state, d_initial_state);
     else
-        gdr_bwd_kernel<1><<<grid, 256, 0, ST(stream)>>>(B, S, Hqk, Hv, Dv, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldv, beta, alpha, checkpoints, nchunk, (const bf16_t*)d_o, (bf16_t*)dv, lddv, pdq, pdk, pdb, pda, qs);
+        gdr_bwd_kernel<1><<<grid, 256, 0, ST(stream)>>>(B, S, Hqk, Hv, Dv, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldv, beta, alpha, checkpoints, nchunk, (const bf16_t*)d_o, (bf16_t*)dv, lddv, pdq, pdk, pdb, pda, qs, d_final_state, d_initial_state);
     MI355_LAUNCH_CHECK("gated_delta_rule_bwd");
     const int64_t n = (int64_t)B * S * Hqk * Dk + (int64_t)B * S * Hv;
     gdr_bwd_reduce_kernel<<<grid1d(n), 256, 0, ST(stream)>>>(B, S, Hqk, Hv, RG, Dk, pdq, pdk, pdb, pda, (bf16_t*)dq, (bf16_t*)dk, dbeta, dalpha, qs);

@@ -285,9 +285,12 @@ def gated_delta_rule_fwd(q, k, v, beta, alpha, B, S, Hqk, Hv, Dk, Dv, keep=True,
     return o, ck, fin
 
 
-def gated_delta_rule_bwd(q, k, v, beta, alpha, ck, do, dv, B, S, Hqk, Hv, Dk, Dv):
-    """dv: destination view [B*S, Hv*Dv].  Returns (dq, dk bf16 [B*S, Hqk*Dk], dbeta, dalpha fp32 [B*S, Hv])."""
-    L.require_gpu(q, k, v, beta, alpha, ck, do, dv)
+def gated_delta_rule_bwd(q, k, v, beta, alpha, ck, do, dv, B, S, Hqk, Hv, Dk, Dv, d_final=None, want_d_initial=False):
+    """dv: destination view [B*S, Hv*Dv].  Returns (dq, dk bf16 [B*S, Hqk*Dk], dbeta, dalpha fp32 [B*S, Hv]) -- and, with ``want_d_initial``, the fp32
+    [B, Hv, Dv, Dk] gradient of the carried-in state as a fifth element.  ``d_final``: the gradient arriving at the forward's final state (or None)."""
+    L.require_gpu(q, k, v, beta, alpha, ck, do, dv, d_final)
+    if d_final is not None and not (d_final.dtype == F32 and d_final.is_contiguous() and tuple(d_final.shape) == (B, Hv, Dv, Dk)):
+        raise ValueError("gated_delta_rule_bwd: d_final must be contiguous fp32 [B, Hv, Dv, Dk]")
     _check_gdr(q, k, v, beta, alpha, B, S, Hqk, Hv, Dk, Dv)
     _cols(dv, "gated_delta_rule_bwd(dv)")
     if not (do.dtype == BF16 and do.is_contiguous() and tuple(do.shape) == (B * S, Hv * Dv)) or tuple(dv.shape) != (B * S, Hv * Dv):
@@ -303,9 +306,10 @@ def gated_delta_rule_bwd(q, k, v, beta, alpha, ck, do, dv, B, S, Hqk, Hv, Dk, Dv
     dk = torch.empty_like(k)
     dbeta = torch.empty_like(beta)
     dalpha = torch.empty_like(alpha)
+    d_init = torch.empty((B, Hv, Dv, Dk), dtype=F32, device=q.device) if want_d_initial else None
     L.call("mi355_gated_delta_rule_bwd", B, S, Hqk, Hv, Dk, Dv, L.ptr(q), L.ptr(k), L.ptr(v), v.stride(0), L.ptr(beta), L.ptr(alpha), L.ptr(ck), L.ptr(do),
-           L.ptr(dq), L.ptr(dk), L.ptr(dv), dv.stride(0), L.ptr(dbeta), L.ptr(dalpha), L.ptr(ws), ws.numel() * 4)
-    return dq, dk, dbeta, dalpha
+           L.ptr(dq), L.ptr(dk), L.ptr(dv), dv.stride(0), L.ptr(dbeta), L.ptr(dalpha), L.ptr(ws), ws.numel() * 4, L.ptr(d_final), L.ptr(d_init))
+    return (dq, dk, dbeta, dalpha, d_init) if want_d_initial else (dq, dk, dbeta, dalpha)
 
 
 def gated_rmsnorm_fwd(o, w_f32, gate, H, D, eps=1e-6):

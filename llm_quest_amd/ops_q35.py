@@ -107,18 +107,31 @@ def gated_attention_forward(att, arena, h1, rt):
     wq, wk = Q.zc_weight(att.q_norm.scale), Q.zc_weight(att.k_norm.scale)
     q, rstd_q = Q.headnorm_rope_fwd(proj[:, :QG], H, D, 2 * D, wq, rt.cos_t, rt.sin_t, rt.pos, eps=att.q_norm.eps)
     k, rstd_k = Q.headnorm_rope_fwd(proj[:, QG : QG + KV], G, D, D, wk, rt.cos_t, rt.sin_t, rt.pos, eps=att.k_norm.eps)
-    ctx, lse = Q.attn_generic_fwd(q, k, proj[:, QG + KV :], rt.B, rt.S, H, G, D, key_mask=rt.key_mask)
+    drop = None
+    p_drop = float(getattr(att, "p_dropout", 0.0))
+    if p_drop > 0.0:  # SDPA's dropout_p (qwen3_next_attention.py:245-253): Philox masks inside the kernels, regenerated in the backward
+        if rt.key_mask is not None:
+            raise NotImplementedError("GatedAttention: attention dropout together with a padding mask is not built on the HIP path (causal mask only)")
+        from . import rng
+
+        drop = (p_drop,) + rng.draw()
+        ctx, lse = K.attn_dropout_fwd(q, k, proj[:, QG + KV :], rt.B, rt.S, H, G, D, *drop, causal=True)
+    else:
+        ctx, lse = Q.attn_generic_fwd(q, k, proj[:, QG + KV :], rt.B, rt.S, H, G, D, key_mask=rt.key_mask)
     gated = Q.sigmoid_gate_fwd(ctx, proj[:, D:QG], H, D, 2 * D)
-    return gated, (proj, wq, wk, q, k, rstd_q, rstd_k, ctx, lse)
+    return gated, (proj, wq, wk, q, k, rstd_q, rstd_k, ctx, lse, drop)
 
 
 def gated_attention_backward(att, arena, h1, saved, dgated, rt, defer=None):
     H, G, D, QG, KV = _att_dims(att)
-    proj, wq, wk, q, k, rstd_q, rstd_k, ctx, lse = saved
+    proj, wq, wk, q, k, rstd_q, rstd_k, ctx, lse, drop = saved
     dproj = torch.empty_like(proj)
     dctx = Q.sigmoid_gate_bwd(ctx, proj[:, D:QG], H, D, 2 * D, dgated, dproj[:, D:QG], 2 * D)
     dq, dk = torch.empty_like(q), torch.empty_like(k)
-    Q.attn_generic_bwd(q, k, proj[:, QG + KV :], ctx, dctx, lse, rt.B, rt.S, H, G, D, dq, dk, dproj[:, QG + KV :], key_mask=rt.key_mask)
+    if drop is not None:
+        K.attn_dropout_bwd(q, k, proj[:, QG + KV :], ctx, dctx, lse, rt.B, rt.S, H, G, D, dq, dk, dproj[:, QG + KV :], *drop, causal=True)
+    else:
+        Q.attn_generic_bwd(q, k, proj[:, QG + KV :], ctx, dctx, lse, rt.B, rt.S, H, G, D, dq, dk, dproj[:, QG + KV :], key_mask=rt.key_mask)
     dwq = Q.headnorm_rope_bwd(proj[:, :QG], H, D, 2 * D, wq, rt.cos_t, rt.sin_t, rt.pos, rstd_q, dq, dproj[:, :QG], 2 * D)
     dwk = Q.headnorm_rope_bwd(proj[:, QG : QG + KV], G, D, D, wk, rt.cos_t, rt.sin_t, rt.pos, rstd_k, dk, dproj[:, QG : QG + KV], D)
     _bf16_vec_grad(arena, att.q_norm.scale, dwq)
@@ -333,26 +346,32 @@ class GatedDeltaRuleFn(torch.autograd.Function):
     (qwen3_next_attention.py:103-159); q/k heads already expanded to the value heads."""
 
     @staticmethod
-    def forward(ctx, q, k, v, beta, alpha):
+    def forward(ctx, q, k, v, beta, alpha, prev_state=None):
         b, h, s, dk = q.shape
         dv = v.shape[-1]
         tm = lambda t: t.permute(0, 2, 1, 3).reshape(b * s, -1).contiguous()
         q2, k2, v2 = tm(q.to(BF16)), tm(k.to(BF16)), tm(v.to(BF16))
         be = beta.to(F32).permute(0, 2, 1).reshape(b * s, h).contiguous()
         al = alpha.to(F32).permute(0, 2, 1).reshape(b * s, h).contiguous()
-        o, ck, fin = Q.gated_delta_rule_fwd(q2, k2, v2, be, al, b, s, h, h, dk, dv, keep=True, want_state=True)
+        # a carried-in state (reference :103: prev_state) is copied: the kernel advances the state in place, the caller's tensor stays as it was
+        state = None if prev_state is None else prev_state.detach().to(F32).contiguous().clone()
+        o, ck, fin = Q.gated_delta_rule_fwd(q2, k2, v2, be, al, b, s, h, h, dk, dv, keep=True, want_state=True, state=state)
         ctx.saved = (q2, k2, v2, be, al, ck)
-        ctx.meta = (b, h, s, dk, dv, q.dtype, k.dtype, v.dtype, beta.dtype, alpha.dtype)
-        ctx.mark_non_differentiable(fin)
+        ctx.meta = (b, h, s, dk, dv, q.dtype, k.dtype, v.dtype, beta.dtype, alpha.dtype, None if prev_state is None else prev_state.dtype)
+        ctx.set_materialize_grads(False)  # an unused last state arrives as None, not as a zero tensor the kernel would have to read
         return o.view(b, s, h, dv).permute(0, 2, 1, 3).to(q.dtype), fin
 
     @staticmethod
-    def backward(ctx, do, _dstate):
+    def backward(ctx, do, dstate):
         q2, k2, v2, be, al, ck = ctx.saved
-        b, h, s, dk, dv, qd, kd, vd, bd, ad = ctx.meta
+        b, h, s, dk, dv, qd, kd, vd, bd, ad, sd = ctx.meta
+        if do is None:
+            do = torch.zeros((b, h, s, dv), dtype=BF16, device=q2.device)
         do2 = do.to(BF16).permute(0, 2, 1, 3).reshape(b * s, h * dv).contiguous()
         dv2 = torch.empty_like(v2)
-        dq, dk_, dbe, dal = Q.gated_delta_rule_bwd(q2, k2, v2, be, al, ck, do2, dv2, b, s, h, h, dk, dv)
+        d_final = None if dstate is None else dstate.to(F32).contiguous()
+        res = Q.gated_delta_rule_bwd(q2, k2, v2, be, al, ck, do2, dv2, b, s, h, h, dk, dv, d_final=d_final, want_d_initial=sd is not None)
+        dq, dk_, dbe, dal = res[:4]
         hm = lambda t, d: t.view(b, s, h, d).permute(0, 2, 1, 3)
         hs = lambda t: t.view(b, s, h).permute(0, 2, 1)
-        return hm(dq, dk).to(qd), hm(dk_, dk).to(kd), hm(dv2, dv).to(vd), hs(dbe).to(bd), hs(dal).to(ad)
+        return hm(dq, dk).to(qd), hm(dk_, dk).to(kd), hm(dv2, dv).to(vd), hs(dbe).to(bd), hs(dal).to(ad), (res[4].to(sd) if sd is not None else None)

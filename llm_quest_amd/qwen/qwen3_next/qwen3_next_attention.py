@@ -49,11 +49,11 @@ def gated_delta_rule(queries, keys, values, beta, alpha, prev_state=None):
     """Reference :103-159.  (b, h, s, d) operands, beta / alpha (b, h, s); returns (attn_output, last_state).  Differentiable."""
     L.require_gpu(queries, keys, values, beta, alpha)
     if prev_state is not None:
-        # a carried-in recurrent state (b, h, v_head_dim, qk_head_dim): prefill continuation / decode.  Forward only -- the backward pass replays
-        # from its own checkpoints and has no d(prev_state); the returned state is a new tensor, prev_state is left as it was (as upstream).
-        if torch.is_grad_enabled() and any(t.requires_grad for t in (queries, keys, values, beta, alpha, prev_state)):
-            raise NotImplementedError("gated_delta_rule: training through a carried-in recurrent state is not built (forward / no_grad only)")
+        # a carried-in recurrent state (b, h, v_head_dim, qk_head_dim): prefill continuation / decode, or training through it (the backward takes the
+        # gradient arriving at the returned state and leaves d(prev_state)); the returned state is a new tensor, prev_state is left as it was (as upstream)
         L.require_gpu(prev_state)
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (queries, keys, values, beta, alpha, prev_state)):
+            return ops_q35.GatedDeltaRuleFn.apply(queries, keys, values, beta, alpha, prev_state)
         b, h, s, dk = queries.shape
         dv = values.shape[-1]
         tm = lambda t: t.permute(0, 2, 1, 3).reshape(b * s, -1).contiguous()
@@ -80,9 +80,11 @@ class GatedAttention(nn.Module):
         self.d_out = self.num_heads * self.head_dim
         self.dtype = cfg["dtype"]
         self.num_repeat = self.num_heads // self.num_kv_groups
-        self.p_dropout = cfg["p_dropout"] if cfg["training"] else 0.0
-        if self.p_dropout:
-            raise NotImplementedError("attention dropout is not on the HIP path (the Qwen3.5 configs use p_dropout = 0)")
+        # as upstream (:181): dropout_p of the SDPA call whenever the CONFIG says training.  On the HIP path the weights are dropped inside the attention
+        # kernels (Philox masks regenerated in the backward, llm_quest_amd/rng.py); built for the causal mask alone -- with a padding mask it raises
+        self.p_dropout = float(cfg["p_dropout"]) if cfg["training"] else 0.0
+        if not 0.0 <= self.p_dropout < 1.0:
+            raise ValueError(f"dropout probability has to be in [0, 1), got {self.p_dropout}")
         # w_queries_gate | w_keys | w_values are adjacent in the block's arena: one projection GEMM
         self.w_queries_gate = nn.Linear(self.d_in, self.d_out * 2, bias=False, dtype=self.dtype)
         self.w_keys = nn.Linear(self.d_in, self.num_kv_groups * self.head_dim, bias=False, dtype=self.dtype)

@@ -87,9 +87,10 @@ def causal_depthwise_conv_silu(x, w):
 
 
 # ------------------------------------------------------------------------------------------------- modules
-def gated_attention(sd, pre, cfg, x, allow, cos, sin, position_ids, attn_mask):
+def gated_attention(sd, pre, cfg, x, allow, cos, sin, position_ids, attn_mask, att_mul=None):
     """MRoPEGatedAttention.forward / GatedAttention.forward (qwen3_5_text_model.py:205-265, qwen3_next_attention.py:204-261).
-    allow: (ctx, ctx) bool, True = may attend (the model's inverted causal buffer)."""
+    allow: (ctx, ctx) bool, True = may attend (the model's inverted causal buffer).  ``att_mul`` stands for SDPA's ``dropout_p`` (:245-253)
+    with the mask given: a (b, heads, s, s) tensor of 0 or 1 / (1 - p) applied to the softmax weights."""
     b, s, _ = x.shape
     H, G, D = cfg["n_heads"], cfg["num_kv_groups"], cfg["head_dim"]
     qg = F.linear(x, sd[pre + "w_queries_gate.weight"]).view(b, s, H, 2 * D)
@@ -108,7 +109,13 @@ def gated_attention(sd, pre, cfg, x, allow, cos, sin, position_ids, attn_mask):
     m = allow[:s, :s]
     if attn_mask is not None:  # as upstream: OR of the allow-mask with the inverted padding mask
         m = m.view(1, 1, s, s) | ~attn_mask.bool().view(b, 1, 1, s)
-    ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=m, is_causal=False, dropout_p=0.0, enable_gqa=True)
+    if att_mul is None:
+        ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=m, is_causal=False, dropout_p=0.0, enable_gqa=True)
+    else:  # the math SDPA performs, with the dropout multiplier in the place SDPA applies it (after the softmax, before the product with V)
+        kk, vv = k.repeat_interleave(H // G, dim=1), v.repeat_interleave(H // G, dim=1)
+        sc = (q.float() @ kk.float().mT) * D ** -0.5
+        w = torch.softmax(sc.masked_fill(~m, float("-inf")), dim=-1) * att_mul
+        ctx = (w @ vv.float()).to(q.dtype)
     ctx = ctx.transpose(1, 2).contiguous().view(b, s, H * D) * gate_out
     return F.linear(ctx, sd[pre + "out_proj.weight"])
 

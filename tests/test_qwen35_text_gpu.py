@@ -478,7 +478,7 @@ def test_functional_gated_delta_rule_has_the_reference_signature(golden):
 
 def test_functional_gated_delta_rule_carries_a_previous_state(golden):
     """prev_state (reference :103-159): running the sequence in two pieces, the second from the first piece's state, gives the one-piece result;
-    prev_state itself is left untouched and training through it is refused loudly."""
+    prev_state itself is left untouched (training through it: test_gated_delta_rule_trains_through_a_carried_state)."""
     from llm_quest_amd.qwen.qwen3_next.qwen3_next_attention import gated_delta_rule
 
     t = golden("qwen35_text_tiny")
@@ -493,8 +493,8 @@ def test_functional_gated_delta_rule_carries_a_previous_state(golden):
     assert torch.equal(st1, keep), "prev_state must not be modified"
     assert torch.equal(o1, o_all[:, :, :cut]) and ulp_diff(o2, o_all[:, :, cut:].contiguous()) <= 1 and rel_l2(st2, st_all) < 1e-6
     assert ulp_diff(torch.cat((o1, o2), 2), t["gdr.out"]) <= 1 and rel_l2(st2, t["gdr.state"]) < 1e-5
-    with pytest.raises(NotImplementedError, match="carried-in"):
-        gated_delta_rule(q.requires_grad_(True), k, v, beta, alpha, prev_state=st1)
+    o3, st3 = gated_delta_rule(q[:, :, cut:].clone().requires_grad_(True), k[:, :, cut:], v[:, :, cut:], beta[:, :, cut:], alpha[:, :, cut:], prev_state=st1)
+    assert torch.equal(o3.detach(), o2) and torch.equal(st3.detach(), st2) and torch.equal(st1, keep), "the differentiable path computes the same forward"
 
 
 def test_text_model_loss_path_and_determinism():
@@ -596,3 +596,116 @@ def test_rccl_gradsync_qwen35_single_rank():
         dist.destroy_process_group()
         for m in vlm.language_model.trf_blocks:
             object.__setattr__(m, "_grad_ready", None)
+
+
+def test_gated_attention_with_attention_dropout_given_the_mask():
+    """``GatedAttention`` with ``p_dropout`` > 0 under ``training`` (reference qwen3_next_attention.py:181,245-253: SDPA's ``dropout_p``): the weights are
+    dropped inside the attention kernels by Philox masks that the backward regenerates.  Output and every gradient against the oracle's fp32 twin
+    evaluated with the SAME mask (oracle/dropout.py); a repeat with the same (seed, offset) is bit-identical, another offset is not; with a padding mask
+    the combination raises instead of silently ignoring the dropout."""
+    from llm_quest_amd import rng
+    from llm_quest_amd.common.buffers import GlobalBuffers
+    from llm_quest_amd.qwen.qwen3_next.qwen3_next_attention import GatedAttention
+    from oracle import dropout as OD
+
+    torch.manual_seed(21)
+    p, seed = 0.2, 4242
+    cfg = dict(emb_dim=64, n_heads=2, num_kv_groups=1, head_dim=32, rope_base=10_000, partial_rope_factor=0.5, context_length=64, dtype=BF16,
+               p_dropout=p, training=True, mrope_section=[3, 3, 2])
+    att = GatedAttention(cfg)
+    assert att.p_dropout == p and GatedAttention({**cfg, "training": False}).p_dropout == 0.0
+    with torch.no_grad():
+        for n_, p_ in att.named_parameters():
+            if n_.endswith("scale"):
+                p_.add_((0.1 * torch.randn(p_.shape)).to(p_.dtype))
+    sd = {"a." + k: v.detach().clone() for k, v in att.state_dict().items()}
+    b, s = 2, 21
+    x = torch.randn(b, s, 64).to(BF16)
+    g = torch.randn(b, s, 64).to(BF16)
+    cos, sin = GlobalBuffers.get_rope_params(64, cfg["rope_base"], 32, rotation_factor=0.5)
+    allow = ~GlobalBuffers.get_causal_mask(64)
+    att = att.cuda().train()
+
+    def run(offset):
+        rng.manual(seed, offset)
+        try:
+            xd = x.cuda().requires_grad_(True)
+            for p_ in att.parameters():
+                p_.grad = None
+            y = att(xd, allow.cuda(), cos.cuda(), sin.cuda())
+            y.backward(g.cuda())
+        finally:
+            rng.follow_torch()
+        return y.detach(), xd.grad.clone(), {n_: p_.grad.detach().float().clone() for n_, p_ in att.named_parameters()}
+
+    y, dx, grads = run(0)
+    y2, dx2, _ = run(0)
+    y3, _, _ = run(1)
+    assert torch.equal(y, y2) and torch.equal(dx, dx2) and not torch.equal(y, y3)
+    mul = OD.attention_multiplier(b, 2, s, p, seed, 0)
+    tw = {k: (v.float().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    xf = x.float().requires_grad_(True)
+    ref = OT.gated_attention(tw, "a.", cfg, xf, allow, cos, sin, None, None, att_mul=mul)
+    ref.backward(g.float())
+    assert rel_l2(y, ref) < 2e-2, rel_l2(y, ref)
+    assert rel_l2(ref, OT.gated_attention(tw, "a.", cfg, xf, allow, cos, sin, None, None)) > 5e-2  # the masks really acted
+    assert rel_l2(dx, xf.grad) < 3e-2, rel_l2(dx, xf.grad)
+    for n_, gr in grads.items():
+        assert rel_l2(gr, tw["a." + n_].grad) < 4e-2, (n_, rel_l2(gr, tw["a." + n_].grad))
+    am = torch.ones(b, s, dtype=torch.bool)
+    am[0, 15:] = False
+    with pytest.raises(NotImplementedError):
+        att(x.cuda(), allow.cuda(), cos.cuda(), sin.cuda(), attn_mask=am.cuda())
+
+
+@pytest.mark.parametrize("dk,dv,s1,s2", [(16, 16, 12, 9), (128, 128, 21, 20)])
+def test_gated_delta_rule_trains_through_a_carried_state(dk, dv, s1, s2):
+    """``gated_delta_rule(..., prev_state)`` under autograd (reference qwen3_next_attention.py:103-159: the recurrence simply starts from ``prev_state`` and
+    returns the last state, both differentiable): a sequence cut in two -- the second call starts from the first one's state -- must give the gradients
+    of the uncut sequence (the backward of the second half leaves d(prev_state), the backward of the first half starts from it), and both must match the
+    oracle's recurrence under fp32 autograd, including the gradient of a carried-in state and of a loss on the returned state."""
+    from llm_quest_amd.qwen.qwen3_next.qwen3_next_attention import gated_delta_rule
+
+    torch.manual_seed(31)
+    b, h, s = 2, 4, s1 + s2
+    nrm = lambda t: torch.nn.functional.normalize(t, dim=-1)
+    q, k = nrm(torch.randn(b, h, s, dk)).to(BF16), nrm(torch.randn(b, h, s, dk)).to(BF16)
+    v = torch.randn(b, h, s, dv).to(BF16)
+    beta = torch.rand(b, h, s)
+    alpha = 0.5 + 0.5 * torch.rand(b, h, s)
+    s0 = 0.1 * torch.randn(b, h, dv, dk)
+    go = torch.randn(b, h, s, dv)
+    gs = 0.1 * torch.randn(b, h, dv, dk)
+
+    # oracle: the recurrence in fp32 autograd, from the carried-in state
+    ins = [t.clone().float().requires_grad_(True) for t in (q, k, v, beta, alpha, s0)]
+    qf, kf, vf, bf, af, sf = ins
+    st, outs = sf, []
+    for t in range(s):
+        st = af[:, :, t, None, None] * st
+        u = bf[:, :, t, None] * (vf[:, :, t] - (st * kf[:, :, t, None, :]).sum(-1))
+        st = st + u[..., None] * kf[:, :, t, None, :]
+        outs.append((st * (qf[:, :, t, None, :] * dk ** -0.5)).sum(-1))
+    o_ref = torch.stack(outs, dim=2)
+    ((o_ref * go).sum() + (st * gs).sum()).backward()
+
+    def leaves():
+        return [t.clone().cuda().requires_grad_(True) for t in (q, k, v, beta, alpha, s0)]
+
+    # one call from the carried-in state
+    a = leaves()
+    o1, f1 = gated_delta_rule(*a[:5], prev_state=a[5])
+    ((o1.float() * go.cuda()).sum() + (f1 * gs.cuda()).sum()).backward()
+    assert rel_l2(o1, o_ref) < 1e-2 and rel_l2(f1, st) < 2e-3
+    for name, mine, ref in zip(("q", "k", "v", "beta", "alpha", "prev_state"), a, ins):
+        assert mine.grad is not None, name
+        assert rel_l2(mine.grad, ref.grad) < 1.5e-2, (name, rel_l2(mine.grad, ref.grad))
+    # the same sequence cut in two: the state gradient crosses the cut
+    c = leaves()
+    cut = lambda t, lo, hi: t[:, :, lo:hi]
+    oa, fa = gated_delta_rule(*(cut(t, 0, s1) for t in c[:5]), prev_state=c[5])
+    ob, fb = gated_delta_rule(*(cut(t, s1, s) for t in c[:5]), prev_state=fa)
+    ((torch.cat([oa, ob], dim=2).float() * go.cuda()).sum() + (fb * gs.cuda()).sum()).backward()
+    assert torch.equal(torch.cat([oa, ob], dim=2), o1) or rel_l2(torch.cat([oa, ob], dim=2), o1) < 2e-3
+    for name, two, one in zip(("q", "k", "v", "beta", "alpha", "prev_state"), c, a):
+        assert rel_l2(two.grad, one.grad) < 6e-3, (name, rel_l2(two.grad, one.grad))
