@@ -756,6 +756,18 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
 
     }
     if (extra_barrier) __builtin_amdgcn_s_barrier();
+#ifdef GEMM_EPI_ABL  // profiling builds only (tools/build_variant.sh epi1 gemm_p2 "-DGEMM_EPI_ABL=1", tools/time_nt_shapes.py): no write-out at all -- what is left is
+    // prologue + main loop.  Round 4, batch 160: QKV 907 -> 767 us, gate-up + SwiGLU 1 490 -> 1 100, down dgrad + SwiGLU backward 975 -> 575, dctx 455 -> 368.
+    if (GEMM_EPI_ABL & 1) {
+        float keep = 0.f;
+#pragma unroll
+        for (int i = 0; i < T::FM; ++i)
+#pragma unroll
+            for (int j = 0; j < T::FN; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (keep == 12345.678f) reinterpret_cast<float*>(p.C)[0] = keep;  // keeps the main loop alive
+        return;
+    }
+#endif
     // ---- epilogue: acc -> LDS (fp32, 64x64 per wave at a time) -> coalesced rows ---------------------------------
     __syncthreads();
     float* stg = reinterpret_cast<float*>(smem) + wave * 64 * EPI_LD;
