@@ -78,6 +78,16 @@ __device__ unsigned long long g_gemm_prof[32];
 #define GP_ADD(i, t0) do { } while (0)
 #endif
 
+#ifndef GEMM_TL
+#define GEMM_TL 0  // profiling builds only: per-workgroup wall-clock stamps (100 MHz s_memrealtime) of prologue / main loop / write-out, tools/gemm_timeline.py
+#endif
+#if GEMM_TL
+__device__ unsigned long long g_gemm_tl[32768][8];
+#define TL_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 32768) g_gemm_tl[blockIdx.x][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TL_STAMP(i) do { } while (0)
+#endif
+
 struct GemmParams {
     const bf16_t* A;
     const bf16_t* B;
@@ -221,6 +231,13 @@ template <class T, bool A_TR, bool B_TR, int OUT_DT>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, const int split, char* smem) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    TL_STAMP(0);
+#if GEMM_TL
+    if (threadIdx.x == 0 && blockIdx.x < 32768) {
+        g_gemm_tl[blockIdx.x][6] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);  // XCC_ID, HW_ID
+        g_gemm_tl[blockIdx.x][7] = (unsigned long long)pid;
+    }
+#endif
 
     // ---- tile index -> (tm, tn): row super-groups ----------------------------------------------------
     // super-group height by in-step A/B on the VLM step (ms/step, two runs each): 2: 245.9 / 246.2, 3: 243.8 / 243.8, 4: 245.3 / 245.3, 6: 243.8 / 244.3,
@@ -727,6 +744,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
     if (t0 < nt) {
         wait_tile(nt - 1 - t0);
         __builtin_amdgcn_s_barrier();
+        TL_STAMP(1);
         if (t0 + T::NS - 1 < nt) issue_tile(t0 + T::NS - 1, T::NS - 1);
         loadB(b0, smem + T::A_BYTES, 0);
         loadA(aE, smem, 0, 0);
@@ -756,6 +774,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
 
     }
     if (extra_barrier) __builtin_amdgcn_s_barrier();
+    TL_STAMP(2);
 #ifdef GEMM_EPI_ABL  // profiling builds only (tools/build_variant.sh epi1 gemm_p2 "-DGEMM_EPI_ABL=1", tools/time_nt_shapes.py): no write-out at all -- what is left is
     // prologue + main loop.  Round 4, batch 160: QKV 907 -> 767 us, gate-up + SwiGLU 1 490 -> 1 100, down dgrad + SwiGLU backward 975 -> 575, dctx 455 -> 368.
     if (GEMM_EPI_ABL & 1) {
@@ -770,6 +789,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
 #endif
     // ---- epilogue: acc -> LDS (fp32, 64x64 per wave at a time) -> coalesced rows ---------------------------------
     __syncthreads();
+    TL_STAMP(3);
     float* stg = reinterpret_cast<float*>(smem) + wave * 64 * EPI_LD;
     // "No fused form" and "this 64x64 sub-block lies inside the matrix and is 16-byte addressable" are resolved once, outside the store
     // passes: the plain epilogue (with or without bias / residual) gets a straight-line copy of them for interior sub-blocks.  With the kind
@@ -1004,6 +1024,9 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
                                     u32x4 o;
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) o[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+#if defined(GEMM_EPI_ABL) && (GEMM_EPI_ABL & 2)  // profiling: the whole write-out except the store instruction itself
+                                    if (o[0] == 0x7fc12345u && p.M < 0)
+#endif
                                     *reinterpret_cast<u32x4*>(c) = o;
                                 } else {
                                     for (int e = 0; e < nvalid; ++e) c[e] = f2bf(v[e] + (r ? bf2f(r[e]) : 0.f));
@@ -1071,6 +1094,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
     } else {
         run_epilogue(std::integral_constant<int, -1>{});  // other fused forms: kind read at run time, bounds checked per row
     }
+#if GEMM_TL
+    TL_STAMP(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TL_STAMP(5);
+#endif
 }
 
 template <class T, bool A_TR, bool B_TR, int OUT_DT>
@@ -1080,6 +1108,183 @@ __global__ __launch_bounds__(T::NTHREADS, T::MIN_WAVES) void gemm_bf16_kernel(Ge
     const int split = blockIdx.x / nwg;
     gemm_tile<T, A_TR, B_TR, OUT_DT>(p, xcd_chunked(blockIdx.x - split * nwg, nwg), split, smem);
 }
+
+// ---------------------------------------------------------------------------------------------- persistent NT kernel (tile hint 7)
+// tools/gemm_timeline.py (per-workgroup wall-clock stamps, round 4) on the QKV projection of the step, 256x256 tile, K = 1024: of a tile's 31.0 us turn on its CU the
+// main loop is 24.8; the rest is prologue 1.9 (entry -> first K-tile landed), barrier 0.6, write-out 2.45 (LDS-bandwidth: 512 KiB of fp32 staging traffic per tile),
+// stores retiring 0.5 and 0.8 between a workgroup's end and its successor's entry.  This kernel keeps ONE workgroup per CU alive over its share of the tiles:
+//   * the K-tile stream runs across tile boundaries (the last two barriers of a tile request the next tile's first two K-tiles), so there is no prologue, no
+//     retire wait and no workgroup turnover;
+//   * the write-out stages through a 32-KiB region BESIDE the two stages (4 KiB per wave: 32 rows x 64 columns of packed bf16 at a time, swizzled, not padded), so it
+//     needs no barrier and does not collide with the stream; the B fragment is the MFMA's first operand, so a lane holds four consecutive columns of a row and
+//     packs them itself: a quarter of the LDS bytes of the fp32 staging.
+// Results are bit-identical to gemm_bf16_kernel (same MFMA sequence per output, same rounding).  NT form, bf16 output, K % 64 == 0, N % 8 == 0, no bias.
+#if GEMM_PART == 2 || !defined(GEMM_PART)
+#if GEMM_TL
+#define TLQ(q, i) do { if (threadIdx.x == 0 && (q) < 32768) g_gemm_tl[q][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TLQ(q, i) do { } while (0)
+#endif
+template <int KIND>
+__global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmParams p, int ntiles) {
+    using T = Cfg256;
+    constexpr int BK = 64, HM = T::FM / 2;
+    static_assert(T::A_PPW == 4 && T::B_PPW == 4 && T::FM == 8 && T::FN == 4 && T::NS == 2, "written for 8 waves of 128x64 on two 64-KiB stages");
+    __shared__ __attribute__((aligned(16))) char smem[2 * T::STAGE + 32768];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char* const stg = smem + 2 * T::STAGE + wave * 4096;
+    const int wr0 = (wave / T::WN) * T::WTM, wc0 = (wave % T::WN) * T::WTN;
+    const int nt = (int)(p.K / BK);
+    const int G = gridDim.x;
+
+    auto origin = [&](int q, int64_t& m0, int64_t& n0) {
+        const int pid = xcd_chunked(q, ntiles);
+        constexpr int GROUP_M = 6;
+        const int in_group = GROUP_M * p.tiles_n;
+        const int first_m = (pid / in_group) * GROUP_M;
+        const int gsz = min(p.tiles_m - first_m, GROUP_M);
+        m0 = (int64_t)(first_m + (pid % in_group) % gsz) * T::BM;
+        n0 = (int64_t)((pid % in_group) / gsz) * T::BN;
+    };
+    // ---- the request side of the stream: tile qi, K-tile ti, element number si (stage si & 1)
+    unsigned voffA[T::A_PPW], voffB[T::B_PPW];
+    const bf16_t *baseA = p.A, *baseB = p.B;
+    auto plan = [&](int q) {
+        int64_t m0, n0;
+        origin(q, m0, n0);
+        int unusedA[T::A_PPW], unusedB[T::B_PPW];
+        piece_offsets<false, T::BM, BK, T::A_PPW>(wave, lane, p.lda, p.M - m0, voffA, unusedA);
+        piece_offsets<false, T::BN, BK, T::B_PPW>(wave, lane, p.ldb, p.N - n0, voffB, unusedB);
+        baseA = uniform_ptr(p.A + m0 * p.lda);
+        baseB = uniform_ptr(p.B + n0 * p.ldb);
+    };
+    int qi = blockIdx.x, ti = 0, si = 0;
+    auto request_next = [&]() {
+        if (qi < ntiles) {
+            char* dA = smem + (si & 1) * T::STAGE + wave * T::A_PPW * 1024;
+            char* dB = smem + (si & 1) * T::STAGE + T::A_BYTES + wave * T::B_PPW * 1024;
+            const bf16_t* pa = baseA + (int64_t)ti * BK;
+            const bf16_t* pb = baseB + (int64_t)ti * BK;
+#pragma unroll
+            for (int j = 0; j < T::A_PPW; ++j) dma_piece(pa, voffA[j], dA + j * 1024);
+#pragma unroll
+            for (int j = 0; j < T::B_PPW; ++j) dma_piece(pb, voffB[j], dB + j * 1024);
+            if (++ti == nt) {
+                ti = 0;
+                qi += G;
+                if (qi < ntiles) plan(qi);
+            }
+        }
+        ++si;
+    };
+
+    int qc = blockIdx.x, sc = 0;  // the multiplying side: tile qc, element number sc
+    if (qc >= ntiles) return;
+    plan(qi);
+    f32x4 acc[T::FM][T::FN];
+#pragma unroll
+    for (int i = 0; i < T::FM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 aE[HM], aO[HM], b0[T::FN], b1[T::FN];
+    auto loadA = [&](bf16x8 (&a)[HM], const char* sA, int kk, int mh) {
+#pragma unroll
+        for (int i = 0; i < HM; ++i) a[i] = frag_rowk<BK>(sA, wr0 + (mh * HM + i) * 16, kk, lane);
+    };
+    auto loadB = [&](bf16x8 (&b)[T::FN], const char* sB, int kk) {
+#pragma unroll
+        for (int j = 0; j < T::FN; ++j) b[j] = frag_rowk<BK>(sB, wc0 + j * 16, kk, lane);
+    };
+    auto mma = [&](const bf16x8 (&a)[HM], const bf16x8 (&b)[T::FN], int mh) {  // B fragment first: the lane holds C[row lane & 15][4 (lane >> 4) + e]
+#pragma unroll
+        for (int i = 0; i < HM; ++i)
+#pragma unroll
+            for (int j = 0; j < T::FN; ++j)
+                acc[mh * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[mh * HM + i][j], 0, 0, 0);
+    };
+    request_next();
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    request_next();
+    loadB(b0, smem + T::A_BYTES, 0);
+    loadA(aE, smem, 0, 0);
+    for (;;) {
+        TLQ(qc, 0);
+        const bool more_tiles = qc + G < ntiles;
+        for (int t = 0; t < nt; ++t, ++sc) {
+            const char* sA = smem + (sc & 1) * T::STAGE;
+            const char* sB = sA + T::A_BYTES;
+            loadA(aO, sA, 0, 1);
+            mma(aE, b0, 0);
+            loadB(b1, sB, 1);
+            loadA(aE, sA, 1, 0);
+            mma(aO, b0, 1);
+            loadA(aO, sA, 1, 1);
+            mma(aE, b1, 0);
+            const bool last = t + 1 == nt;
+            if (!last || more_tiles) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the element are complete ...
+                wait_vmcnt<0>();                                    // ... its share of the next element has landed (and the previous tile's stores have retired)
+                __builtin_amdgcn_s_barrier();                       // ... for every wave
+                request_next();                                     // element sc + 2 into the stage just left: at the end of a tile that is the NEXT tile's stream
+                if (!last) {
+                    const char* nA = smem + ((sc + 1) & 1) * T::STAGE;
+                    loadB(b0, nA + T::A_BYTES, 0);
+                    loadA(aE, nA, 0, 0);
+                }
+            }
+            mma(aO, b1, 1);
+        }
+        TLQ(qc, 2);
+        // ---- write-out of tile qc: 4 sub-blocks of 32 rows x 64 columns per wave; packed bf16 through this wave's own 4 KiB
+        int64_t m0, n0;
+        origin(qc, m0, n0);
+        const int g = lane >> 4, r16 = lane & 15;
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < T::FN; ++j) {
+                    const f32x4 v = acc[sb * 2 + ii][j];
+                    acc[sb * 2 + ii][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    const u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                    // row r = ii * 16 + r16: 16-byte chunk (2 j + g / 2) ^ (r & 7), 8-byte half (g & 1) ^ (r >> 3 & 1): the 16 rows of one store instruction hit 32 distinct banks
+                    *reinterpret_cast<u32x2*>(stg + (ii * 16 + r16) * 128 + (((2 * j + (g >> 1)) ^ (r16 & 7)) << 4) + ((((g & 1) ^ (r16 >> 3)) & 1) << 3)) = pk;
+                }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int row = pass * 8 + (lane >> 3), ch = lane & 7;
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((ch ^ (row & 7)) << 4));
+                const u32x4 o = (pass & 1) ? (u32x4){raw[2], raw[3], raw[0], raw[1]} : raw;  // rows 8-15 of a 16-row tile were written with their halves exchanged
+                const int64_t gm = m0 + wr0 + sb * 32 + row, gn = n0 + wc0 + ch * 8;
+                if (gm < p.M && gn < p.N) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + gm * p.ldc + gn) = o;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        TLQ(qc, 4);
+        qc += G;
+        if (qc >= ntiles) break;
+        const char* nA = smem + (sc & 1) * T::STAGE;
+        loadB(b0, nA + T::A_BYTES, 0);
+        loadA(aE, nA, 0, 0);
+    }
+}
+
+int launch_persist(GemmParams p, hipStream_t s) {
+    using T = Cfg256;
+    p.tiles_m = (int)((p.M + T::BM - 1) / T::BM);
+    p.tiles_n = (int)((p.N + T::BN - 1) / T::BN);
+    const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n;
+    MI355_REQUIRE(tiles < 0x7fffffffLL / 16, "mi355_gemm_bf16: grid too large");
+    const int grid = (int)(tiles < 256 ? tiles : 256);  // one workgroup per CU
+    hipLaunchKernelGGL(gemm_nt_persist_kernel<MI355_EPI_NONE>, dim3(grid), dim3(T::NTHREADS), 0, s, p, (int)tiles);
+    MI355_LAUNCH_CHECK("mi355_gemm_bf16(persistent)");
+    return 0;
+}
+#endif  // part 2
 
 // Several independent problems of one operand form in ONE launch (the four weight gradients of a transformer block:
 // each alone has fewer output tiles than the chip has CUs, together they fill it).  The concatenated tile list is cut
@@ -1293,6 +1498,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(int64_t M, int64_t N, const
         return launch_grouped_form<CFG>(form, *static_cast<GroupTable*>(table), out_dtype, (hipStream_t)stream);                                   \
     }
 GEMM_BRIDGE_DECL(1) GEMM_BRIDGE_DECL(2) GEMM_BRIDGE_DECL(3) GEMM_BRIDGE_DECL(4) GEMM_BRIDGE_DECL(5)
+extern "C" __attribute__((visibility("hidden"))) int mi355_gemm_persist_part2(const void* params, void* stream);
+#if GEMM_PART == 2 || GEMM_PART == -1
+extern "C" int mi355_gemm_persist_part2(const void* params, void* stream) { return launch_persist(*static_cast<const GemmParams*>(params), (hipStream_t)stream); }
+#endif
 #if GEMM_PART == 1 || GEMM_PART == -1
 GEMM_BRIDGE_DEF(1, Cfg128)
 #endif
@@ -1309,6 +1518,13 @@ GEMM_BRIDGE_DEF(4, Cfg256b)
 GEMM_BRIDGE_DEF(5, Cfg256w)
 #endif
 
+#if GEMM_TL
+extern "C" int mi355_debug_gemm_tl(unsigned long long* out, int n) {  // out[n][8]
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (n > 32768 || hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_tl), sizeof(unsigned long long) * 8 * n) != hipSuccess) return 2;
+    return 0;
+}
+#endif
 #if GEMM_PART <= 0
 #if GEMM_PROF
 extern "C" int mi355_debug_gemm_prof(unsigned long long* out, int reset) {
@@ -1346,7 +1562,7 @@ extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const 
                       "mi355_gemm_bf16(SwiGLU backward epilogue): bf16 output [M, 2N] (ldc >= 2N), residual = the forward gate-up output [M, 2N], N %% 8 == 0, no bias");
     const int ablate = tile_hint >> 8;
     tile_hint &= 0xff;
-    MI355_REQUIRE(tile_hint >= 0 && tile_hint <= 5, "mi355_gemm_bf16: tile_hint must be 0 (auto), 1 (128x128), 2 (256x256), 3 (256x256, alternating wave groups), 4 (3 with one barrier per phase) or 5 (256x256, four waves of 128x128)");
+    MI355_REQUIRE((tile_hint >= 0 && tile_hint <= 5) || tile_hint == 7, "mi355_gemm_bf16: tile_hint must be 0 (auto), 1 (128x128), 2 (256x256), 3 (256x256, alternating wave groups), 4 (3 with one barrier per phase), 5 (256x256, four waves of 128x128) or 7 (2 as a persistent workgroup per CU)");
     GemmParams p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.bias = bias; p.R = residual;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
@@ -1373,6 +1589,12 @@ extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const 
         else if (form == MI355_GEMM_TN) cfg = (M * N > 5 * 1024 * 1024) ? 5 : 1;
         else if (form == MI355_GEMM_NT) cfg = 2;
         else cfg = 3;
+    }
+    if (cfg == 7) {
+        const bool ok = form == MI355_GEMM_NT && out_dtype == MI355_DT_BF16 && epilogue == MI355_EPI_NONE && !bias && !residual && (K & 63) == 0 && K >= 128 && (N & 7) == 0 &&
+                        (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 && M >= 256 && N >= 256;
+        if (ok) return mi355_gemm_persist_part2(&p, s);
+        cfg = 2;
     }
     switch (cfg) {
         case 2: return mi355_gemm_part2(form, &p, out_dtype, workspace, workspace_bytes, s);
