@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(T::NTHREADS, T::MIN_WAVES) void gemm_bf16_kernel(Ge
 #else
 #define TLQ(q, i) do { } while (0)
 #endif
-template <int KIND>
+template <int KIND, bool RES>  // KIND: MI355_EPI_NONE (RES: + bf16 residual, added in fp32 before the rounding), MI355_EPI_SWIGLU_FWD, MI355_EPI_SWIGLU_BWD (see gemm_tile's epilogue for both)
 __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmParams p, int ntiles) {
     using T = Cfg256;
     constexpr int BK = 64, HM = T::FM / 2;
@@ -1154,10 +1154,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmParams p, i
         int64_t m0, n0;
         origin(q, m0, n0);
         int unusedA[T::A_PPW], unusedB[T::B_PPW];
-        piece_offsets<false, T::BM, BK, T::A_PPW>(wave, lane, p.lda, p.M - m0, voffA, unusedA);
-        piece_offsets<false, T::BN, BK, T::B_PPW>(wave, lane, p.ldb, p.N - n0, voffB, unusedB);
+        int l = lane;
+        asm volatile("" : "+v"(l));  // recomputed from the lane number once per tile: hoisted, the per-piece rows and chunks would occupy 16 registers across the main loop
+        piece_offsets<false, T::BM, BK, T::A_PPW>(wave, l, p.lda, p.M - m0, voffA, unusedA);
         baseA = uniform_ptr(p.A + m0 * p.lda);
-        baseB = uniform_ptr(p.B + n0 * p.ldb);
+        if constexpr (KIND == MI355_EPI_SWIGLU_FWD) {
+            // every 64 output columns of the tile are [32 lin1 rows | the 32 lin_gate rows of the SAME hidden units] of the fused weight (see gemm_tile)
+            const int64_t nh = p.N >> 1;
+#pragma unroll
+            for (int j = 0; j < T::B_PPW; ++j) {
+                const int r = (wave * T::B_PPW + j) * 8 + l / 8;
+                const int c = swz_rowk<BK>(l % 8, r);
+                const int64_t hid = (n0 >> 1) + (r >> 6) * 32 + (r & 31);
+                voffB[j] = hid < nh ? (unsigned)((((r >> 5) & 1) * nh + hid) * p.ldb * 2 + c * 16) : OOB;
+            }
+            baseB = uniform_ptr(p.B);
+        } else {
+            piece_offsets<false, T::BN, BK, T::B_PPW>(wave, l, p.ldb, p.N - n0, voffB, unusedB);
+            baseB = uniform_ptr(p.B + n0 * p.ldb);
+        }
     };
     int qi = blockIdx.x, ti = 0, si = 0;
     auto request_next = [&]() {
@@ -1183,10 +1198,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmParams p, i
     if (qc >= ntiles) return;
     plan(qi);
     f32x4 acc[T::FM][T::FN];
-#pragma unroll
-    for (int i = 0; i < T::FM; ++i)
-#pragma unroll
-        for (int j = 0; j < T::FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     bf16x8 aE[HM], aO[HM], b0[T::FN], b1[T::FN];
     auto loadA = [&](bf16x8 (&a)[HM], const char* sA, int kk, int mh) {
 #pragma unroll
@@ -1196,12 +1207,45 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmParams p, i
 #pragma unroll
         for (int j = 0; j < T::FN; ++j) b[j] = frag_rowk<BK>(sB, wc0 + j * 16, kk, lane);
     };
-    auto mma = [&](const bf16x8 (&a)[HM], const bf16x8 (&b)[T::FN], int mh) {  // B fragment first: the lane holds C[row lane & 15][4 (lane >> 4) + e]
+    // B fragment first: the lane holds C[row lane & 15][4 (lane >> 4) + e].  ZERO: the tile's first k-step starts from the constant 0 (no accumulator is cleared anywhere)
+    auto mma = [&](bool zero, const bf16x8 (&a)[HM], const bf16x8 (&b)[T::FN], int mh) {
+        if (zero) {  // wave-uniform
 #pragma unroll
-        for (int i = 0; i < HM; ++i)
+            for (int i = 0; i < HM; ++i)
 #pragma unroll
-            for (int j = 0; j < T::FN; ++j)
-                acc[mh * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[mh * HM + i][j], 0, 0, 0);
+                for (int j = 0; j < T::FN; ++j) acc[mh * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < HM; ++i)
+#pragma unroll
+                for (int j = 0; j < T::FN; ++j) acc[mh * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[mh * HM + i][j], 0, 0, 0);
+        }
+    };
+    bool more_tiles = false;
+    auto kstep = [&](int t) {  // one element of the stream: 64 MFMAs in four phases (k-step, row half), the next element's first fragments requested under the last
+        const char* sA = smem + (sc & 1) * T::STAGE;
+        const char* sB = sA + T::A_BYTES;
+        loadA(aO, sA, 0, 1);
+        mma(t == 0, aE, b0, 0);
+        loadB(b1, sB, 1);
+        loadA(aE, sA, 1, 0);
+        mma(t == 0, aO, b0, 1);
+        loadA(aO, sA, 1, 1);
+        mma(false, aE, b1, 0);
+        const bool last = t + 1 == nt;
+        if (!last || more_tiles) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the element are complete ...
+            wait_vmcnt<0>();                                    // ... its share of the next element has landed (and the previous tile's stores have retired)
+            __builtin_amdgcn_s_barrier();                       // ... for every wave
+            request_next();                                     // element sc + 2 into the stage just left: at the end of a tile that is the NEXT tile's stream
+            if (!last) {
+                const char* nA = smem + ((sc + 1) & 1) * T::STAGE;
+                loadB(b0, nA + T::A_BYTES, 0);
+                loadA(aE, nA, 0, 0);
+            }
+        }
+        mma(false, aO, b1, 1);
+        ++sc;
     };
     request_next();
     wait_vmcnt<0>();
@@ -1211,59 +1255,140 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmParams p, i
     loadA(aE, smem, 0, 0);
     for (;;) {
         TLQ(qc, 0);
-        const bool more_tiles = qc + G < ntiles;
-        for (int t = 0; t < nt; ++t, ++sc) {
-            const char* sA = smem + (sc & 1) * T::STAGE;
-            const char* sB = sA + T::A_BYTES;
-            loadA(aO, sA, 0, 1);
-            mma(aE, b0, 0);
-            loadB(b1, sB, 1);
-            loadA(aE, sA, 1, 0);
-            mma(aO, b0, 1);
-            loadA(aO, sA, 1, 1);
-            mma(aE, b1, 0);
-            const bool last = t + 1 == nt;
-            if (!last || more_tiles) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the element are complete ...
-                wait_vmcnt<0>();                                    // ... its share of the next element has landed (and the previous tile's stores have retired)
-                __builtin_amdgcn_s_barrier();                       // ... for every wave
-                request_next();                                     // element sc + 2 into the stage just left: at the end of a tile that is the NEXT tile's stream
-                if (!last) {
-                    const char* nA = smem + ((sc + 1) & 1) * T::STAGE;
-                    loadB(b0, nA + T::A_BYTES, 0);
-                    loadA(aE, nA, 0, 0);
-                }
-            }
-            mma(aO, b1, 1);
-        }
+        more_tiles = qc + G < ntiles;
+        for (int t = 0; t < nt; ++t) kstep(t);
         TLQ(qc, 2);
-        // ---- write-out of tile qc: 4 sub-blocks of 32 rows x 64 columns per wave; packed bf16 through this wave's own 4 KiB
+        // ---- write-out of tile qc: 4 sub-blocks of 32 rows x 64 columns per wave; packed bf16 through this wave's own 4 KiB.  LDS operations of a wave execute in
+        // order, so sub-block sb + 1 is staged right behind the row reads of sub-block sb, whose stores go out while it is being packed; rows and columns beyond the
+        // matrix are dropped by the buffer range check (offset OOB), so the passes have no branches.
+        int le = lane;
+        asm volatile("" : "+v"(le));  // derived per tile, not kept across the main loop
+        const int g = le >> 4, r16 = le & 15;
+        // staging addresses of this lane.  Write side: row r = ii * 16 + r16 of a 32 x 64 sub-block (128-byte rows), 16-byte chunk (2 j + g / 2) ^ (r & 7), 8-byte half
+        // (g & 1) ^ (r >> 3 & 1): the 16 rows one store instruction covers hit 32 distinct banks.  Read side: row pass * 8 + lane / 8, chunk (lane & 7) ^ (row & 7).
+        const int wr_off = r16 * 128 + ((((g & 1) ^ (r16 >> 3)) & 1) << 3), wr_x = r16 & 7;
+        const int rd_row = le >> 3, rd_ch = le & 7;
+        const int rd_off = rd_row * 128 + ((rd_ch ^ (rd_row & 7)) << 4);  // (pass * 8 + rd_row) & 7 == rd_row & 7
         int64_t m0, n0;
         origin(qc, m0, n0);
-        const int g = lane >> 4, r16 = lane & 15;
+        const int64_t rows_left = p.M - m0 - wr0;
+        u32x4 rd[4];
+        [[maybe_unused]] u32x2 rres[2][T::FN];   // RES: the residual of a sub-block in the accumulators' layout (8-byte loads)
+        [[maybe_unused]] u32x4 uv[4], gv[4];     // SwiGLU backward: the forward's gate-up pair of a sub-block's rows (16-byte loads)
+        [[maybe_unused]] u32x2 partner[4];       // SwiGLU forward: the other operand of the four units this lane activates
+        const int hi4 = rd_ch >> 2;
+        // column base of this wave in C (and R), validity of this lane's 8 columns
+        int64_t cbase, cbase2 = 0;
+        bool col_ok;
+        if constexpr (KIND == MI355_EPI_SWIGLU_FWD) {
+            const int64_t nh = p.N >> 1, hid = (n0 >> 1) + (wc0 >> 6) * 32 + (rd_ch & 3) * 8;
+            col_ok = hid < nh;
+            cbase = (hi4 ? nh : 0) + hid;  // gate-up output: u into [:, hid], g into [:, N/2 + hid]
+            cbase2 = hid + 4 * hi4;        // activation output (R): four units per lane
+        } else {
+            cbase = n0 + wc0 + rd_ch * 8;
+            col_ok = cbase < p.N;
+        }
+        auto rsrc_c = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<bf16_t*>(p.C) + (m0 + wr0) * p.ldc, 0, 0x7fffffff, 0x00020000);
+        auto rsrc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(p.R)) + (m0 + wr0) * p.ldr, 0, 0x7fffffff, 0x00020000);
+        auto fetch_res = [&](int sb) {  // residual of sub-block sb, requested a sub-block before it is packed
+            if constexpr (RES) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int j = 0; j < T::FN; ++j) {
+                        const int row = sb * 32 + ii * 16 + r16;
+                        const int64_t col = n0 + wc0 + j * 16 + 4 * g;
+                        rres[ii][j] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_r, (row < rows_left && col < p.N) ? (unsigned)((row * p.ldr + col) * 2) : OOB, 0, 0));
+                    }
+            }
+        };
+        auto fetch_ug = [&](int sb) {  // gate-up rows of sub-block sb, requested when it is staged, used a sub-block later (after the stores of sb - 1 have consumed theirs)
+            if constexpr (KIND == MI355_EPI_SWIGLU_BWD) {
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {
+                    const int row = sb * 32 + pass * 8 + rd_row;
+                    const bool ok = col_ok && row < rows_left;
+                    uv[pass] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, ok ? (unsigned)((row * p.ldr + cbase) * 2) : OOB, 0, 0));
+                    gv[pass] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, ok ? (unsigned)((row * p.ldr + cbase + p.N) * 2) : OOB, 0, 0));
+                }
+            }
+        };
+        auto stores = [&](int sb) {
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const u32x4 o = (pass & 1) ? (u32x4){rd[pass][2], rd[pass][3], rd[pass][0], rd[pass][1]} : rd[pass];  // rows 8-15 of a 16-row tile were written with their halves exchanged
+                const int row = sb * 32 + pass * 8 + rd_row;
+                const bool ok = col_ok && row < rows_left;
+                if constexpr (KIND == MI355_EPI_SWIGLU_BWD) {
+                    // o = d(act) of hidden units cbase..+7, rounded to bf16: d(gate-up) = [d * g sig(g) | d * u sig(g) (1 + g (1 - sig(g)))] into C[:, unit], C[:, N + unit] (ldc = 2N)
+                    u32x4 o0, o1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float du[2], dg[2];
+#pragma unroll
+                        for (int hlf = 0; hlf < 2; ++hlf) {
+                            const float d_ = hlf ? __uint_as_float(o[e] & 0xffff0000u) : __uint_as_float(o[e] << 16);
+                            const float u_ = hlf ? __uint_as_float(uv[pass][e] & 0xffff0000u) : __uint_as_float(uv[pass][e] << 16);
+                            const float g_ = hlf ? __uint_as_float(gv[pass][e] & 0xffff0000u) : __uint_as_float(gv[pass][e] << 16);
+                            swiglu_grads(d_, u_, g_, du[hlf], dg[hlf]);
+                        }
+                        o0[e] = pack_bf2(du[0], du[1]);
+                        o1[e] = pack_bf2(dg[0], dg[1]);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(o0, rsrc_c, ok ? (unsigned)((row * p.ldc + cbase) * 2) : OOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(o1, rsrc_c, ok ? (unsigned)((row * p.ldc + cbase + p.N) * 2) : OOB, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rsrc_c, ok ? (unsigned)((row * p.ldc + cbase) * 2) : OOB, 0, 0);
+                    if constexpr (KIND == MI355_EPI_SWIGLU_FWD) {
+                        // this lane's 8 columns are u (chunks 0-3) or g (chunks 4-7) of 8 hidden units; it activates four of them: units 0-3 (u lanes) resp. 4-7 (g lanes),
+                        // the other operand = the partner lane's chunk, read back from the staging rows; a = u * silu(g) on the ROUNDED operands, as mi355_swiglu_fwd sees them
+                        const u32x2 pv = partner[pass];
+                        float a4[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned wm = o[2 * hi4 + (e >> 1)], wo = pv[e >> 1];
+                            const float mine = (e & 1) ? __uint_as_float(wm & 0xffff0000u) : __uint_as_float(wm << 16);
+                            const float other = (e & 1) ? __uint_as_float(wo & 0xffff0000u) : __uint_as_float(wo << 16);
+                            a4[e] = hi4 ? swiglu_act(other, mine) : swiglu_act(mine, other);
+                        }
+                        const u32x2 av = {pack_bf2(a4[0], a4[1]), pack_bf2(a4[2], a4[3])};
+                        __builtin_amdgcn_raw_buffer_store_b64(av, rsrc_r, ok ? (unsigned)((row * p.ldr + cbase2) * 2) : OOB, 0, 0);
+                    }
+                }
+            }
+        };
+        fetch_res(0);
 #pragma unroll
         for (int sb = 0; sb < 4; ++sb) {
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
                 for (int j = 0; j < T::FN; ++j) {
-                    const f32x4 v = acc[sb * 2 + ii][j];
-                    acc[sb * 2 + ii][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    f32x4 v = acc[sb * 2 + ii][j];
+                    if constexpr (RES) {
+                        v[0] += __uint_as_float(rres[ii][j][0] << 16);
+                        v[1] += __uint_as_float(rres[ii][j][0] & 0xffff0000u);
+                        v[2] += __uint_as_float(rres[ii][j][1] << 16);
+                        v[3] += __uint_as_float(rres[ii][j][1] & 0xffff0000u);
+                    }
                     const u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-                    // row r = ii * 16 + r16: 16-byte chunk (2 j + g / 2) ^ (r & 7), 8-byte half (g & 1) ^ (r >> 3 & 1): the 16 rows of one store instruction hit 32 distinct banks
-                    *reinterpret_cast<u32x2*>(stg + (ii * 16 + r16) * 128 + (((2 * j + (g >> 1)) ^ (r16 & 7)) << 4) + ((((g & 1) ^ (r16 >> 3)) & 1) << 3)) = pk;
+                    *reinterpret_cast<u32x2*>(stg + ii * 2048 + wr_off + (((2 * j + (g >> 1)) ^ wr_x) << 4)) = pk;
                 }
-            __builtin_amdgcn_wave_barrier();
+            if (sb > 0) stores(sb - 1);
+            if (sb < 3) fetch_res(sb + 1);
+            fetch_ug(sb);
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
-                const int row = pass * 8 + (lane >> 3), ch = lane & 7;
-                const u32x4 raw = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((ch ^ (row & 7)) << 4));
-                const u32x4 o = (pass & 1) ? (u32x4){raw[2], raw[3], raw[0], raw[1]} : raw;  // rows 8-15 of a 16-row tile were written with their halves exchanged
-                const int64_t gm = m0 + wr0 + sb * 32 + row, gn = n0 + wc0 + ch * 8;
-                if (gm < p.M && gn < p.N) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + gm * p.ldc + gn) = o;
+                rd[pass] = *reinterpret_cast<const u32x4*>(stg + pass * 1024 + rd_off);
+                if constexpr (KIND == MI355_EPI_SWIGLU_FWD) {
+                    // partner chunk rd_ch ^ 4 of the same row, its half hi4 (units 4-7 of the partner's eight for g lanes, 0-3 for u lanes); odd passes hold rows whose halves are exchanged
+                    const int prow = rd_row;  // (pass * 8 + rd_row) & 7
+                    partner[pass] = *reinterpret_cast<const u32x2*>(stg + pass * 1024 + rd_row * 128 + ((((rd_ch ^ 4) ^ (prow & 7))) << 4) + (((hi4 ^ pass) & 1) << 3));
+                }
             }
-            __builtin_amdgcn_wave_barrier();
         }
+        stores(3);
         TLQ(qc, 4);
         qc += G;
         if (qc >= ntiles) break;
@@ -1279,8 +1404,11 @@ int launch_persist(GemmParams p, hipStream_t s) {
     p.tiles_n = (int)((p.N + T::BN - 1) / T::BN);
     const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n;
     MI355_REQUIRE(tiles < 0x7fffffffLL / 16, "mi355_gemm_bf16: grid too large");
-    const int grid = (int)(tiles < 256 ? tiles : 256);  // one workgroup per CU
-    hipLaunchKernelGGL(gemm_nt_persist_kernel<MI355_EPI_NONE>, dim3(grid), dim3(T::NTHREADS), 0, s, p, (int)tiles);
+    const dim3 grid((unsigned)(tiles < 256 ? tiles : 256)), block(T::NTHREADS);  // one workgroup per CU
+    if (p.epilogue == MI355_EPI_SWIGLU_FWD) hipLaunchKernelGGL((gemm_nt_persist_kernel<MI355_EPI_SWIGLU_FWD, false>), grid, block, 0, s, p, (int)tiles);
+    else if (p.epilogue == MI355_EPI_SWIGLU_BWD) hipLaunchKernelGGL((gemm_nt_persist_kernel<MI355_EPI_SWIGLU_BWD, false>), grid, block, 0, s, p, (int)tiles);
+    else if (p.R) hipLaunchKernelGGL((gemm_nt_persist_kernel<MI355_EPI_NONE, true>), grid, block, 0, s, p, (int)tiles);
+    else hipLaunchKernelGGL((gemm_nt_persist_kernel<MI355_EPI_NONE, false>), grid, block, 0, s, p, (int)tiles);
     MI355_LAUNCH_CHECK("mi355_gemm_bf16(persistent)");
     return 0;
 }
@@ -1591,8 +1719,9 @@ extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const 
         else cfg = 3;
     }
     if (cfg == 7) {
-        const bool ok = form == MI355_GEMM_NT && out_dtype == MI355_DT_BF16 && epilogue == MI355_EPI_NONE && !bias && !residual && (K & 63) == 0 && K >= 128 && (N & 7) == 0 &&
-                        (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 && M >= 256 && N >= 256;
+        const bool ok = form == MI355_GEMM_NT && out_dtype == MI355_DT_BF16 && (epilogue == MI355_EPI_NONE || epilogue == MI355_EPI_SWIGLU_FWD || epilogue == MI355_EPI_SWIGLU_BWD) &&
+                        !bias && (K & 63) == 0 && K >= 128 && (N & 7) == 0 && (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 && M >= 256 && N >= 256 &&
+                        (!residual || ((ldr & 7) == 0 && ((uintptr_t)residual & 15) == 0)) && ldc * 2 * 256 < 0x7fffffffLL && ldr * 2 * 256 < 0x7fffffffLL;
         if (ok) return mi355_gemm_persist_part2(&p, s);
         cfg = 2;
     }

@@ -9,11 +9,12 @@ lib = L.load()
 r = lambda *s: (0.1 * torch.randn(*s, device="cuda")).to(torch.bfloat16)
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 113440
 shapes = {"qkv": (4096, 1024), "dctx": (2048, 1024), "n1024k1024": (1024, 1024), "down": (1024, 3072)}
+TILE = int(os.environ.get("TL_TILE", "2"))  # 7: the persistent kernel (stamps 0 = tile's main loop begins, 2 = ends, 4 = write-out issued; indexed by tile)
 for name in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["qkv", "down"]):
     N, Kd = shapes[name]
     x, w = r(M, Kd), r(N, Kd)
-    o = K.gemm(L.GEMM_NT, x, w)
-    for _ in range(40): K.gemm(L.GEMM_NT, x, w, out=o)
+    o = K.gemm(L.GEMM_NT, x, w, tile=TILE)
+    for _ in range(40): K.gemm(L.GEMM_NT, x, w, out=o, tile=TILE)
     torch.cuda.synchronize()
     ntile = ((M + 255) // 256) * ((N + 255) // 256)
     n = min(ntile, 32768)
@@ -21,6 +22,16 @@ for name in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["qkv", "down"]):
     rc = lib.mi355_debug_gemm_tl(buf.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong)), n)
     assert rc == 0, rc
     t = buf[:, :6].astype(np.int64)
+    if TILE == 7:
+        order = np.argsort(t[:, 0])
+        ml, wo = (t[:, 2] - t[:, 0]) / 100.0, (t[:, 4] - t[:, 2]) / 100.0
+        span = (t[:, 4].max() - t[:, 0].min()) / 100.0
+        # a workgroup's consecutive tiles are q, q + 256, ...: the gap between write-out end and the next main loop's begin
+        G = min(ntile, 256)
+        gaps = np.array([(t[q + G, 0] - t[q, 4]) / 100.0 for q in range(n - G)])
+        print(f"== {name} persistent: M {M} N {N} K {Kd} tiles {ntile} span {span:.1f} us; per tile: main loop {ml.mean():.2f} (p10 {np.percentile(ml, 10):.2f}, p90 {np.percentile(ml, 90):.2f}), "
+              f"write-out {wo.mean():.2f} (p10 {np.percentile(wo, 10):.2f}, p90 {np.percentile(wo, 90):.2f}), between tiles {gaps.mean():.2f}")
+        continue
     hw = buf[:, 6]
     xcc = (hw >> np.uint64(32)) & np.uint64(15)
     hwid = hw & np.uint64(0xffffffff)
