@@ -1276,6 +1276,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmParams p, i
         [[maybe_unused]] u32x2 rres[2][T::FN];   // RES: the residual of a sub-block in the accumulators' layout (8-byte loads)
         [[maybe_unused]] u32x4 uv[4], gv[4];     // SwiGLU backward: the forward's gate-up pair of a sub-block's rows (16-byte loads)
         [[maybe_unused]] u32x2 partner[4];       // SwiGLU forward: the other operand of the four units this lane activates
+        [[maybe_unused]] float psum[4][4];       // attention delta: this wave's half-head row sums (sub-block, pass), complete in every lane of the row's eight
         const int hi4 = rd_ch >> 2;
         // column base of this wave in C (and R), validity of this lane's 8 columns
         int64_t cbase, cbase2 = 0;
@@ -1304,13 +1305,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmParams p, i
             }
         };
         auto fetch_ug = [&](int sb) {  // gate-up rows of sub-block sb, requested when it is staged, used a sub-block later (after the stores of sb - 1 have consumed theirs)
-            if constexpr (KIND == MI355_EPI_SWIGLU_BWD) {
+            if constexpr (KIND == MI355_EPI_SWIGLU_BWD || KIND == MI355_EPI_ATTN_DELTA) {
 #pragma unroll
                 for (int pass = 0; pass < 4; ++pass) {
                     const int row = sb * 32 + pass * 8 + rd_row;
                     const bool ok = col_ok && row < rows_left;
-                    uv[pass] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, ok ? (unsigned)((row * p.ldr + cbase) * 2) : OOB, 0, 0));
-                    gv[pass] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, ok ? (unsigned)((row * p.ldr + cbase + p.N) * 2) : OOB, 0, 0));
+                    uv[pass] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, ok ? (unsigned)((row * p.ldr + cbase) * 2) : OOB, 0, 0));  // delta: the forward's ctx
+                    if constexpr (KIND == MI355_EPI_SWIGLU_BWD)
+                        gv[pass] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, ok ? (unsigned)((row * p.ldr + cbase + p.N) * 2) : OOB, 0, 0));
                 }
             }
         };
@@ -1340,6 +1342,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmParams p, i
                     __builtin_amdgcn_raw_buffer_store_b128(o1, rsrc_c, ok ? (unsigned)((row * p.ldc + cbase + p.N) * 2) : OOB, 0, 0);
                 } else {
                     __builtin_amdgcn_raw_buffer_store_b128(o, rsrc_c, ok ? (unsigned)((row * p.ldc + cbase) * 2) : OOB, 0, 0);
+                    if constexpr (KIND == MI355_EPI_ATTN_DELTA) {
+                        // o = d(ctx), rounded; uv = ctx: the row's dot product over this lane's 8 columns, folded over the row's eight lanes = half a head (the wave's 64 columns)
+                        float dsum = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            dsum += __uint_as_float(o[e] << 16) * __uint_as_float(uv[pass][e] << 16) + __uint_as_float(o[e] & 0xffff0000u) * __uint_as_float(uv[pass][e] & 0xffff0000u);
+                        dsum += __shfl_xor(dsum, 1, 64);
+                        dsum += __shfl_xor(dsum, 2, 64);
+                        dsum += __shfl_xor(dsum, 4, 64);
+                        psum[sb][pass] = dsum;
+                    }
                     if constexpr (KIND == MI355_EPI_SWIGLU_FWD) {
                         // this lane's 8 columns are u (chunks 0-3) or g (chunks 4-7) of 8 hidden units; it activates four of them: units 0-3 (u lanes) resp. 4-7 (g lanes),
                         // the other operand = the partner lane's chunk, read back from the staging rows; a = u * silu(g) on the ROUNDED operands, as mi355_swiglu_fwd sees them
@@ -1389,6 +1402,31 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmParams p, i
             }
         }
         stores(3);
+        if constexpr (KIND == MI355_EPI_ATTN_DELTA) {
+            // a head's two halves sit in two neighbouring waves: every wave parks its 128 row sums in its own staging region (behind its last row reads: LDS operations
+            // execute in order), one barrier, then one thread per (row, head) adds the halves in a fixed order and writes the attention backward's three row constants.
+            // The regions are next written in the following tile's write-out, which every wave reaches only through that tile's K-loop barriers.
+            static_assert(T::NTHREADS == 512 && T::WN == 4 && T::WTN == 64, "delta write-out: 2 x 4 waves of 128 x 64 on a 256 x 256 tile");
+            float* part = reinterpret_cast<float*>(stg);
+#pragma unroll
+            for (int sb = 0; sb < 4; ++sb)
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass)
+                    if (rd_ch == 0) part[sb * 32 + pass * 8 + rd_row] = psum[sb][pass];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int t_ = threadIdx.x, row = t_ & 255, hsel = t_ >> 8;
+            const float* p0 = reinterpret_cast<const float*>(smem + 2 * T::STAGE + ((row >> 7) * 4 + 2 * hsel) * 4096);
+            const float sum = p0[row & 127] + p0[1024 + (row & 127)];
+            const int64_t gm = m0 + row, head = (n0 >> 7) + hsel;
+            if (gm < p.M && head < p.ad_Hq) {
+                const int64_t bb = gm / p.ad_S, sq = gm - bb * p.ad_S;
+                const int64_t di = (bb * p.ad_Hq + head) * p.ad_S + sq;
+                p.ad_delta[di] = sum;
+                p.ad_ndl[di] = -sum;
+                p.ad_nl2[di] = -p.ad_lse[di] * 1.4426950408889634f;
+            }
+        }
         TLQ(qc, 4);
         qc += G;
         if (qc >= ntiles) break;
@@ -1407,6 +1445,7 @@ int launch_persist(GemmParams p, hipStream_t s) {
     const dim3 grid((unsigned)(tiles < 256 ? tiles : 256)), block(T::NTHREADS);  // one workgroup per CU
     if (p.epilogue == MI355_EPI_SWIGLU_FWD) hipLaunchKernelGGL((gemm_nt_persist_kernel<MI355_EPI_SWIGLU_FWD, false>), grid, block, 0, s, p, (int)tiles);
     else if (p.epilogue == MI355_EPI_SWIGLU_BWD) hipLaunchKernelGGL((gemm_nt_persist_kernel<MI355_EPI_SWIGLU_BWD, false>), grid, block, 0, s, p, (int)tiles);
+    else if (p.epilogue == MI355_EPI_ATTN_DELTA) hipLaunchKernelGGL((gemm_nt_persist_kernel<MI355_EPI_ATTN_DELTA, false>), grid, block, 0, s, p, (int)tiles);
     else if (p.R) hipLaunchKernelGGL((gemm_nt_persist_kernel<MI355_EPI_NONE, true>), grid, block, 0, s, p, (int)tiles);
     else hipLaunchKernelGGL((gemm_nt_persist_kernel<MI355_EPI_NONE, false>), grid, block, 0, s, p, (int)tiles);
     MI355_LAUNCH_CHECK("mi355_gemm_bf16(persistent)");
@@ -1666,6 +1705,13 @@ extern "C" int mi355_debug_gemm_prof(unsigned long long* out, int reset) {
 }
 #endif
 
+// tiles from which an eligible NT launch takes the persistent kernel by itself (MI355_GEMM_PERSIST_MIN_TILES: 1 = always -- the tests run ragged shapes through it --,
+// a huge value = never: A/B runs); read per call, the tests change it inside one process
+static int64_t persist_min_tiles() {
+    const char* e = getenv("MI355_GEMM_PERSIST_MIN_TILES");
+    return e && *e ? atoll(e) : 512;
+}
+
 extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                                int64_t ldb, void* C, int64_t ldc, int out_dtype, const float* bias,
                                const void* residual, int64_t ldr, int epilogue, void* workspace, int64_t workspace_bytes,
@@ -1718,10 +1764,15 @@ extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const 
         else if (form == MI355_GEMM_NT) cfg = 2;
         else cfg = 3;
     }
+    // the persistent form of tile 2 (hint 7): same bits, no prologue / barrier / workgroup turnover per tile and a quarter of the staging traffic.  Round 4, batch 160, isolated:
+    // QKV 890-917 -> 818-825 us, gate-up + SwiGLU 1 489-1 494 -> 1 418-1 422, down dgrad + SwiGLU backward 959-986 -> 920, dqkv dgrad 788-818 -> 756-764.  Chosen by itself from two
+    // rounds of tiles upward (below that every workgroup has one tile and split-K may pay instead)
+    const bool persist_ok = form == MI355_GEMM_NT && out_dtype == MI355_DT_BF16 && (epilogue == MI355_EPI_NONE || epilogue == MI355_EPI_SWIGLU_FWD || epilogue == MI355_EPI_SWIGLU_BWD) &&
+                            !bias && (K & 63) == 0 && K >= 128 && (N & 7) == 0 && (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 && M >= 256 && N >= 256 &&
+                            (!residual || ((ldr & 7) == 0 && ((uintptr_t)residual & 15) == 0)) && ldc * 2 * 256 < 0x7fffffffLL && ldr * 2 * 256 < 0x7fffffffLL;
+    if (cfg == 2 && tile_hint == 0 && persist_ok && ((M + 255) / 256) * ((N + 255) / 256) >= persist_min_tiles()) cfg = 7;
     if (cfg == 7) {
-        const bool ok = form == MI355_GEMM_NT && out_dtype == MI355_DT_BF16 && (epilogue == MI355_EPI_NONE || epilogue == MI355_EPI_SWIGLU_FWD || epilogue == MI355_EPI_SWIGLU_BWD) &&
-                        !bias && (K & 63) == 0 && K >= 128 && (N & 7) == 0 && (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 && M >= 256 && N >= 256 &&
-                        (!residual || ((ldr & 7) == 0 && ((uintptr_t)residual & 15) == 0)) && ldc * 2 * 256 < 0x7fffffffLL && ldr * 2 * 256 < 0x7fffffffLL;
+        const bool ok = persist_ok;
         if (ok) return mi355_gemm_persist_part2(&p, s);
         cfg = 2;
     }
@@ -1749,6 +1800,9 @@ extern "C" int mi355_gemm_bf16_attn_delta(int64_t M, int64_t N, int64_t K, const
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldctx;
     p.epilogue = MI355_EPI_ATTN_DELTA; p.tiles_m = p.tiles_n = 0; p.ksplit = 1; p.ws = nullptr; p.ablate = 0;
     p.ad_lse = lse; p.ad_delta = delta; p.ad_nl2 = neg_lse_log2e; p.ad_ndl = neg_delta; p.ad_S = S; p.ad_Hq = Hq;
+    // the persistent form (same bits) from two rounds of tiles upward
+    if ((K & 63) == 0 && K >= 128 && ((M + 255) / 256) * ((N + 255) / 256) >= persist_min_tiles() && ldc * 2 * 256 < 0x7fffffffLL && ldctx * 2 * 256 < 0x7fffffffLL)
+        return mi355_gemm_persist_part2(&p, (hipStream_t)stream);
     return mi355_gemm_part2(MI355_GEMM_NT, &p, MI355_DT_BF16, nullptr, 0, (hipStream_t)stream);
 }
 

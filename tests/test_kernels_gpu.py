@@ -590,15 +590,18 @@ def test_attention_backward_with_the_query_norm_backward_as_its_write_out(K, B, 
     assert K.rope_cs16(skew, sin_d) is None, "tables whose halves differ must take the fp32 path"
 
 
+@pytest.mark.parametrize("persistent", [False, True])
 @pytest.mark.parametrize("B,S,Hq,Hkv", [(6, 709, 4, 2), (9, 500, 3, 1)])
-def test_out_projection_dgrad_leaves_the_attention_backwards_row_constants(K, B, S, Hq, Hkv):
-    """mi355_gemm_bf16_attn_delta: d(ctx) bit-identical to the plain dgrad; delta[b, h, s] = sum_d d(ctx) * ctx on the ROUNDED d(ctx) (what the
+def test_out_projection_dgrad_leaves_the_attention_backwards_row_constants(K, B, S, Hq, Hkv, persistent, monkeypatch):
+    """(``persistent``: the same epilogue in the persistent NT kernel, which the library takes by itself from 512 tiles upward -- forced here from one tile.)
+    mi355_gemm_bf16_attn_delta: d(ctx) bit-identical to the plain dgrad; delta[b, h, s] = sum_d d(ctx) * ctx on the ROUNDED d(ctx) (what the
     stand-alone delta pass reads; fp32 sums in another order: 1e-5), -delta and -lse * log2(e) exact in the backward's scratch; an odd head count
     (the last 256-column tile holds one head) and a row count that is no multiple of 256; and the attention backward that skips its delta pass
     (MI355_ATTN_DELTA_READY) gives the gradients of the one that runs it, to the rounding of delta."""
     from llm_quest_amd import _lib as L
     from oracle import ops
 
+    monkeypatch.setenv("MI355_GEMM_PERSIST_MIN_TILES", "1" if persistent else "1000000000")
     D, d_model = 128, 512
     qkv, qw, kw = _qkv_case(B, S, Hq, Hkv, D, 41)
     cos, sin = ops.rope_tables(1_000_000, D, 1024)
@@ -936,6 +939,37 @@ def test_gemm_swiglu_forward_epilogue_equals_two_kernels_bit_for_bit():
             gu, a = K.gemm_gateup_swiglu(x, w, tile=tile)
             assert torch.equal(gu, gu_ref), (M, F, tile)
             assert torch.equal(a, a_ref), (M, F, tile)
+
+
+@pytest.mark.parametrize("M,N,K_", [(256, 256, 128), (1000, 512, 128), (709 * 5 + 3, 1024, 1024), (2600, 4096, 256), (4099, 264, 192), (300, 256, 64), (513, 776, 2048), (4200, 512, 256)])
+def test_persistent_nt_kernel_equals_the_per_tile_kernel_bit_for_bit(M, N, K_, monkeypatch):
+    """Tile hint 7 (one workgroup per CU walking its tiles, K-tile stream across tile boundaries, packed-bf16 write-out) against hint 2 for every epilogue it
+    carries -- plain, residual, SwiGLU forward, SwiGLU backward -- on ragged M, N that is no multiple of the tile, a single tile, more tiles than CUs;
+    K % 64 != 0 and K < 128 fall back to the per-tile kernel inside the library.  Then the same through the automatic choice (threshold lowered to one tile)."""
+    from llm_quest_amd import _lib as L
+    from llm_quest_amd import kernels as K
+
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K_)
+    rnd = lambda *s: dev((0.3 * torch.randn(*s, generator=g)).to(BF16))
+    x, w, res = rnd(M, K_), rnd(N, K_), rnd(M, N)
+    ref = K.gemm(L.GEMM_NT, x, w, tile=2, allow_split_k=False)
+    ref_res = K.gemm(L.GEMM_NT, x, w, residual=res, tile=2, allow_split_k=False)
+    got = torch.full_like(ref, 7.0)  # every element must be written
+    K.gemm(L.GEMM_NT, x, w, out=got, tile=7)
+    assert torch.equal(got, ref)
+    assert torch.equal(K.gemm(L.GEMM_NT, x, w, residual=res, tile=7), ref_res)
+    F = (N // 64) * 32  # fused gate-up weight [2F, K], F % 32 == 0
+    wgu = rnd(2 * F, K_)
+    gu2, a2 = K.gemm_gateup_swiglu(x, wgu, tile=2)
+    gu7, a7 = K.gemm_gateup_swiglu(x, wgu, tile=7)
+    assert torch.equal(gu7, gu2) and torch.equal(a7, a2)
+    dy, w2, gu = rnd(M, K_), rnd(K_, N), rnd(M, 2 * N)
+    assert torch.equal(K.gemm_dgrad_swiglu_bwd(dy, w2, gu, tile=7), K.gemm_dgrad_swiglu_bwd(dy, w2, gu, tile=2))
+    monkeypatch.setenv("MI355_GEMM_PERSIST_MIN_TILES", "1")
+    assert torch.equal(K.gemm(L.GEMM_NT, x, w, allow_split_k=False), ref)
+    assert torch.equal(K.gemm(L.GEMM_NT, x, w, residual=res, allow_split_k=False), ref_res)
+    gu0, a0 = K.gemm_gateup_swiglu(x, wgu)
+    assert torch.equal(gu0, gu2) and torch.equal(a0, a2)
 
 
 @pytest.mark.parametrize("tanh", [False, True])
