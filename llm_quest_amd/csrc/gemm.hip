@@ -947,12 +947,13 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
                                     // partner operand of my four units: staging columns (other half) + (l8 & 3) * 8 + 4 * hi4
                                     const f32x4 pv = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + (hi4 ? 0 : 32) + (l8 & 3) * 8 + 4 * hi4);
                                     float a4[4];
+                                    const unsigned own0 = hi4 ? own[2] : own[0], own1 = hi4 ? own[3] : own[1];  // selects, not an indexed vector and a divergent branch
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) {
-                                        const unsigned w = own[2 * hi4 + (e >> 1)];
+                                        const unsigned w = (e >> 1) ? own1 : own0;
                                         const float mine = (e & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16);
                                         const float other = bf2f(f2bf(pv[e]));
-                                        a4[e] = hi4 ? swiglu_act(other, mine) : swiglu_act(mine, other);
+                                        a4[e] = swiglu_act(hi4 ? other : mine, hi4 ? mine : other);
                                     }
                                     const u32x2 av = {pack_bf2(a4[0], a4[1]), pack_bf2(a4[2], a4[3])};
                                     *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(const_cast<void*>(p.R)) + gm * p.ldr + hid + 4 * hi4) = av;
@@ -1356,14 +1357,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmParams p, i
                     if constexpr (KIND == MI355_EPI_SWIGLU_FWD) {
                         // this lane's 8 columns are u (chunks 0-3) or g (chunks 4-7) of 8 hidden units; it activates four of them: units 0-3 (u lanes) resp. 4-7 (g lanes),
                         // the other operand = the partner lane's chunk, read back from the staging rows; a = u * silu(g) on the ROUNDED operands, as mi355_swiglu_fwd sees them
+                        // (operands are picked with selects, word by word: written as `hi4 ? act(other, mine) : act(mine, other)` on an indexed `o[2 * hi4 + ..]`, every lane
+                        // ran both sides of a divergent branch -- twice the exponentials -- behind a chain of compares for the index)
                         const u32x2 pv = partner[pass];
+                        const unsigned own0 = hi4 ? o[2] : o[0], own1 = hi4 ? o[3] : o[1];
+                        const unsigned uw[2] = {hi4 ? pv[0] : own0, hi4 ? pv[1] : own1}, gw[2] = {hi4 ? own0 : pv[0], hi4 ? own1 : pv[1]};
                         float a4[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const unsigned wm = o[2 * hi4 + (e >> 1)], wo = pv[e >> 1];
-                            const float mine = (e & 1) ? __uint_as_float(wm & 0xffff0000u) : __uint_as_float(wm << 16);
-                            const float other = (e & 1) ? __uint_as_float(wo & 0xffff0000u) : __uint_as_float(wo << 16);
-                            a4[e] = hi4 ? swiglu_act(other, mine) : swiglu_act(mine, other);
+                            const float u_ = (e & 1) ? __uint_as_float(uw[e >> 1] & 0xffff0000u) : __uint_as_float(uw[e >> 1] << 16);
+                            const float g_ = (e & 1) ? __uint_as_float(gw[e >> 1] & 0xffff0000u) : __uint_as_float(gw[e >> 1] << 16);
+                            a4[e] = swiglu_act(u_, g_);
                         }
                         const u32x2 av = {pack_bf2(a4[0], a4[1]), pack_bf2(a4[2], a4[3])};
                         __builtin_amdgcn_raw_buffer_store_b64(av, rsrc_r, ok ? (unsigned)((row * p.ldr + cbase2) * 2) : OOB, 0, 0);
