@@ -169,7 +169,7 @@ def pmc_step_traffic():
 
 
 def dominant_kernel_rate(batch, device):
-    """HIP-event timing of the step's dominant kernel class (gemm_bf16_kernel) on its largest shapes, on the stream the
+    """HIP-event timing of the step's dominant kernel class (gemm_nt_persist_kernel for the NT forms, gemm_bf16_kernel for TN) on its largest shapes, on the stream the
     kernels are launched on (torch's current stream)."""
     from llm_quest_amd import _lib as L
     from llm_quest_amd import kernels as K
@@ -595,7 +595,7 @@ def main():
         if train_step is not None:
             line["with_optimizer_step"] = train_step
         if world == 1:
-            line["roofline"]["dominant_kernel"] = {"name": "gemm_bf16_kernel", "hip_event_timing": dominant_kernel_rate(args.batch, device)}
+            line["roofline"]["dominant_kernel"] = {"name": "gemm_nt_persist_kernel / gemm_bf16_kernel (NT projections on the persistent form of tile 2; weight gradients on tile 5)", "hip_event_timing": dominant_kernel_rate(args.batch, device)}
             pmc, why_gemm = pmc_traffic()
             step_pmc, why_step = pmc_step_traffic()
             pmc_batch = step_pmc.get("per_gpu_batch") if step_pmc else None

@@ -8,8 +8,8 @@ for d in $E/*/; do n=$(ls $d*/ 2>/dev/null | sed 's/_.*//' | sort -u | wc -l); [
 B=$(python -c "import json;print(json.load(open('$E/stamp.json'))['per_gpu_batch'])"); M=$((B * 709))
 python tools/pmc_step.py $E/step_fetch $E/step_write 4 profiles/${ROUND}_pmc_tcc_step.json $E | tail -1
 python tools/pmc_gemm.py profiles/${ROUND}_pmc_tcc_gemm.json $E \
-  "NT:$E/nt_gateup_fetch:$E/nt_gateup_write:$M:6144:1024:gemm_bf16_kernel NT tile 2, gate-up forward C[$M,6144] = X[$M,1024] W[6144,1024]^T (plain epilogue)" \
-  "NT_dgrad:$E/nt_dgrad_fetch:$E/nt_dgrad_write:$M:1024:6144:gemm_bf16_kernel NT tile 2, gate-up dgrad dX[$M,1024] = dY[$M,6144] (W^T)[1024,6144]^T (the step's form)" \
+  "NT:$E/nt_gateup_fetch:$E/nt_gateup_write:$M:6144:1024:gemm_nt_persist_kernel (tile 2 as a persistent workgroup per CU), gate-up forward C[$M,6144] = X[$M,1024] W[6144,1024]^T (plain epilogue)" \
+  "NT_dgrad:$E/nt_dgrad_fetch:$E/nt_dgrad_write:$M:1024:6144:gemm_nt_persist_kernel (tile 2 as a persistent workgroup per CU), gate-up dgrad dX[$M,1024] = dY[$M,6144] (W^T)[1024,6144]^T (the step's form)" \
   "TN:$E/tn_wgrad_fetch:$E/tn_wgrad_write:6144:1024:$M:gemm_bf16_kernel TN tile 5 (four waves of 128x128), gate-up wgrad dW[6144,1024] = dY[$M,6144]^T X[$M,1024]" | tail -1
 rm -f profiles/${ROUND}_pmc_sq_counters.json
 for l in nt_gateup nt_dgrad tn_wgrad attn; do python tools/pmc_sq.py profiles/${ROUND}_pmc_sq_counters.json ${l}_b$B $E $E/${l}_sq1 $E/${l}_sq2 > /dev/null; done

@@ -11,11 +11,11 @@ def avg(d, counter):
     vals, durs = [], []
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == counter and "gemm_bf16_kernel" in r["Kernel_Name"]:
+            if r["Counter_Name"] == counter and ("gemm_bf16_kernel" in r["Kernel_Name"] or "gemm_nt_persist_kernel" in r["Kernel_Name"]):
                 vals.append(float(r["Counter_Value"]))
     for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "gemm_bf16_kernel" in r["Kernel_Name"]:
+            if ("gemm_bf16_kernel" in r["Kernel_Name"] or "gemm_nt_persist_kernel" in r["Kernel_Name"]):
                 durs.append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
     vals, durs = vals[1:] or vals, durs[1:] or durs
     return sum(vals) / len(vals), sum(durs) / len(durs)
