@@ -96,6 +96,7 @@ class GradSync:
         self._pending = []
         self._done = set()
         self.comm_stream = None
+        self._beside = False  # collectives of this step are running beside the compute stream
         self.backend = dist.get_backend(group) if dist.is_initialized() else None
         for m in self.owners:
             object.__setattr__(m, "_grad_ready", self._on_ready)
@@ -154,6 +155,7 @@ class GradSync:
             if ev is None:
                 ev = self._events[id(arena)] = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(buf.device))
+            self._collectives_beside_compute()
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
                 if self.backend == "nccl":
@@ -165,6 +167,16 @@ class GradSync:
         else:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
             buf.div_(self.world)
+
+    def _collectives_beside_compute(self):
+        """From here to the join in finish_step a collective's channels may hold CUs: GEMM launches issued meanwhile must not be the persistent kernel
+        (kernels.persistent_gemm: its workgroups have to start together).  Launches already queued are in front of the bucket's event, i.e. finished before the
+        collective starts."""
+        if not self._beside:
+            from . import kernels as K
+
+            K.persistent_gemm(False)
+            self._beside = True
 
     def _on_ready(self, module):
         if not self.enabled or not self._sync_on:
@@ -271,6 +283,11 @@ class GradSync:
         self._reduce_tail_params()
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if self._beside:
+            from . import kernels as K
+
+            K.persistent_gemm(True)
+            self._beside = False
         global _ACTIVE
         _ACTIVE = None
 

@@ -44,6 +44,23 @@ def _workspace(device):
     return ws
 
 
+_PERSIST_USER = os.environ.get("MI355_GEMM_PERSIST_MIN_TILES")  # the user's own threshold, if any
+
+
+def persistent_gemm(enabled):
+    """The library takes the persistent NT kernel (one workgroup per CU for a launch's whole length, csrc/gemm.hip) by itself from 512 tiles upward.  That kernel
+    assumes its 256 workgroups all START together: a CU that a collective's channel occupies takes no GEMM workgroup (each needs the CU's whole register file and
+    LDS), and the workgroups that find no CU only start when the first ones have walked their whole share -- the launch then lasts up to twice as long, where the
+    per-tile kernel merely loses the occupied CUs' share.  ``ddp.GradSync`` therefore switches the automatic choice off from the first collective of a backward until
+    the streams have joined (``persistent_gemm(False)`` ... ``persistent_gemm(True)``); an explicit ``tile=7`` still selects it."""
+    if not enabled:
+        os.environ["MI355_GEMM_PERSIST_MIN_TILES"] = "1000000000"
+    elif _PERSIST_USER is None:
+        os.environ.pop("MI355_GEMM_PERSIST_MIN_TILES", None)
+    else:
+        os.environ["MI355_GEMM_PERSIST_MIN_TILES"] = _PERSIST_USER
+
+
 def gemm(form, a, b, out=None, out_dtype=BF16, bias=None, residual=None, gelu=False, allow_split_k=True, tile=0):
     """C = epi(op(A) op(B) + bias) + residual.  form NT: A[M,K] B[N,K]; NN: A[M,K] B[K,N]; TN: A[K,M] B[K,N]."""
     L.require_gpu(a, b, out, bias, residual)

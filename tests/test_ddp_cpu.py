@@ -279,3 +279,24 @@ def test_tied_head_embedding_bucket_is_exchanged_in_two_parts_gloo():
     for p in procs:
         p.join(60)
     assert all(p.exitcode == 0 for p in procs) and res == {0: True, 1: True}
+
+
+def test_persistent_gemm_switch_restores_the_users_threshold(monkeypatch):
+    """kernels.persistent_gemm(False) keeps the library off the persistent NT kernel (whose workgroups must all start together) while collectives run beside
+    the compute stream; persistent_gemm(True) puts back what the user had set -- nothing, or their own threshold."""
+    import os
+
+    from llm_quest_amd import kernels as K
+
+    var = "MI355_GEMM_PERSIST_MIN_TILES"
+    monkeypatch.delenv(var, raising=False)
+    monkeypatch.setattr(K, "_PERSIST_USER", None)
+    K.persistent_gemm(False)
+    assert os.environ[var] == "1000000000"
+    K.persistent_gemm(True)
+    assert var not in os.environ
+    monkeypatch.setattr(K, "_PERSIST_USER", "64")
+    K.persistent_gemm(False)
+    assert os.environ[var] == "1000000000"
+    K.persistent_gemm(True)
+    assert os.environ[var] == "64"
