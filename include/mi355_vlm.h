@@ -71,7 +71,12 @@ int mi355_abi_version(void);
  *   workspace    optional fp32 scratch (16-byte aligned) of workspace_bytes: lets problems with few output tiles
  *                and a long K (weight gradients) split K over several workgroups (slabs + reduce); NULL = never split.
  *   tile_hint    0 = choose by shape; 1 = 128x128 tile (4 waves), 2 = 256x256 tile (8 waves), 3 = 256x256, alternating wave groups,
- *                4 = 3 with one barrier per phase, 5 = 256x256 as four waves of 128x128 (one per SIMD, accumulators in AGPRs)
+ *                4 = 3 with one barrier per phase, 5 = 256x256 as four waves of 128x128 (one per SIMD, accumulators in AGPRs),
+ *                7 = 2 as ONE workgroup per CU that walks its share of the tiles (K-tile stream across tile boundaries, packed-bf16 write-out beside the
+ *                    stages; same bits as 2): NT form, bf16 output, K % 64 == 0, K >= 128, N % 8 == 0, no bias; plain / residual / SwiGLU-forward /
+ *                    SwiGLU-backward epilogues; other calls fall back to 2.  0 takes it by itself from 512 tiles upward (environment variable
+ *                    MI355_GEMM_PERSIST_MIN_TILES, read per call, moves that threshold: its 256 workgroups assume they all start together, so a caller that runs
+ *                    collectives or another stream's kernels beside its GEMMs raises it for that time -- llm_quest_amd/ddp.py does)
  * Requirements: K-contiguous dims multiple of 8 elements (16-byte rows); see DESIGN.md.            */
 int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                     int64_t ldb, void* C, int64_t ldc, int out_dtype, const float* bias, const void* residual,
