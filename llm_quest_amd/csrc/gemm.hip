@@ -1122,7 +1122,7 @@ __global__ __launch_bounds__(T::NTHREADS, T::MIN_WAVES) void gemm_bf16_kernel(Ge
 // Results are bit-identical to gemm_bf16_kernel (same MFMA sequence per output, same rounding).  NT form, bf16 output, K % 64 == 0, N % 8 == 0, no bias.
 #if GEMM_PART == 2 || !defined(GEMM_PART)
 #if GEMM_TL
-#define TLQ(q, i) do { if (threadIdx.x == 0 && (q) < 32768) g_gemm_tl[q][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define TLQ(q, i) do { if (threadIdx.x == 0 && (q) < 32768) { g_gemm_tl[q][i] = __builtin_amdgcn_s_memrealtime(); g_gemm_tl[q][(i) + 1] = __builtin_readcyclecounter(); } } while (0)  // + the shader clock's counter: cycles / time = the clock the tile ran at
 #else
 #define TLQ(q, i) do { } while (0)
 #endif

@@ -29,6 +29,9 @@ for name in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["qkv", "down"]):
         # a workgroup's consecutive tiles are q, q + 256, ...: the gap between write-out end and the next main loop's begin
         G = min(ntile, 256)
         gaps = np.array([(t[q + G, 0] - t[q, 4]) / 100.0 for q in range(n - G)])
+        mhz = (t[:, 3] - t[:, 1]) / np.maximum(ml, 1e-3)  # shader-clock cycles per microsecond over the main loop
+        print(f"   shader clock during the main loops: mean {mhz.mean():.0f} MHz (p10 {np.percentile(mhz, 10):.0f}, p90 {np.percentile(mhz, 90):.0f}); main loop {((t[:, 3] - t[:, 1])).mean():.0f} cycles per tile, "
+              f"MFMA issue {2 * 64 * (Kd // 64) * 16} cycles per SIMD at 16 per 16x16x32 and two waves")
         print(f"== {name} persistent: M {M} N {N} K {Kd} tiles {ntile} span {span:.1f} us; per tile: main loop {ml.mean():.2f} (p10 {np.percentile(ml, 10):.2f}, p90 {np.percentile(ml, 90):.2f}), "
               f"write-out {wo.mean():.2f} (p10 {np.percentile(wo, 10):.2f}, p90 {np.percentile(wo, 90):.2f}), between tiles {gaps.mean():.2f}")
         continue
