@@ -78,6 +78,9 @@ __device__ unsigned long long g_gemm_prof[32];
 #define GP_ADD(i, t0) do { } while (0)
 #endif
 
+#ifndef PERSIST_LOADERS
+#define PERSIST_LOADERS 1  // the persistent kernel's LDS-DMA requests: 1 = waves 0-3 issue their SIMD partner's (waves 4-7) too, 0 = every wave its own (A/B builds)
+#endif
 #ifndef GEMM_TL
 #define GEMM_TL 0  // profiling builds only: per-workgroup wall-clock stamps (100 MHz s_memrealtime) of prologue / main loop / write-out, tools/gemm_timeline.py
 #endif
@@ -1148,44 +1151,61 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmParams p, i
         m0 = (int64_t)(first_m + (pid % in_group) % gsz) * T::BM;
         n0 = (int64_t)((pid % in_group) / gsz) * T::BN;
     };
-    // ---- the request side of the stream: tile qi, K-tile ti, element number si (stage si & 1)
-    unsigned voffA[T::A_PPW], voffB[T::B_PPW];
+    // ---- the request side of the stream: tile qi, K-tile ti, element number si (stage si & 1).  LOADERS (PERSIST_LOADERS): the requests of a SIMD's two waves (w and
+    // w + 4) are all issued by wave w.  Issued symmetrically, both waves of a SIMD stand in the CU's one address unit's queue at the same time, right behind the barrier,
+    // and the matrix pipe idles; with one of them requesting for both, the other multiplies meanwhile
+    constexpr int RW = PERSIST_LOADERS ? 2 : 1;  // waves' worth of pieces a requesting wave issues
+    unsigned voffA[RW * T::A_PPW], voffB[RW * T::B_PPW];
     const bf16_t *baseA = p.A, *baseB = p.B;
     auto plan = [&](int q) {
         int64_t m0, n0;
         origin(q, m0, n0);
-        int unusedA[T::A_PPW], unusedB[T::B_PPW];
         int l = lane;
         asm volatile("" : "+v"(l));  // recomputed from the lane number once per tile: hoisted, the per-piece rows and chunks would occupy 16 registers across the main loop
-        piece_offsets<false, T::BM, BK, T::A_PPW>(wave, l, p.lda, p.M - m0, voffA, unusedA);
         baseA = uniform_ptr(p.A + m0 * p.lda);
-        if constexpr (KIND == MI355_EPI_SWIGLU_FWD) {
-            // every 64 output columns of the tile are [32 lin1 rows | the 32 lin_gate rows of the SAME hidden units] of the fused weight (see gemm_tile)
-            const int64_t nh = p.N >> 1;
+        baseB = KIND == MI355_EPI_SWIGLU_FWD ? uniform_ptr(p.B) : uniform_ptr(p.B + n0 * p.ldb);
 #pragma unroll
-            for (int j = 0; j < T::B_PPW; ++j) {
-                const int r = (wave * T::B_PPW + j) * 8 + l / 8;
-                const int c = swz_rowk<BK>(l % 8, r);
-                const int64_t hid = (n0 >> 1) + (r >> 6) * 32 + (r & 31);
-                voffB[j] = hid < nh ? (unsigned)((((r >> 5) & 1) * nh + hid) * p.ldb * 2 + c * 16) : OOB;
+        for (int h = 0; h < RW; ++h) {
+            const int w = wave + 4 * h;
+            unsigned vA[T::A_PPW], vB[T::B_PPW];
+            int unusedA[T::A_PPW], unusedB[T::B_PPW];
+            piece_offsets<false, T::BM, BK, T::A_PPW>(w, l, p.lda, p.M - m0, vA, unusedA);
+            if constexpr (KIND == MI355_EPI_SWIGLU_FWD) {
+                // every 64 output columns of the tile are [32 lin1 rows | the 32 lin_gate rows of the SAME hidden units] of the fused weight (see gemm_tile)
+                const int64_t nh = p.N >> 1;
+#pragma unroll
+                for (int j = 0; j < T::B_PPW; ++j) {
+                    const int r = (w * T::B_PPW + j) * 8 + l / 8;
+                    const int c = swz_rowk<BK>(l % 8, r);
+                    const int64_t hid = (n0 >> 1) + (r >> 6) * 32 + (r & 31);
+                    vB[j] = hid < nh ? (unsigned)((((r >> 5) & 1) * nh + hid) * p.ldb * 2 + c * 16) : OOB;
+                }
+            } else {
+                piece_offsets<false, T::BN, BK, T::B_PPW>(w, l, p.ldb, p.N - n0, vB, unusedB);
             }
-            baseB = uniform_ptr(p.B);
-        } else {
-            piece_offsets<false, T::BN, BK, T::B_PPW>(wave, l, p.ldb, p.N - n0, voffB, unusedB);
-            baseB = uniform_ptr(p.B + n0 * p.ldb);
+#pragma unroll
+            for (int j = 0; j < T::A_PPW; ++j) {
+                voffA[h * T::A_PPW + j] = vA[j];
+                voffB[h * T::B_PPW + j] = vB[j];
+            }
         }
     };
     int qi = blockIdx.x, ti = 0, si = 0;
     auto request_next = [&]() {
         if (qi < ntiles) {
-            char* dA = smem + (si & 1) * T::STAGE + wave * T::A_PPW * 1024;
-            char* dB = smem + (si & 1) * T::STAGE + T::A_BYTES + wave * T::B_PPW * 1024;
-            const bf16_t* pa = baseA + (int64_t)ti * BK;
-            const bf16_t* pb = baseB + (int64_t)ti * BK;
+            if (!PERSIST_LOADERS || wave < 4) {  // (wave-uniform)
+                char* dA = smem + (si & 1) * T::STAGE + wave * T::A_PPW * 1024;
+                char* dB = smem + (si & 1) * T::STAGE + T::A_BYTES + wave * T::B_PPW * 1024;
+                const bf16_t* pa = baseA + (int64_t)ti * BK;
+                const bf16_t* pb = baseB + (int64_t)ti * BK;
 #pragma unroll
-            for (int j = 0; j < T::A_PPW; ++j) dma_piece(pa, voffA[j], dA + j * 1024);
+                for (int h = 0; h < RW; ++h) {
 #pragma unroll
-            for (int j = 0; j < T::B_PPW; ++j) dma_piece(pb, voffB[j], dB + j * 1024);
+                    for (int j = 0; j < T::A_PPW; ++j) dma_piece(pa, voffA[h * T::A_PPW + j], dA + (h * 4 * T::A_PPW + j) * 1024);
+#pragma unroll
+                    for (int j = 0; j < T::B_PPW; ++j) dma_piece(pb, voffB[h * T::B_PPW + j], dB + (h * 4 * T::B_PPW + j) * 1024);
+                }
+            }
             if (++ti == nt) {
                 ti = 0;
                 qi += G;
