@@ -78,9 +78,6 @@ __device__ unsigned long long g_gemm_prof[32];
 #define GP_ADD(i, t0) do { } while (0)
 #endif
 
-#ifndef PERSIST_LOADERS
-#define PERSIST_LOADERS 1  // the persistent kernel's LDS-DMA requests: 1 = waves 0-3 issue their SIMD partner's (waves 4-7) too, 0 = every wave its own (A/B builds)
-#endif
 #ifndef GEMM_TL
 #define GEMM_TL 0  // profiling builds only: per-workgroup wall-clock stamps (100 MHz s_memrealtime) of prologue / main loop / write-out, tools/gemm_timeline.py
 #endif
@@ -1151,60 +1148,81 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmParams p, i
         m0 = (int64_t)(first_m + (pid % in_group) % gsz) * T::BM;
         n0 = (int64_t)((pid % in_group) / gsz) * T::BN;
     };
-    // ---- the request side of the stream: tile qi, K-tile ti, element number si (stage si & 1).  LOADERS (PERSIST_LOADERS): the requests of a SIMD's two waves (w and
-    // w + 4) are all issued by wave w.  Issued symmetrically, both waves of a SIMD stand in the CU's one address unit's queue at the same time, right behind the barrier,
-    // and the matrix pipe idles; with one of them requesting for both, the other multiplies meanwhile
-    constexpr int RW = PERSIST_LOADERS ? 2 : 1;  // waves' worth of pieces a requesting wave issues
-    unsigned voffA[RW * T::A_PPW], voffB[RW * T::B_PPW];
-    const bf16_t *baseA = p.A, *baseB = p.B;
+    // ---- the request side of the stream: tile qi, K-tile ti, element number si (stage si & 1).  The LDS-DMA requests of a SIMD's two waves (w and w + 4) are divided by
+    // OPERAND, not by wave: wave w requests the A-panel pieces of both (8 per K-tile), right behind the barrier that frees the stage; wave w + 4 requests the B-panel
+    // pieces of both (weights: they come from L2) a phase later, under its partner's MFMAs.  Issued symmetrically (every wave its own 4 + 4 behind the barrier), both waves
+    // of a SIMD stand in the CU's one address unit's queue at the same time and the matrix pipe idles; with the two request bursts half a K-tile apart, one wave of every
+    // SIMD always multiplies.  (All 16 requests on wave w, none on w + 4: between the two -- the requesting wave's burst plus its own 64 MFMAs is the K-tile's critical path.)
+    // The SwiGLU-backward form keeps all 16 requests on wave w (BY_OPERAND false): with the second request point in the K-tile its register allocation spills 72 values.
+    constexpr bool BY_OPERAND = KIND != MI355_EPI_SWIGLU_BWD;
+    const bool a_side = wave < 4;
+    const int wlo = wave & 3;
+    unsigned voff[2 * T::A_PPW];  // this wave's operand: pieces of waves wlo (0-3) and wlo + 4 (4-7)
+    [[maybe_unused]] unsigned voff2[2 * T::B_PPW];  // !BY_OPERAND: wave w's B-panel pieces
+    static_assert(T::A_PPW == T::B_PPW, "one offset array serves either operand");
+    const bf16_t* baseX = p.A;
+    [[maybe_unused]] const bf16_t* baseY = p.B;
     auto plan = [&](int q) {
         int64_t m0, n0;
         origin(q, m0, n0);
         int l = lane;
         asm volatile("" : "+v"(l));  // recomputed from the lane number once per tile: hoisted, the per-piece rows and chunks would occupy 16 registers across the main loop
-        baseA = uniform_ptr(p.A + m0 * p.lda);
-        baseB = KIND == MI355_EPI_SWIGLU_FWD ? uniform_ptr(p.B) : uniform_ptr(p.B + n0 * p.ldb);
+        if (a_side) {  // (wave-uniform)
+            baseX = uniform_ptr(p.A + m0 * p.lda);
 #pragma unroll
-        for (int h = 0; h < RW; ++h) {
-            const int w = wave + 4 * h;
-            unsigned vA[T::A_PPW], vB[T::B_PPW];
-            int unusedA[T::A_PPW], unusedB[T::B_PPW];
-            piece_offsets<false, T::BM, BK, T::A_PPW>(w, l, p.lda, p.M - m0, vA, unusedA);
-            if constexpr (KIND == MI355_EPI_SWIGLU_FWD) {
-                // every 64 output columns of the tile are [32 lin1 rows | the 32 lin_gate rows of the SAME hidden units] of the fused weight (see gemm_tile)
-                const int64_t nh = p.N >> 1;
+            for (int h = 0; h < 2; ++h) {
+                unsigned v[T::A_PPW];
+                int unused[T::A_PPW];
+                piece_offsets<false, T::BM, BK, T::A_PPW>(wlo + 4 * h, l, p.lda, p.M - m0, v, unused);
 #pragma unroll
-                for (int j = 0; j < T::B_PPW; ++j) {
-                    const int r = (w * T::B_PPW + j) * 8 + l / 8;
-                    const int c = swz_rowk<BK>(l % 8, r);
-                    const int64_t hid = (n0 >> 1) + (r >> 6) * 32 + (r & 31);
-                    vB[j] = hid < nh ? (unsigned)((((r >> 5) & 1) * nh + hid) * p.ldb * 2 + c * 16) : OOB;
+                for (int j = 0; j < T::A_PPW; ++j) voff[h * T::A_PPW + j] = v[j];
+                if constexpr (!BY_OPERAND) {
+                    piece_offsets<false, T::BN, BK, T::B_PPW>(wlo + 4 * h, l, p.ldb, p.N - n0, v, unused);
+#pragma unroll
+                    for (int j = 0; j < T::B_PPW; ++j) voff2[h * T::B_PPW + j] = v[j];
                 }
-            } else {
-                piece_offsets<false, T::BN, BK, T::B_PPW>(w, l, p.ldb, p.N - n0, vB, unusedB);
             }
+            if constexpr (!BY_OPERAND) baseY = uniform_ptr(p.B + n0 * p.ldb);
+        } else if constexpr (BY_OPERAND) {
+            baseX = KIND == MI355_EPI_SWIGLU_FWD ? uniform_ptr(p.B) : uniform_ptr(p.B + n0 * p.ldb);
 #pragma unroll
-            for (int j = 0; j < T::A_PPW; ++j) {
-                voffA[h * T::A_PPW + j] = vA[j];
-                voffB[h * T::B_PPW + j] = vB[j];
+            for (int h = 0; h < 2; ++h) {
+                const int w = wlo + 4 * h;
+                unsigned v[T::B_PPW];
+                if constexpr (KIND == MI355_EPI_SWIGLU_FWD) {
+                    // every 64 output columns of the tile are [32 lin1 rows | the 32 lin_gate rows of the SAME hidden units] of the fused weight (see gemm_tile)
+                    const int64_t nh = p.N >> 1;
+#pragma unroll
+                    for (int j = 0; j < T::B_PPW; ++j) {
+                        const int r = (w * T::B_PPW + j) * 8 + l / 8;
+                        const int c = swz_rowk<BK>(l % 8, r);
+                        const int64_t hid = (n0 >> 1) + (r >> 6) * 32 + (r & 31);
+                        v[j] = hid < nh ? (unsigned)((((r >> 5) & 1) * nh + hid) * p.ldb * 2 + c * 16) : OOB;
+                    }
+                } else {
+                    int unused[T::B_PPW];
+                    piece_offsets<false, T::BN, BK, T::B_PPW>(w, l, p.ldb, p.N - n0, v, unused);
+                }
+#pragma unroll
+                for (int j = 0; j < T::B_PPW; ++j) voff[h * T::B_PPW + j] = v[j];
             }
         }
     };
     int qi = blockIdx.x, ti = 0, si = 0;
-    auto request_next = [&]() {
+    auto request_next = [&]() {  // this wave's operand of element si
         if (qi < ntiles) {
-            if (!PERSIST_LOADERS || wave < 4) {  // (wave-uniform)
-                char* dA = smem + (si & 1) * T::STAGE + wave * T::A_PPW * 1024;
-                char* dB = smem + (si & 1) * T::STAGE + T::A_BYTES + wave * T::B_PPW * 1024;
-                const bf16_t* pa = baseA + (int64_t)ti * BK;
-                const bf16_t* pb = baseB + (int64_t)ti * BK;
+            char* dst = smem + (si & 1) * T::STAGE + (a_side ? 0 : T::A_BYTES) + wlo * T::A_PPW * 1024;
+            const bf16_t* px = baseX + (int64_t)ti * BK;
 #pragma unroll
-                for (int h = 0; h < RW; ++h) {
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int j = 0; j < T::A_PPW; ++j) dma_piece(pa, voffA[h * T::A_PPW + j], dA + (h * 4 * T::A_PPW + j) * 1024);
+                for (int j = 0; j < T::A_PPW; ++j) dma_piece(px, voff[h * T::A_PPW + j], dst + (h * 4 * T::A_PPW + j) * 1024);
+            if constexpr (!BY_OPERAND) {
+                const bf16_t* py = baseY + (int64_t)ti * BK;
 #pragma unroll
-                    for (int j = 0; j < T::B_PPW; ++j) dma_piece(pb, voffB[h * T::B_PPW + j], dB + (h * 4 * T::B_PPW + j) * 1024);
-                }
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int j = 0; j < T::B_PPW; ++j) dma_piece(py, voff2[h * T::B_PPW + j], dst + T::A_BYTES + (h * 4 * T::B_PPW + j) * 1024);
             }
             if (++ti == nt) {
                 ti = 0;
@@ -1248,6 +1266,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmParams p, i
         const char* sB = sA + T::A_BYTES;
         loadA(aO, sA, 0, 1);
         mma(t == 0, aE, b0, 0);
+        if (BY_OPERAND && !a_side && sc > 0) request_next();  // the B panels of element sc + 1 (its A panels were requested behind the last barrier; elements 0 and 1: before the loop)
         loadB(b1, sB, 1);
         loadA(aE, sA, 1, 0);
         mma(t == 0, aO, b0, 1);
@@ -1258,7 +1277,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmParams p, i
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the element are complete ...
             wait_vmcnt<0>();                                    // ... its share of the next element has landed (and the previous tile's stores have retired)
             __builtin_amdgcn_s_barrier();                       // ... for every wave
-            request_next();                                     // element sc + 2 into the stage just left: at the end of a tile that is the NEXT tile's stream
+            if (a_side) request_next();                         // the A panels of element sc + 2 into the stage just left: at the end of a tile that is the NEXT tile's stream
             if (!last) {
                 const char* nA = smem + ((sc + 1) & 1) * T::STAGE;
                 loadB(b0, nA + T::A_BYTES, 0);
@@ -1268,10 +1287,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmParams p, i
         mma(false, aO, b1, 1);
         ++sc;
     };
-    request_next();
+    if (BY_OPERAND || a_side) request_next();  // elements 0 and 1: both operands
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    request_next();
+    if (BY_OPERAND || a_side) request_next();
     loadB(b0, smem + T::A_BYTES, 0);
     loadA(aE, smem, 0, 0);
     for (;;) {
