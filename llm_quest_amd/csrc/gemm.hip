@@ -216,6 +216,7 @@ __device__ __forceinline__ void wait_vmcnt() {
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else static_assert(N == 0, "add the immediate");
 }
@@ -488,20 +489,22 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
             for (int g = 0; g < 8; ++g) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) mma(acc[g >> 1][(g & 1) * 4 + q], a0[g >> 1], b[CUR][(g & 1) * 4 + q]);
-                issue_piece(t + 3, nst, g);
+                if ((g & 1) == 0) issue_piece(t + 3, nst, g >> 1);  // the A pieces here, the B pieces in phase 1: one request per 8 MFMAs over the whole K-tile (all eight in phase 0
+                                                                     // were one per 4 MFMAs from four waves at once, then none for 32 MFMAs; the ring is three tiles deep, nothing waits for them)
                 if (g < HM) frag_tr_issue<T::BM>(h_a1[g], sA, wr0 + (HM + g) * 16, 0, lane);
                 __builtin_amdgcn_sched_barrier(0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" : TRH(h_a1[0]), TRH(h_a1[1]), TRH(h_a1[2]), TRH(h_a1[3])::"memory");
 #pragma unroll
             for (int i = 0; i < HM; ++i) a1[i] = tr_join(h_a1[i]);
-            wait_vmcnt<16>();
+            wait_vmcnt<12>();  // tile t + 1 has landed: tile t + 2 and the four A pieces of t + 3 may be in flight
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) mma(acc[HM + (g >> 2)][(g & 3) * 2 + q], a1[g >> 2], b[CUR][(g & 3) * 2 + q]);
+                if ((g & 3) == 1) issue_piece(t + 3, nst, T::A_PPW + (g >> 2));
                 if (g < T::FN) frag_tr_issue<T::BN>(h_b[g], nA + T::A_BYTES, wc0 + g * 16, 0, lane);
                 else if (g < T::FN + HM) frag_tr_issue<T::BM>(h_a0[g - T::FN], nA, wr0 + (g - T::FN) * 16, 0, lane);
                 __builtin_amdgcn_sched_barrier(0);
