@@ -259,12 +259,19 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
     unsigned voffA[T::A_PPW], voffB[T::B_PPW];
     int kneedA[T::A_PPW], kneedB[T::B_PPW];
     constexpr int BK = T::BK;
-    piece_offsets<A_TR, T::BM, BK, T::A_PPW>(wave, lane, p.lda, p.M - m0, voffA, kneedA);
-    piece_offsets<B_TR, T::BN, BK, T::B_PPW>(wave, lane, p.ldb, p.N - n0, voffB, kneedB);
+    // SPLIT (NT on the 8-wave 256x256 tile): the requests of a SIMD's two waves (w and w + 4) are divided by OPERAND, as in gemm_nt_persist_kernel -- waves 0-3 request
+    // the A-panel pieces of both (their own in the "A" set below, their partner's in the "B" set), behind the barrier; waves 4-7 the B-panel pieces of both, a phase later
+    constexpr bool SPLIT = T::NW == 8 && T::BK == 64 && !A_TR && !B_TR && T::A_PPW == T::B_PPW;
+    const bool a_side = !SPLIT || wave < 4;
+    const int w1 = SPLIT ? (wave & 3) : wave, w2 = SPLIT ? (wave & 3) + 4 : wave;  // whose pieces the first / second set holds
+    if (!SPLIT || a_side) piece_offsets<A_TR, T::BM, BK, T::A_PPW>(w1, lane, p.lda, p.M - m0, voffA, kneedA);
+    else piece_offsets<B_TR, T::BN, BK, T::B_PPW>(w1, lane, p.ldb, p.N - n0, voffA, kneedA);
+    if (SPLIT && a_side) piece_offsets<A_TR, T::BM, BK, T::A_PPW>(w2, lane, p.lda, p.M - m0, voffB, kneedB);
+    else piece_offsets<B_TR, T::BN, BK, T::B_PPW>(w2, lane, p.ldb, p.N - n0, voffB, kneedB);
     const bf16_t* baseA = A_TR ? p.A + m0 : p.A + m0 * p.lda;
     const bf16_t* baseB = B_TR ? p.B + n0 : p.B + n0 * p.ldb;
     if constexpr (!B_TR) {
-        if (p.epilogue == MI355_EPI_SWIGLU_FWD) {
+        if (p.epilogue == MI355_EPI_SWIGLU_FWD && !(SPLIT && a_side)) {
             // gate-up projection with the activation in the epilogue: every 64 output columns of the tile are [32 lin1 rows | the 32
             // lin_gate rows of the SAME hidden units] of the fused weight [lin1 (N/2 rows) | lin_gate (N/2 rows)], so a wave's 64x64
             // staging block holds u and g side by side.  Only the row each DMA lane fetches changes.
@@ -272,15 +279,30 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
             const int64_t nh = p.N >> 1;
 #pragma unroll
             for (int j = 0; j < T::B_PPW; ++j) {
-                const int r = (wave * T::B_PPW + j) * RPP + lane / CH;
+                const int r = (w2 * T::B_PPW + j) * RPP + lane / CH;
                 const int c = swz_rowk<BK>(lane % CH, r);
                 const int64_t hid = (n0 >> 1) + (r >> 6) * 32 + (r & 31);
                 const int64_t grow = ((r >> 5) & 1) * nh + hid;
                 voffB[j] = hid < nh ? (unsigned)(grow * p.ldb * 2 + c * 16) : OOB;
                 kneedB[j] = c * 8;
             }
+            if constexpr (SPLIT) {  // (the requesting wave's first set: the partner's B pieces)
+#pragma unroll
+                for (int j = 0; j < T::B_PPW; ++j) {
+                    const int r = (w1 * T::B_PPW + j) * RPP + lane / CH;
+                    const int c = swz_rowk<BK>(lane % CH, r);
+                    const int64_t hid = (n0 >> 1) + (r >> 6) * 32 + (r & 31);
+                    const int64_t grow = ((r >> 5) & 1) * nh + hid;
+                    voffA[j] = hid < nh ? (unsigned)(grow * p.ldb * 2 + c * 16) : OOB;
+                    kneedA[j] = c * 8;
+                }
+            }
             baseB = p.B;
         }
+    }
+    if constexpr (SPLIT) {  // both sets of a wave come from ONE operand
+        if (a_side) baseB = baseA;
+        else baseA = baseB;
     }
     baseA = uniform_ptr(baseA);
     baseB = uniform_ptr(baseB);
@@ -291,8 +313,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
         const int64_t krem = p.K - (int64_t)t * BK;
         const bf16_t* pa = baseA + t * stepA;
         const bf16_t* pb = baseB + t * stepB;
-        char* dA = smem + stage * T::STAGE + wave * T::A_PPW * 1024;
-        char* dB = smem + stage * T::STAGE + T::A_BYTES + wave * T::B_PPW * 1024;
+        char* dA = smem + stage * T::STAGE + ((SPLIT && !a_side) ? T::A_BYTES : 0) + w1 * T::A_PPW * 1024;
+        char* dB = smem + stage * T::STAGE + ((SPLIT && a_side) ? 0 : T::A_BYTES) + w2 * T::B_PPW * 1024;
 #pragma unroll
         for (int j = 0; j < T::A_PPW; ++j) dma_piece(pa, kneedA[j] < krem ? voffA[j] : OOB, dA + j * 1024);
 #pragma unroll
@@ -757,6 +779,10 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
         const char* sB = sA + T::A_BYTES;
         loadA(aO, sA, 0, 1);
         mma(aE, b0, 0);  // phase 0
+        if constexpr (SPLIT) {  // the B panels of tile t + 1 (its A panels went out behind the last barrier; tile t0 + 1: in front of the loop)
+            static_assert(!SPLIT || T::NS == 2, "written for the two-stage ring");
+            if (!a_side && t > t0 && t + 1 < nt && !(p.ablate & 1)) issue_tile(t + 1, (t + 1 - t0) % T::NS);
+        }
         loadB(b1, sB, 1);
         loadA(aE, sA, 1, 0);
         mma(aO, b0, 1);  // phase 1
@@ -766,7 +792,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of tile t are complete ...
             wait_tile(nt - 2 - t);                              // ... and its share of tile t+1 has landed
             if (!(p.ablate & 4)) __builtin_amdgcn_s_barrier();  // ... for every wave
-            if (t + T::NS < nt && !(p.ablate & 1)) issue_tile(t + T::NS, (t - t0) % T::NS);
+            if (t + T::NS < nt && !(p.ablate & 1) && a_side) issue_tile(t + T::NS, (t - t0) % T::NS);
             const char* nA = smem + ((t + 1 - t0) % T::NS) * T::STAGE;
             loadB(b0, nA + T::A_BYTES, 0);
             loadA(aE, nA, 0, 0);
