@@ -445,6 +445,8 @@ def main():
     ap.add_argument("--ragged", action="store_true", help="text lengths ~ U[256, 512] (padding mask active in attention and loss) instead of all-ones masks")
     ap.add_argument("--optimizer", choices=["on", "off"], default="on", help="also time the same steps with clip + AdamW (reported beside the fwd+bwd metric)")
     ap.add_argument("--vision-ahead", choices=["on", "off"], default="on", help="frozen ViT of the next step's batch on a second stream (vlm_engine.VisionAhead), as the training loop runs it")
+    ap.add_argument("--tower", choices=["default", "fp32", "bf16"], default="default", help="arithmetic of the frozen vision tower (vit_model.tower_precision): fp32 = the reference's "
+                    "(vlm_engine.py:99-104 runs the ViT outside autocast; split-bf16 GEMMs + exact-fp32 attention), bf16 = bf16 MFMA operands on an fp32 residual stream; default = the package's default")
     args = ap.parse_args()
     args.batch_given = args.batch is not None
     if args.batch is None:
@@ -481,6 +483,11 @@ def main():
     _lib.load()
 
     vit, vit_cfg, ad, llm, llm_cfg = build_models(device)
+    if args.tower != "default":
+        vit.tower_precision = args.tower
+    from llm_quest_amd.multimodal.vision_transformer.vit_model import tower_precision
+
+    tower = tower_precision(vit)
     sync = ddp.sync_for_vlm(llm, ad)
     sync.broadcast_parameters([llm, ad, vit])
     img, ids, mask = synthetic_batch(args.batch, device, seed=123 + rank, ragged=args.ragged)
@@ -582,6 +589,7 @@ def main():
                 "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}", "text_mask": "ragged U[256,512]" if args.ragged else "all ones",
                 "units_per_sample": UNITS_PER_SAMPLE,
                 "vision_tower": "frozen ViT forward of the NEXT step's batch on a second HIP stream, one per timed step (vlm_engine.VisionAhead)" if ahead is not None else "in front of the decoder, same stream",
+                "vision_tower_precision": tower + (" (the reference's: fp32-grade split-bf16 GEMMs + exact-fp32 attention)" if tower == "fp32" else " MFMA operands, fp32 residual stream"),
             },
             "roofline": {
                 "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

@@ -262,6 +262,15 @@ int mi355_cast(int64_t n, const void* src, int src_dtype, void* dst, int dst_dty
 /* y[b, s, :] = x[b, s, :] + pos[s, :]  with row 0 of each batch = cls + pos[0] (vit_model.py:86-87,145) */
 int mi355_vit_embed_assemble(int B, int S, int width, const float* patch_proj, const float* cls, const float* pos,
                              float* out, void* stream);
+/* The frozen vision tower at the reference's precision (multimodal/vlm_engine.py:99-104 calls the ViT without autocast: fp32 tensors end to end).
+ * mi355_split3_bf16: x fp32 [rows, K] (row pitch ldx) -> y bf16 [rows, 3K] dense, hi = bf16(x), lo = bf16(x - hi);  weight_order 0: [hi | lo | hi]
+ * (activations), 1: [hi | hi | lo] (weights), so that ONE mi355_gemm_bf16(NT) with K' = 3K accumulates a_hi w_hi + a_lo w_hi + a_hi w_lo in fp32:
+ * the nn.Linear calls of vit_attention.py:58-60,88, vit_transformer_block.py:59-63 and the patch projection vit_model.py:83 at fp32 grade. */
+int mi355_split3_bf16(int64_t rows, int K, const float* x, int64_t ldx, void* y, int weight_order, void* stream);
+/* softmax(Q K^T * scale) V on fp32 tensors, all keys visible (vit_attention.py:73-82), exact-fp32 MFMA.  q/k/v/o token-major [B*S, H*D] views with
+ * row pitches in floats; D == 64, S <= 288. */
+int mi355_attn_f32_fwd(int B, int S, int H, int D, const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                       float* o, int64_t ldo, float scale, void* stream);
 /* sum of squares of a bf16/fp32 vector into out[0] (+=) : global grad-norm for clip_grad_norm_ (engine.py:445).  partials: scratch of
  * MI355_SUMSQ_PARTS floats owned by the caller -- one per stream (per-block partial sums, added in a fixed order: no float atomics). */
 #define MI355_SUMSQ_PARTS 4096

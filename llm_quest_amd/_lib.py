@@ -54,6 +54,8 @@ SIGNATURES = {
     "mi355_layernorm_bwd": [_L, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _F, _I, _P],
     "mi355_cast": [_L, _P, _I, _P, _I, _P],
     "mi355_vit_embed_assemble": [_I, _I, _I, _P, _P, _P, _P, _P],
+    "mi355_split3_bf16": [_L, _I, _P, _L, _P, _I, _P],
+    "mi355_attn_f32_fwd": [_I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L, _F, _P],
     "mi355_sumsq": [_L, _P, _I, _P, _P, _P],
     "mi355_clip_scale": [_L, _P, _I, _P, _F, _P],
     "mi355_add_f32_to_bf16": [_L, _P, _P, _P, _P],

@@ -648,6 +648,30 @@ def cast(src, dtype):
     return dst
 
 
+def split3(x2d, weight_order=False):
+    """fp32 [rows, K] (row-strided view allowed) -> bf16 [rows, 3K]: [hi | lo | hi] (activations) or [hi | hi | lo] (``weight_order``), hi = bf16(x),
+    lo = bf16(x - hi).  One NT GEMM over K' = 3K of an activation block against a weight block is the fp32-grade product (csrc/tower_f32.hip)."""
+    L.require_gpu(x2d)
+    _rowmajor(x2d, "split3 input")
+    if x2d.dtype != F32 or x2d.shape[1] % 8 or x2d.stride(0) % 4:
+        raise ValueError("split3: fp32 rows with a width that is a multiple of 8 and a row pitch that is a multiple of 4")
+    out = torch.empty((x2d.shape[0], 3 * x2d.shape[1]), dtype=BF16, device=x2d.device)
+    L.call("mi355_split3_bf16", x2d.shape[0], x2d.shape[1], L.ptr(x2d), x2d.stride(0), L.ptr(out), int(bool(weight_order)))
+    return out
+
+
+def attn_f32_fwd(q, k, v, B, S, H, D, scale=None):
+    """softmax(q k^T scale) v on fp32 [B*S, H*D] operands (row-strided views allowed), every key visible; returns fp32 [B*S, H*D]."""
+    L.require_gpu(q, k, v)
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _rowmajor(t, n)
+        if t.dtype != F32 or tuple(t.shape) != (B * S, H * D) or t.stride(0) % 4:
+            raise ValueError(f"attn_f32_fwd: {n} must be fp32 [{B * S}, {H * D}] with a row pitch that is a multiple of 4")
+    o = torch.empty((B * S, H * D), dtype=F32, device=q.device)
+    L.call("mi355_attn_f32_fwd", B, S, H, D, L.ptr(q), q.stride(0), L.ptr(k), k.stride(0), L.ptr(v), v.stride(0), L.ptr(o), o.stride(0), D ** -0.5 if scale is None else scale)
+    return o
+
+
 def vit_embed_assemble(proj, cls, pos, B, S, width):
     L.require_gpu(proj, cls, pos)
     out = torch.empty((B, S, width), dtype=F32, device=proj.device)

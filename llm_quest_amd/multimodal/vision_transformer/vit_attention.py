@@ -24,6 +24,21 @@ def bf16_cached(module, tag, params, rows_dim0=True):
     return val
 
 
+def split3_cached(module, tag, params):
+    """[hi | hi | lo] bf16 column blocks of fp32 master weights (concatenated along dim 0): the weight operand of the fp32-grade tower's GEMMs
+    (csrc/tower_f32.hip; the activation side is ``kernels.split3`` in the [hi | lo | hi] order).  Rebuilt only when a parameter changed."""
+    ver = tuple((p.data_ptr(), p._version) for p in params)
+    slot = module.__dict__.setdefault("_bf16_cache", {})
+    hit = slot.get(tag)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    with torch.no_grad():
+        parts = [K.split3(p.detach().reshape(p.shape[0], -1).to(F32).contiguous(), weight_order=True) for p in params]
+        val = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+    slot[tag] = (ver, val)
+    return val
+
+
 def f32_cat_cached(module, tag, params):
     ver = tuple((p.data_ptr(), p._version) for p in params)
     slot = module.__dict__.setdefault("_bf16_cache", {})
@@ -70,6 +85,17 @@ class ViTMultiHeadAttention(nn.Module):
         ctx, _ = K.attn_fwd(qkv[:, :d], qkv[:, d : 2 * d], qkv[:, 2 * d :], B, S, self.num_heads, self.num_heads, self.head_dim,
                             key_mask=None, causal=False, scale=self.att_scaling)
         return ctx
+
+    def context_f32(self, h3, B, S):
+        """The same at the reference's fp32 precision (the frozen tower of multimodal/vlm_engine.py:99-104): ``h3`` = split3 of the LayerNormed fp32
+        tokens -> fp32 context [B*S, d_out] before out_proj.  fp32-grade projections (three bf16 MFMA products), exact-fp32 attention."""
+        d = self.d_out
+        wqkv = split3_cached(self, "wqkv3", [self.w_queries.weight, self.w_keys.weight, self.w_values.weight])
+        bqkv = None
+        if self.w_queries.bias is not None:
+            bqkv = f32_cat_cached(self, "bqkv", [self.w_queries.bias, self.w_keys.bias, self.w_values.bias])
+        qkv = K.gemm(L.GEMM_NT, h3, wqkv, bias=bqkv, out_dtype=F32)
+        return K.attn_f32_fwd(qkv[:, :d], qkv[:, d : 2 * d], qkv[:, 2 * d :], B, S, self.num_heads, self.head_dim, scale=self.att_scaling)
 
     def forward(self, x):
         """x (b, s, d_in) fp32 or bf16 -> (b, s, d_out) in x.dtype.  An ordinary autograd module as upstream (vit_attention.py:44-91): one

@@ -5,7 +5,7 @@ import torch.nn as nn
 
 from llm_quest_amd import _lib as L
 from llm_quest_amd import kernels as K
-from llm_quest_amd.multimodal.vision_transformer.vit_attention import bf16_cached
+from llm_quest_amd.multimodal.vision_transformer.vit_attention import bf16_cached, split3_cached
 from llm_quest_amd.multimodal.vision_transformer.vit_transformer_block import LayerNorm, ViTTransformerBlock
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -28,11 +28,15 @@ class PatchEmbedding2D(nn.Module):
         self.conv_proj = nn.Conv2d(num_channels, emb_dim, kernel_size=(patch_size, patch_size), stride=(patch_size, patch_size), padding=0, bias=True)
         self.cls_token = nn.Parameter(torch.randn(1, 1, emb_dim))
 
-    def project(self, x):
-        """(b, c, h, w) fp32 -> patch projections fp32 [b*num_patches, emb] (bias added, no CLS)."""
+    def project(self, x, f32=False):
+        """(b, c, h, w) fp32 -> patch projections fp32 [b*num_patches, emb] (bias added, no CLS).  ``f32``: pixels and weights as split bf16
+        operands (fp32-grade product, the frozen tower at the reference's precision)."""
         assert x.shape[2] == self.img_width and x.shape[3] == self.img_height, (
             f"Input image shape {x.shape} does not match expected shape {self.img_width}x{self.img_height}"
         )
+        if f32:
+            rows = K.split3(K.patchify(x.contiguous().to(F32), self.patch_size, out_dtype=F32))
+            return K.gemm(L.GEMM_NT, rows, split3_cached(self, "wconv3", [self.conv_proj.weight]), bias=self.conv_proj.bias.detach(), out_dtype=F32)
         rows = K.patchify(x.contiguous().to(F32), self.patch_size, out_dtype=BF16)
         w = bf16_cached(self, "wconv", [self.conv_proj.weight])
         return K.gemm(L.GEMM_NT, rows, w, bias=self.conv_proj.bias.detach(), out_dtype=F32)
@@ -70,6 +74,26 @@ class PatchEmbedding2D(nn.Module):
         return T.run_piece(self, x, fwd, bwd)
 
 
+TOWER_PRECISIONS = ("bf16", "fp32")
+
+
+def tower_precision(vit):
+    """Arithmetic of the FROZEN tower's hidden states (``ViTModel(images, output_hidden_states=True)`` without grad: the vision half of the early-fusion
+    step).  "fp32": what the reference computes there (multimodal/vlm_engine.py:99-104 calls the ViT outside autocast) -- split-bf16 GEMMs + exact-fp32
+    attention, hidden states within 1e-4 of the fp32 reference; "bf16": bf16 MFMA operands with an fp32 residual stream (the dtype flow of the
+    reference's ViT TRAINING path under autocast), hidden states within ~1e-2.  Per model (``vit.tower_precision = ...``) or
+    ``MI355_VIT_TOWER``; DESIGN.md section 4 has the measured price of each."""
+    import os
+
+    val = getattr(vit, "tower_precision", None) or os.environ.get("MI355_VIT_TOWER", DEFAULT_TOWER_PRECISION)
+    if val not in TOWER_PRECISIONS:
+        raise ValueError(f"tower precision must be one of {TOWER_PRECISIONS}, got {val!r}")
+    return val
+
+
+DEFAULT_TOWER_PRECISION = "bf16"  # measured (profiles/r05_notes.md): fp32 costs the early-fusion step 4.0 % (447.1 -> 465.2 ms at per-GPU batch 160)
+
+
 class ViTModel(nn.Module):
     """Patch embed + learned positions + pre-LN encoder + final LN (+ class head) (reference: vit_model.py:92-160)."""
 
@@ -92,12 +116,13 @@ class ViTModel(nn.Module):
         b = x.shape[0]
         pe = self.patch_embedding
         s, d = pe.num_patches + 1, self.pos_embedding.shape[-1]
-        proj = pe.project(x)
+        f32 = output_hidden_states and tower_precision(self) == "fp32"
+        proj = pe.project(x, f32)
         # CLS row + positional embedding in one pass (vit_model.py:86-87,145)
         h = K.vit_embed_assemble(proj, pe.cls_token.detach().reshape(-1).contiguous(), self.pos_embedding.detach().reshape(s, d).contiguous(), b, s, d)
         h2 = h.view(b * s, d)
         for blk in self.transformer_blocks:
-            h2 = blk.run(h2, b, s)
+            h2 = blk.run_f32(h2, b, s) if f32 else blk.run(h2, b, s)
         if output_hidden_states:
             return self.final_ln.normalize(h2, F32).view(b, s, d)
         cls_rows = h2.view(b, s, d)[:, 0].contiguous()

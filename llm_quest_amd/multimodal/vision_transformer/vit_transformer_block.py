@@ -5,7 +5,7 @@ import torch.nn as nn
 
 from llm_quest_amd import _lib as L
 from llm_quest_amd import kernels as K
-from llm_quest_amd.multimodal.vision_transformer.vit_attention import ViTMultiHeadAttention, bf16_cached
+from llm_quest_amd.multimodal.vision_transformer.vit_attention import ViTMultiHeadAttention, bf16_cached, split3_cached
 
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -127,6 +127,19 @@ class ViTTransformerBlock(nn.Module):
         if p > 0:
             return K.dropout(K.gemm(L.GEMM_NT, f, w2, bias=self.ffn.layers[2].bias.detach(), out_dtype=F32), p, *rng.draw(), residual=x2)
         return K.gemm(L.GEMM_NT, f, w2, bias=self.ffn.layers[2].bias.detach(), residual=x2, out_dtype=F32)
+
+    def run_f32(self, x2d, B, S):
+        """x2d fp32 [B*S, d] -> fp32 [B*S, d] at the reference's fp32 precision (inference only: the frozen tower of the early-fusion step,
+        multimodal/vlm_engine.py:99-104).  Every nn.Linear is ONE bf16 MFMA GEMM over split operands ([hi | lo | hi] x [hi | hi | lo], K' = 3K, fp32
+        accumulation and output), attention runs on the exact-fp32 MFMA, LayerNorm / GELU / residual adds in fp32 as before."""
+        if self.training and (self.dropout.p > 0 or self.att.dropout.p > 0):
+            raise RuntimeError("ViTTransformerBlock.run_f32 is the frozen tower's inference path: call .eval() (dropout is active)")
+        att, ffn = self.att, self.ffn
+        ctx = att.context_f32(K.split3(self.ln_1.normalize(x2d, F32)), B, S)
+        x2 = K.gemm(L.GEMM_NT, K.split3(ctx), split3_cached(att, "wo3", [att.out_proj.weight]), bias=att.out_proj.bias.detach(), residual=x2d, out_dtype=F32)
+        h = K.split3(self.ln_2.normalize(x2, F32))
+        f = K.gemm(L.GEMM_NT, h, split3_cached(ffn, "w1_3", [ffn.layers[0].weight]), bias=ffn.layers[0].bias.detach(), gelu=True, out_dtype=F32)
+        return K.gemm(L.GEMM_NT, K.split3(f), split3_cached(ffn, "w2_3", [ffn.layers[2].weight]), bias=ffn.layers[2].bias.detach(), residual=x2, out_dtype=F32)
 
     def forward(self, x):
         """(b, s, d) -> (b, s, d) in x.dtype; trains stand-alone (one autograd node over ``vit_train.block_forward`` / ``block_backward``,

@@ -193,17 +193,19 @@ def test_full_size_step_loss_at_init_and_determinism():
 
 
 def test_full_size_step_matches_the_cpu_oracle():
-    """BASELINE config 4 at FULL model size against the CPU oracle itself (2 samples, all 28 layers, S = 709, V = 151 936): the oracle --
-    pinned to the reference by the fixtures -- runs the same weights and inputs twice, in bf16 (the reference's arithmetic) and in fp32
-    (the twin).  Loss of the whole step (own vision tower): within 1e-3 relative of the fp32-evaluated loss.  Gradients of the first, a middle
-    and the last block (query / key projections, QK-norm and block-norm weights, a down projection), of the final norm, the tied embedding /
-    head matrix and the adapter: within 1.5x the oracle's own bf16-vs-fp32 distance (the 1.5x rule, no additive slack at floors >= 1e-2).  A
-    deterministic but wrong kernel at a shape the tiny fixtures never reach (16 heads x 28 layers, N = 151 936) cannot pass this.
+    """BASELINE config 4 at FULL model size against the CPU oracle itself (2 samples, all 28 layers, S = 709, V = 151 936), the PRODUCT path end to
+    end: own frozen tower -> adapter -> fusion -> decoder -> loss -> backward.  The oracle -- pinned to the reference by the fixtures -- runs the same
+    weights and inputs twice, in bf16 (the reference's arithmetic) and in fp32 (the twin).  Loss: within 1e-3 relative of the fp32-evaluated loss.
+    Gradients of the first, a middle and the last block (query / key projections, QK-norm and block-norm weights, a down projection), of the final
+    norm, the tied embedding / head matrix and the adapter: within 1.5x the oracle's own bf16-vs-fp32 distance (the 1.5x rule, no additive slack at
+    floors >= 1e-2).  A deterministic but wrong kernel at a shape the tiny fixtures never reach (16 heads x 28 layers, N = 151 936) cannot pass this.
 
-    The decoder's gradients are judged on the oracle tower's hidden states: the frozen ViT here multiplies bf16 operands on an fp32 residual
-    stream where the reference's VLM loop runs it in fp32 (conscious deviations) -- 1e-2 on the hidden states, asserted
-    below -- and the softmax is sensitive to that perturbation of the 197 vision keys: with the own tower the query / key path sits at
-    1.4-1.75x the floor (tools/diag_grad_noise.py), with the oracle's at 1.0-1.25x, every other tensor at 1.0x either way."""
+    Both tower arithmetics are judged (vit_model.tower_precision):
+      * "fp32" (what the reference's VLM loop computes, multimodal/vlm_engine.py:99-104; +4.0 % step time): hidden states within 1e-4 of the oracle's
+        fp32 tower, every gradient on the 1.5x rule;
+      * "bf16" (the default; bf16 MFMA operands on an fp32 residual stream): hidden states at 1e-2 -- five bf16 roundings away from the reference -- and the softmax
+        is sensitive to that perturbation of the 197 vision keys: the four query / key tensors are held to 2.0x the floor (measured 1.4-1.75x,
+        tools/diag_grad_noise.py), everything else to 1.5x."""
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
     import bench
@@ -217,20 +219,10 @@ def test_full_size_step_matches_the_cpu_oracle():
     vit_sd = {k: v.detach().cpu() for k, v in vit.state_dict().items()}
     with torch.no_grad():
         hid_ref = models.vit_forward(vit_sd, vit_cfg, img, output_hidden_states=True)
-        hid_mine = _vision_states(vit, img.to(dev), False)
-    dev_tower = float((hid_mine.double().cpu() - hid_ref.double()).norm() / hid_ref.double().norm())
-    assert dev_tower < 2e-2, f"frozen tower (bf16 MFMA operands) vs the reference's fp32 tower: {dev_tower:.3e}"
-    loss_own = vlm_step_loss(vit, llm, ad, img.to(dev), ids.to(dev), mask.to(dev), hf_vit_model=False)
-    loss = vlm_step_loss(vit, llm, ad, img.to(dev), ids.to(dev), mask.to(dev), hf_vit_model=False, vit_hidden=hid_ref.to(dev))
-    loss.backward()
     picks = {"llm": ["trf_blocks.0.att.w_queries.weight", "trf_blocks.27.att.w_queries.weight", "trf_blocks.13.ffn.lin2.weight", "final_norm.weight",
                      "emb_dict.weight", "trf_blocks.13.norm2.weight", "trf_blocks.20.att.k_norm.weight", "trf_blocks.20.att.w_keys.weight", "trf_blocks.27.att.q_norm.weight"],
              "ad": ["adapter.0.weight", "adapter.3.weight"]}
-    mine = {}
-    for key, mod in (("llm", llm), ("ad", ad)):
-        named = dict(mod.named_parameters())
-        for n in picks[key]:
-            mine[key + "." + n] = named[n].grad.float().cpu()
+    qk_path = ("w_queries", "w_keys", "q_norm", "k_norm")
     skip = ("mask", "cos", "sin", "out_head.weight")
 
     def oracle_run(dtype):
@@ -247,13 +239,29 @@ def test_full_size_step_matches_the_cpu_oracle():
 
     l_bf16, g_bf16 = oracle_run(BF16)
     l_fp32, g_fp32 = oracle_run(F32)
-    assert abs(float(loss_own) - l_fp32) / l_fp32 < 1e-3, (float(loss_own), l_fp32, l_bf16)
-    assert abs(float(loss) - l_fp32) / l_fp32 < 1e-3, (float(loss), l_fp32, l_bf16)
-    for name, twin in g_fp32.items():
-        floor = float((g_bf16[name].double() - twin.double()).norm() / twin.double().norm())
-        err = float((mine[name].double() - twin.double()).norm() / twin.double().norm())
-        print(f"{name}: mine {err:.3e} floor {floor:.3e}")
-        assert err <= _tol(floor), f"{name}: vs fp32 oracle {err:.3e}, bf16 oracle floor {floor:.3e}"
+    floors = {n: float((g_bf16[n].double() - g_fp32[n].double()).norm() / g_fp32[n].double().norm()) for n in g_fp32}
+
+    for tower, hid_bound in (("fp32", 1e-4), ("bf16", 2e-2)):
+        vit.tower_precision = tower
+        with torch.no_grad():
+            hid_mine = _vision_states(vit, img.to(dev), False)
+        dev_tower = float((hid_mine.double().cpu() - hid_ref.double()).norm() / hid_ref.double().norm())
+        print(f"tower {tower}: hidden states vs the oracle's fp32 tower {dev_tower:.3e}")
+        assert dev_tower < hid_bound, f"frozen tower ({tower}) vs the reference's fp32 tower: {dev_tower:.3e}"
+        llm.zero_grad(set_to_none=True)
+        ad.zero_grad(set_to_none=True)
+        loss = vlm_step_loss(vit, llm, ad, img.to(dev), ids.to(dev), mask.to(dev), hf_vit_model=False)
+        loss.backward()
+        assert abs(float(loss) - l_fp32) / l_fp32 < 1e-3, (tower, float(loss), l_fp32, l_bf16)
+        for key, mod in (("llm", llm), ("ad", ad)):
+            named = dict(mod.named_parameters())
+            for n in picks[key]:
+                name = key + "." + n
+                twin, floor = g_fp32[name], floors[name]
+                err = float((named[n].grad.float().cpu().double() - twin.double()).norm() / twin.double().norm())
+                factor = 2.0 if (tower == "bf16" and any(t in n for t in qk_path)) else 1.5
+                print(f"tower {tower} {name}: mine {err:.3e} floor {floor:.3e} ({err / floor:.2f}x, bound {factor}x)")
+                assert err <= _tol(floor, factor), f"tower {tower} {name}: vs fp32 oracle {err:.3e}, bf16 oracle floor {floor:.3e}"
 
 
 def _tol(floor, factor=1.5):
