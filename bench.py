@@ -600,6 +600,10 @@ def main():
             },
             "loss": round(loss_gpu, 5), "peak_memory_gib": round(torch.cuda.max_memory_allocated(device) / 2**30, 1),
         }
+        if world > 1:  # how the N > 1 step's large NT GEMMs were launched: on the persistent kernel, or on the per-tile kernel inside a window behind a bucket group (ddp.GradSync)
+            from llm_quest_amd import kernels as K_
+
+            line["gemm_windows"] = dict(K_._WINDOW.stats, bucket_blocks=sync.bucket_blocks, window_launches=sync.window_launches)
         if train_step is not None:
             line["with_optimizer_step"] = train_step
         if world == 1:

@@ -33,6 +33,15 @@ and 160 x 512 it is 0.17 GB against 0.31 GB (split).  Without a token count (``b
 with one 16-byte all-reduce (MIN / MAX of T, on a control stream of its own) and raises on EVERY rank instead of hanging in ``all_gather_into_tensor``.
 All ranks must either pass a count or pass none.
 
+Bucket groups and GEMM windows (round 5).  The compute stream's large NT GEMMs run on a persistent kernel -- one workgroup per CU for the launch's whole length,
+all 256 starting together -- and a collective's channels are workgroups that hold CUs: a persistent launch beside a collective lasts up to twice as long, the per-tile
+form of the same kernel loses 17-27 % (tools/contention.py).  So the block buckets go out in GROUPS of ``MI355_DDP_BUCKET_BLOCKS`` (default 7: four groups for the 28
+blocks; the collectives of a group run back to back on the communication stream from the moment its last block is complete), and behind each group the compute stream
+runs a WINDOW: its next ``MI355_DDP_WINDOW_LAUNCHES`` (default 2) persistent-sized NT launches take the per-tile kernel (``kernels.open_gemm_window``) -- the first two
+dgrad GEMMs of the following block, ~2.2 ms against ~1.3 ms of ring all-reduce for 7 x 31.5 MB on eight ranks -- then the compute stream waits for the group's
+completion event (a bound on the worst case, not a stall in the normal one) and the persistent kernel is back.  Five windows per step instead of a whole backward on
+the slower kernel; ``kernels._WINDOW.stats`` counts both kinds of launch and ``bench.py`` prints them for N > 1.
+
 Gradient accumulation: wrap every micro-step but the last in ``with sync.no_sync():`` -- the hooks then leave the buckets
 alone (they keep accumulating locally) and ``finish_step`` is a no-op; the last micro-step exchanges the sums.
 """
@@ -107,6 +116,10 @@ class GradSync:
         self._events = {}
         self._split_now = False       # this step exchanges the early_tail arena in two parts (decided in begin_step)
         self._ctl_stream = None       # the per-step token-count check runs here (begin_step)
+        self.bucket_blocks = max(1, int(os.environ.get("MI355_DDP_BUCKET_BLOCKS", "7")))      # owner buckets per group (one window per group)
+        self.window_launches = max(0, int(os.environ.get("MI355_DDP_WINDOW_LAUNCHES", "2")))  # per-tile NT launches behind a group; 0 = no windows (persistent kernel always)
+        self._group = []              # complete buckets waiting for their group to fill
+        self._group_events = []       # completion events of the groups, reused every step
 
     # ---------------------------------------------------------------- loss weighting / accumulation
     def loss_weight(self, n_tokens):
@@ -155,7 +168,6 @@ class GradSync:
             if ev is None:
                 ev = self._events[id(arena)] = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(buf.device))
-            self._collectives_beside_compute()
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
                 if self.backend == "nccl":
@@ -168,15 +180,34 @@ class GradSync:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
             buf.div_(self.world)
 
-    def _collectives_beside_compute(self):
-        """From here to the join in finish_step a collective's channels may hold CUs: GEMM launches issued meanwhile must not be the persistent kernel
-        (kernels.persistent_gemm: its workgroups have to start together).  Launches already queued are in front of the bucket's event, i.e. finished before the
-        collective starts."""
-        if not self._beside:
-            from . import kernels as K
+    def _window_behind(self, device):
+        """The collectives just enqueued run beside the compute stream: its next ``window_launches`` persistent-sized NT GEMMs take the per-tile kernel, then it waits for
+        their completion event and returns to the persistent kernel (module docstring).  Launches already queued are in front of the buckets' events, i.e. finished
+        before the collectives start."""
+        if self.comm_stream is None or self.window_launches == 0:
+            return
+        from . import kernels as K
 
-            K.persistent_gemm(False)
-            self._beside = True
+        n = K._WINDOW.stats["windows"] % 8
+        while len(self._group_events) <= n:
+            self._group_events.append(torch.cuda.Event())
+        done = self._group_events[n]
+        done.record(self.comm_stream)
+        K.open_gemm_window(self.window_launches, lambda: torch.cuda.current_stream(device).wait_event(done))
+        self._beside = True
+
+    def _flush_group(self):
+        """Hand the waiting buckets to the communication stream, back to back, and open the compute stream's window behind them."""
+        if not self._group:
+            return
+        device = None
+        for ar in self._group:
+            self._reduce(ar)
+            if ar.grad.is_cuda:
+                device = ar.grad.device
+        self._group.clear()
+        if device is not None:
+            self._window_behind(device)
 
     def _on_ready(self, module):
         if not self.enabled or not self._sync_on:
@@ -186,13 +217,17 @@ class GradSync:
             if id(top) not in self._done and top.trainable():
                 self._done.add(id(top))
                 top.untouched_to_zero()
-                self._reduce(top)
+                self._reduce(top)  # the dense part of the tied bucket: at once, under the blocks still to come, with a window of its own
+                if top.grad.is_cuda:
+                    self._window_behind(top.grad.device)
         ar = self._arena(module)
         if id(ar) in self._done:
             return
         self._done.add(id(ar))
         ar.untouched_to_zero()
-        self._reduce(ar)
+        self._group.append(ar)
+        if len(self._group) >= self.bucket_blocks:
+            self._flush_group()
 
     # ---------------------------------------------------------------- the embedding's sparse part of a split bucket
     def splits(self, arena):
@@ -259,6 +294,7 @@ class GradSync:
         exchanged in two parts when ``split_pays`` says so.  Every rank must pass the same value (checked on first use)."""
         global _ACTIVE
         self._done.clear()
+        self._group.clear()
         self._split_now = False
         if embedding_tokens is not None and self.enabled and self._sync_on and self.early_tail is not None:
             self._check_equal_tokens(int(embedding_tokens))  # collective: every rank that passes a count takes part, whatever it then decides
@@ -269,6 +305,7 @@ class GradSync:
         """Reduce buckets not yet sent, then order the compute stream after the communication stream."""
         if not self.enabled or not self._sync_on:
             return
+        self._flush_group()  # a partly filled group (the adapter's bucket, the blocks behind the last full group)
         for m in self.owners:  # anything whose hook never fired (e.g. unused in this step)
             ar = self._arena(m)
             if id(ar) not in self._done and ar.trainable():
@@ -283,10 +320,10 @@ class GradSync:
         self._reduce_tail_params()
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
-        if self._beside:
+        if self._beside:  # the streams have joined: whatever window is still open ends here
             from . import kernels as K
 
-            K.persistent_gemm(True)
+            K.close_gemm_window()
             self._beside = False
         global _ACTIVE
         _ACTIVE = None

@@ -61,6 +61,62 @@ def persistent_gemm(enabled):
         os.environ["MI355_GEMM_PERSIST_MIN_TILES"] = _PERSIST_USER
 
 
+PERSIST_MIN_TILES = 512  # csrc/gemm.hip: persist_min_tiles()
+
+
+class _GemmWindow:
+    """A bounded stretch of the compute stream in which NT launches stay off the persistent kernel (``ddp.GradSync`` opens one behind every bucket group it hands to the
+    communication stream): ``left`` launches to go, then ``on_close`` -- the compute stream waits for the group's collectives -- and the library's own choice is back."""
+
+    def __init__(self):
+        self.left, self.on_close = 0, None
+        self.stats = {"persistent_eligible": 0, "inside_window": 0, "windows": 0}
+
+
+_WINDOW = _GemmWindow()
+
+
+def open_gemm_window(launches, on_close=None):
+    """The next ``launches`` persistent-sized NT GEMM launches run on the per-tile kernel (a collective's channels hold CUs meanwhile; the persistent kernel's 256 workgroups
+    must all start together, see ``persistent_gemm``); in front of the launch after them ``on_close()`` runs and the persistent kernel is allowed again.  A window opened
+    while one is open extends it; both hand-offs run at its end."""
+    w = _WINDOW
+    if w.left == 0 and w.on_close is None:
+        persistent_gemm(False)
+        w.stats["windows"] += 1
+    w.left = max(w.left, int(launches))
+    if on_close is not None:
+        prev = w.on_close
+        w.on_close = on_close if prev is None else (lambda: (prev(), on_close()))
+    elif w.on_close is None:
+        w.on_close = lambda: None
+
+
+def close_gemm_window():
+    """End the window now (``GradSync.finish_step``; also the first launch behind a window's last one)."""
+    w = _WINDOW
+    if w.left == 0 and w.on_close is None:
+        return
+    cb, w.left, w.on_close = w.on_close, 0, None
+    if cb is not None:
+        cb()
+    persistent_gemm(True)
+
+
+def _nt_tick(M, N):
+    """Called in front of every NT launch that is large enough for the persistent kernel."""
+    if ((M + 255) // 256) * ((N + 255) // 256) < PERSIST_MIN_TILES:
+        return
+    w = _WINDOW
+    if w.left > 0:
+        w.left -= 1
+        w.stats["inside_window"] += 1
+        return
+    if w.on_close is not None:
+        close_gemm_window()
+    w.stats["persistent_eligible"] += 1
+
+
 def gemm(form, a, b, out=None, out_dtype=BF16, bias=None, residual=None, gelu=False, allow_split_k=True, tile=0):
     """C = epi(op(A) op(B) + bias) + residual.  form NT: A[M,K] B[N,K]; NN: A[M,K] B[K,N]; TN: A[K,M] B[K,N]."""
     L.require_gpu(a, b, out, bias, residual)
@@ -92,6 +148,8 @@ def gemm(form, a, b, out=None, out_dtype=BF16, bias=None, residual=None, gelu=Fa
         if residual.dtype != out.dtype or tuple(residual.shape) != (M, N):
             raise ValueError("gemm: residual must match the output's shape and dtype")
         ldr = residual.stride(0)
+    if form == L.GEMM_NT:
+        _nt_tick(M, N)
     L.call(
         "mi355_gemm_bf16", form, M, N, K, L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), L.ptr(out), out.stride(0),
         L.dt_code(out.dtype), L.ptr(bias), L.ptr(residual), ldr, L.EPI_GELU if gelu else L.EPI_NONE,
@@ -195,6 +253,7 @@ def gemm_gateup_swiglu(x, w_fused, tile=0):
         raise ValueError("gemm_gateup_swiglu: bf16 X [M, K], fused weight [2F, K] with F % 32 == 0")
     gu = torch.empty((M, N), dtype=BF16, device=x.device)
     a = torch.empty((M, N // 2), dtype=BF16, device=x.device)
+    _nt_tick(M, N)
     L.call("mi355_gemm_bf16", L.GEMM_NT, M, N, Kd, L.ptr(x), x.stride(0), L.ptr(w_fused), w_fused.stride(0), L.ptr(gu), gu.stride(0), L.DT_BF16, None,
            L.ptr(a), a.stride(0), L.EPI_SWIGLU_FWD, None, 0, tile or _TILE_SWIGLU_FWD or _TILE_BY_FORM[L.GEMM_NT] or _TILE_OVERRIDE)
     return gu, a
@@ -213,6 +272,7 @@ def gemm_dgrad_swiglu_bwd(dy, w, gu, tile=0):
     out = torch.empty_like(gu)
     if DGRAD_NT and M >= DGRAD_NT_MIN_ROWS:
         wt = transpose(w)  # [F, N_out]: the same product in the K-contiguous form
+        _nt_tick(M, F)
         L.call("mi355_gemm_bf16", L.GEMM_NT, M, F, Kd, L.ptr(dy), dy.stride(0), L.ptr(wt), wt.stride(0), L.ptr(out), out.stride(0), L.DT_BF16, None,
                L.ptr(gu), gu.stride(0), L.EPI_SWIGLU_BWD, None, 0, tile or _TILE_SWIGLU_BWD or _TILE_BY_FORM[L.GEMM_NT] or _TILE_OVERRIDE)
         return out
@@ -456,6 +516,7 @@ def dgrad_attn_delta(dy, w, ctx, lse, B, S, Hq, D):
     L.require_gpu(dy, wt, ctx, lse)
     out = torch.empty((M, N), dtype=BF16, device=dy.device)
     delta = torch.empty_like(lse)
+    _nt_tick(M, N)
     L.call("mi355_gemm_bf16_attn_delta", M, N, Kd, L.ptr(dy), dy.stride(0), L.ptr(wt), wt.stride(0), L.ptr(out), out.stride(0), L.ptr(ctx), ctx.stride(0),
            S, Hq, D, L.ptr(lse), L.ptr(delta), ws.data_ptr() + off0, ws.data_ptr() + off1)
     return out, delta

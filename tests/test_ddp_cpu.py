@@ -300,3 +300,68 @@ def test_persistent_gemm_switch_restores_the_users_threshold(monkeypatch):
     assert os.environ[var] == "1000000000"
     K.persistent_gemm(True)
     assert os.environ[var] == "64"
+
+
+def test_gemm_window_bounds_the_per_tile_stretch_behind_a_bucket_group(monkeypatch):
+    """kernels.open_gemm_window(k, on_close): the next k persistent-sized NT launches stay off the persistent kernel, the launch after them first runs the
+    hand-off (the compute stream's wait for the group's collectives) and re-enables it; small launches do not count; a window opened inside a window extends
+    it and both hand-offs run; close_gemm_window ends it at once (GradSync.finish_step)."""
+    import os
+
+    from llm_quest_amd import kernels as K
+
+    var = "MI355_GEMM_PERSIST_MIN_TILES"
+    monkeypatch.delenv(var, raising=False)
+    monkeypatch.setattr(K, "_PERSIST_USER", None)
+    monkeypatch.setattr(K, "_WINDOW", K._GemmWindow())
+    big, small = (113440, 4096), (2048, 1024)
+    calls = []
+    K._nt_tick(*big)
+    assert K._WINDOW.stats == {"persistent_eligible": 1, "inside_window": 0, "windows": 0} and var not in os.environ
+    K.open_gemm_window(2, lambda: calls.append("a"))
+    assert os.environ[var] == "1000000000"
+    K._nt_tick(*small)  # 32 tiles: never persistent, not counted
+    K._nt_tick(*big)
+    K.open_gemm_window(2, lambda: calls.append("b"))  # a second group while the window is open: two more launches, both hand-offs at the end
+    K._nt_tick(*big)
+    K._nt_tick(*big)
+    assert calls == [] and os.environ[var] == "1000000000" and K._WINDOW.stats["inside_window"] == 3
+    K._nt_tick(*big)  # the first launch behind the window: hand-offs first, then persistent again
+    assert calls == ["a", "b"] and var not in os.environ
+    assert K._WINDOW.stats == {"persistent_eligible": 2, "inside_window": 3, "windows": 1}
+    K.open_gemm_window(5, lambda: calls.append("c"))
+    K.close_gemm_window()
+    assert calls == ["a", "b", "c"] and var not in os.environ and K._WINDOW.left == 0
+    K.close_gemm_window()  # idempotent
+    assert calls == ["a", "b", "c"]
+
+
+def test_block_buckets_leave_in_groups(monkeypatch):
+    """GradSync collects complete block buckets and hands them over MI355_DDP_BUCKET_BLOCKS at a time; finish_step flushes the rest."""
+    from llm_quest_amd import ddp
+
+    class FakeArena:
+        def __init__(self):
+            self.grad = torch.zeros(4)
+
+        def untouched_to_zero(self):
+            pass
+
+        def trainable(self):
+            return True
+
+    owners = [torch.nn.Linear(2, 2) for _ in range(5)]
+    arenas = {id(m): FakeArena() for m in owners}
+    monkeypatch.setenv("MI355_DDP_BUCKET_BLOCKS", "2")
+    sync = ddp.GradSync(owners)
+    sync.enabled, sync.world = True, 2
+    sent = []
+    monkeypatch.setattr(sync, "_arena", lambda m: arenas[id(m)])
+    monkeypatch.setattr(sync, "_reduce", lambda ar: sent.append(ar))
+    monkeypatch.setattr(sync, "_reduce_tail_params", lambda: None)
+    sync.begin_step()
+    for i, m in enumerate(owners):
+        m._grad_ready(m)
+        assert len(sent) == 2 * ((i + 1) // 2), (i, len(sent))
+    sync.finish_step()
+    assert sent == [arenas[id(m)] for m in owners]

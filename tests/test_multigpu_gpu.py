@@ -138,6 +138,10 @@ def test_bench_two_rank_rehearsal_runs_the_whole_n_gt_1_path_on_one_gpu():
     d2 = json.loads(lines[0])
     assert d2["rehearsal"] is True and d2["n_gpus"] == 2 and d2["rccl_ranks"] == 0 and d2["config"]["global_batch"] == 8 and d2["scaling"] == "weak"
     assert d2["value"] > 0 and d2["steps"] == 2
+    # bucket groups + GEMM windows (ddp.GradSync): only the two launches behind each group (and behind the early dense part of the tied bucket) leave the persistent
+    # kernel -- not the whole backward.  At batch 4 no launch is persistent-sized: a step's windows never count down, merge into one and end in finish_step.
+    gw = d2["gemm_windows"]
+    assert gw["bucket_blocks"] == 7 and gw["window_launches"] == 2 and gw["windows"] >= 3 and gw["inside_window"] == 0, gw
     env1 = {k: v for k, v in os.environ.items() if k != "MI355_DDP_REHEARSAL"}
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, env=env1, capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-3000:]
