@@ -457,6 +457,16 @@ int mi355_attn_dropout_bwd(int B, int S, int Hq, int Hkv, int D, const void* q, 
                            int64_t ldv, const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* lse, float* delta, void* dq,
                            int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int causal, float scale, float p, uint64_t seed,
                            uint64_t offset, void* stream);
+/* The SDPA call of GatedAttention / MRoPEGatedAttention WITH dropout_p and a padding mask (qwen3_next_attention.py:240-253, qwen3_5_text_model.py:244-259): the mask
+ * semantics of mi355_attn_generic_fwd (causal OR padded key, upstream's quirk included) with the Philox dropout of mi355_attn_dropout_fwd on the normalised weights.
+ * key_mask uint8 [B, S] (1 = real token) or NULL. */
+int mi355_attn_generic_dropout_fwd(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
+                                   int64_t ldv, void* o, int64_t ldo, float* lse, const uint8_t* key_mask, float scale, float p, uint64_t seed,
+                                   uint64_t offset, void* stream);
+int mi355_attn_generic_dropout_bwd(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
+                                   int64_t ldv, const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* lse, float* delta,
+                                   void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, const uint8_t* key_mask, float scale,
+                                   float p, uint64_t seed, uint64_t offset, void* stream);
 
 #ifdef __cplusplus
 }

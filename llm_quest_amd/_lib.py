@@ -99,6 +99,8 @@ SIGNATURES = {
     "mi355_rope_apply": [_I, _I, _I, _I, _I, _P, _I, _L, _L, _L, _P, _P, _L, _P, _P, _L, _L, _L, _I, _P],
     "mi355_dropout": [_L, _P, _I, _P, _P, _I, _F, _U, _U, _P],
     "mi355_attn_dropout_fwd": [_I, _I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _I, _F, _F, _U, _U, _P],
+    "mi355_attn_generic_dropout_fwd": [_I, _I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _F, _F, _U, _U, _P],
+    "mi355_attn_generic_dropout_bwd": [_I, _I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _L, _P, _L, _P, _L, _P, _F, _F, _U, _U, _P],
     "mi355_attn_dropout_bwd": [_I, _I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _L, _P, _L, _P, _L, _I, _F, _F, _U, _U, _P],
 }
 # size / constant queries: no stream argument, the return value is the answer (name -> (argtypes, restype))

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void ga_fwd_kernel(int B, int S, int Hq, int H
         for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[dt][i] *= alpha;
-        if (PLAIN && da.thresh) {  // dropout on the weights that multiply V; the row sum above keeps every key
+        if (da.thresh) {  // dropout on the weights that multiply V; the row sum above keeps every key
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float mul[4];
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void ga_bwd_dq_kernel(int B, int S, int Hq, in
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(kimg, ks, lane), qf[ks], s, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(vimg, ks, lane), gf[ks], dp, 0, 0, 0);
         }
-        if (PLAIN && da.thresh) {
+        if (da.thresh) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float mul[4];
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void ga_bwd_dkv_kernel(int B, int S, int Hq, i
                 const bool ok = PLAIN ? (kvalid && qi < S && (!da.causal || key <= qi)) : (kvalid && qi < S && (key <= qi || padded));
                 const float p = ok ? exp2f(s[i] * scale_log2 - stat[0][r]) : 0.f;
                 float keep = 1.f;
-                if (PLAIN && da.thresh) {  // this lane's key inside its group of four, for attention row (b, hq, qi)
+                if (da.thresh) {  // this lane's key inside its group of four, for attention row (b, hq, qi)
                     unsigned bits[4];
                     philox4x32_10((unsigned)key >> 2, (unsigned)(((int64_t)b * Hq + hq) * S + qi), da.o0, da.o1, da.k0, da.k1, bits);
                     const unsigned bsel = (key & 3) == 0 ? bits[0] : (key & 3) == 1 ? bits[1] : (key & 3) == 2 ? bits[2] : bits[3];
@@ -479,5 +479,55 @@ extern "C" int mi355_attn_dropout_bwd(int B, int S, int Hq, int Hkv, int D, cons
 #undef LAUNCH_DQ
 #undef LAUNCH_DKV
     MI355_LAUNCH_CHECK("attn_dropout_bwd");
+    return 0;
+}
+
+// ---- the reference's SDPA call WITH dropout_p and a padding mask (GatedAttention in training mode on padded batches, qwen3_next_attention.py:240-253):
+// the quirk-mask kernels (PLAIN = false) with the dropout arguments set -- Philox masks on the normalised weights, regenerated by the backward.
+extern "C" int mi355_attn_generic_dropout_fwd(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
+                                              int64_t ldv, void* o, int64_t ldo, float* lse, const uint8_t* key_mask, float scale, float p, uint64_t seed,
+                                              uint64_t offset, void* stream) {
+    if (check_ga(B, S, Hq, Hkv, D, ldq, ldk, ldv, ldo)) return 1;
+    MI355_REQUIRE(q && k && v && o && lse, "attn_generic_dropout_fwd: null pointer");
+    DropArgs da;
+    if (make_drop_args("attn_generic_dropout_fwd", B, S, Hq, 1, p, seed, offset, &da)) return 1;
+    dim3 grid((S + 127) / 128, Hq, B);
+#define LAUNCH(DD) ga_fwd_kernel<DD, false><<<grid, 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, key_mask, scale * LOG2E, da)
+    switch (D) {
+        case 32: LAUNCH(32); break;
+        case 64: LAUNCH(64); break;
+        case 128: LAUNCH(128); break;
+        default: LAUNCH(256); break;
+    }
+#undef LAUNCH
+    MI355_LAUNCH_CHECK("attn_generic_dropout_fwd");
+    return 0;
+}
+
+extern "C" int mi355_attn_generic_dropout_bwd(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
+                                              int64_t ldv, const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* lse, float* delta,
+                                              void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, const uint8_t* key_mask, float scale,
+                                              float p, uint64_t seed, uint64_t offset, void* stream) {
+    if (check_ga(B, S, Hq, Hkv, D, ldq, ldk, ldv, ldo)) return 1;
+    if (check_ga(B, S, Hq, Hkv, D, lddq, lddk, lddv, lddo)) return 1;
+    MI355_REQUIRE(q && k && v && o && d_o && lse && delta && dq && dk && dv, "attn_generic_dropout_bwd: null pointer");
+    DropArgs da;
+    if (make_drop_args("attn_generic_dropout_bwd", B, S, Hq, 1, p, seed, offset, &da)) return 1;
+    const int64_t tokens = (int64_t)B * S;
+    int64_t dg = (tokens * Hq + 3) / 4;
+    ga_delta_kernel<<<(int)(dg > 8192 ? 8192 : dg), 256, 0, ST(stream)>>>(tokens, S, Hq, D, (const bf16_t*)o, ldo, (const bf16_t*)d_o, lddo, delta);
+    MI355_LAUNCH_CHECK("attn_generic_dropout_bwd(delta)");
+    dim3 gq((S + 127) / 128, Hq, B);
+#define LAUNCH_DQ(DD) ga_bwd_dq_kernel<DD, false><<<gq, 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dq, lddq, key_mask, scale, da)
+#define LAUNCH_DKV(DD, NP) ga_bwd_dkv_kernel<DD, NP, false><<<dim3(((S + 127) / 128) * NP, Hkv, B), 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, key_mask, scale, da)
+    switch (D) {
+        case 32: LAUNCH_DQ(32); LAUNCH_DKV(32, 1); break;
+        case 64: LAUNCH_DQ(64); LAUNCH_DKV(64, 1); break;
+        case 128: LAUNCH_DQ(128); LAUNCH_DKV(128, 1); break;
+        default: LAUNCH_DQ(256); LAUNCH_DKV(256, 2); break;
+    }
+#undef LAUNCH_DQ
+#undef LAUNCH_DKV
+    MI355_LAUNCH_CHECK("attn_generic_dropout_bwd");
     return 0;
 }

@@ -964,3 +964,33 @@ def attn_dropout_bwd(q, k, v, o, do, lse, B, S, Hq, Hkv, D, dq, dk, dv, p, seed,
     L.call("mi355_attn_dropout_bwd", B, S, Hq, Hkv, D, L.ptr(q), q.stride(0), L.ptr(k), k.stride(0), L.ptr(v), v.stride(0), L.ptr(o), o.stride(0),
            L.ptr(do), do.stride(0), L.ptr(lse), L.ptr(delta), L.ptr(dq), dq.stride(0), L.ptr(dk), dk.stride(0), L.ptr(dv), dv.stride(0),
            int(causal), scale, float(p), int(seed), int(offset))
+
+
+def attn_generic_dropout_fwd(q, k, v, B, S, Hq, Hkv, D, p, seed, offset, key_mask=None, scale=None):
+    """The SDPA call of (MRoPE)GatedAttention with ``dropout_p`` AND a padding mask: mask semantics of ``kernels_q35.attn_generic_fwd`` (causal, padded keys visible
+    -- upstream's quirk), Philox dropout on the normalised weights as ``attn_dropout_fwd``.  Layout as attn_fwd."""
+    L.require_gpu(q, k, v, key_mask)
+    _check_attn_operand(q, "q", B * S, Hq * D)
+    _check_attn_operand(k, "k", B * S, Hkv * D)
+    _check_attn_operand(v, "v", B * S, Hkv * D)
+    if key_mask is not None and not (key_mask.dtype == torch.uint8 and key_mask.is_contiguous() and tuple(key_mask.shape) == (B, S)):
+        raise ValueError("attention: key_mask must be contiguous uint8 [B,S]")
+    o = torch.empty((B * S, Hq * D), dtype=BF16, device=q.device)
+    lse = torch.empty((B, Hq, S), dtype=F32, device=q.device)
+    scale = D ** -0.5 if scale is None else scale
+    L.call("mi355_attn_generic_dropout_fwd", B, S, Hq, Hkv, D, L.ptr(q), q.stride(0), L.ptr(k), k.stride(0), L.ptr(v), v.stride(0), L.ptr(o), o.stride(0),
+           L.ptr(lse), L.ptr(key_mask), scale, float(p), int(seed), int(offset))
+    return o, lse
+
+
+def attn_generic_dropout_bwd(q, k, v, o, do, lse, B, S, Hq, Hkv, D, dq, dk, dv, p, seed, offset, key_mask=None, scale=None):
+    L.require_gpu(q, k, v, o, do, lse, dq, dk, dv, key_mask)
+    for t, n, w in ((q, "q", Hq), (k, "k", Hkv), (v, "v", Hkv), (o, "o", Hq), (do, "do", Hq), (dq, "dq", Hq), (dk, "dk", Hkv), (dv, "dv", Hkv)):
+        _check_attn_operand(t, n, B * S, w * D)
+    if not (lse.dtype == F32 and lse.is_contiguous() and tuple(lse.shape) == (B, Hq, S)):
+        raise ValueError("attention: lse must be contiguous fp32 [B,Hq,S]")
+    delta = torch.empty_like(lse)
+    scale = D ** -0.5 if scale is None else scale
+    L.call("mi355_attn_generic_dropout_bwd", B, S, Hq, Hkv, D, L.ptr(q), q.stride(0), L.ptr(k), k.stride(0), L.ptr(v), v.stride(0), L.ptr(o), o.stride(0),
+           L.ptr(do), do.stride(0), L.ptr(lse), L.ptr(delta), L.ptr(dq), dq.stride(0), L.ptr(dk), dk.stride(0), L.ptr(dv), dv.stride(0),
+           L.ptr(key_mask), scale, float(p), int(seed), int(offset))

@@ -259,6 +259,93 @@ atexit.register(_close_all)
 
 
 # ----------------------------------------------------------------------------------------------- Qwen3.5 hybrid stack with Qwen3_5Cache
+class Q35Step:
+    """What one cached step of the Qwen3.5 stack shares between its layers: shape, rotary rows, key mask, the cache, and whether the step decodes one
+    token from carried state (GEMV projections, conv / recurrence updates, decode attention) or prefills."""
+
+    __slots__ = ("B", "S", "cos_t", "sin_t", "pos", "km", "cache", "decode")
+
+    def __init__(self, cache, B, S, device, cos, sin, mrope_section, attn_mask=None, position_ids=None, decode=None):
+        from . import kernels_q35 as Q
+
+        self.B, self.S, self.cache = B, S, cache
+        # a layer on its own: one new token against carried state (conv / recurrent state of some linear layer, or cached K / V rows) decodes
+        self.decode = (S == 1 and (cache.has_previous_state or cache.kv_cache.start_pos > 0)) if decode is None else decode
+        start = cache.kv_cache.start_pos
+        if position_ids is None:  # text-only: 1-D rotary rows start .. start+S-1 of the model's table
+            self.cos_t, self.sin_t = cos, sin
+            self.pos = (start + torch.arange(S, dtype=torch.int32, device=device)).repeat(B)
+        else:
+            self.cos_t, self.sin_t = Q.mrope_table(cos, sin, position_ids.to(device), mrope_section)
+            self.pos = torch.arange(B * S, dtype=torch.int32, device=device)
+        self.km = None if attn_mask is None else attn_mask.to(device=device, dtype=torch.uint8).contiguous()
+
+    def lin(self, a, w, residual=None):
+        return gemv(a, w, residual=residual) if self.decode else K.gemm(L.GEMM_NT, a, w, residual=residual)
+
+
+@torch.no_grad()
+def q35_mixer_cached(att, arena, h1, st, i):
+    """The token mixer of layer ``i`` on normalised rows ``h1`` [B*S, d] with the hybrid cache: FusedGatedDeltaNet (conv state + recurrent state,
+    reference qwen3_5_text_model.py:96-191) or MRoPEGatedAttention (K / V rows, :206-267).  Returns the rows in front of ``out_proj``."""
+    from . import kernels_q35 as Q
+    from . import ops_q35
+
+    B, S, cache, decode = st.B, st.S, st.cache, st.decode
+    if att.is_linear:
+        Hqk, Hv, Dk, Dv, QK, VG, C = ops_q35._gdn_dims(att)
+        if st.km is not None:
+            h1 = Q.rowmask(h1, st.km[:, -S:].reshape(-1).contiguous())
+        proj = st.lin(h1, arena.fused(att.w_qkv.weight, att.w_alpha.weight))
+        if decode:
+            y = Q.causal_conv_silu_step(proj[:, :C], cache.get_conv_state(i), att.conv1d.weight)
+        else:
+            ks = att.conv_kernel_size
+            state = torch.zeros((B, ks, C), dtype=BF16, device=h1.device)  # F.pad(fused_qkv, (k - s, 0)): zeros on the left if s < k
+            n = min(ks, S)
+            for b in range(B):
+                K.copy2d(proj[b * S + S - n : (b + 1) * S, :C], state[b, ks - n :])
+            cache.set_conv_state(i, state)
+            y = Q.causal_conv_silu_fwd(proj[:, :C], att.conv1d.weight, B, S)
+        qn, kn = Q.l2norm_fwd(y[:, :QK], Hqk, Dk), Q.l2norm_fwd(y[:, QK : 2 * QK], Hqk, Dk)
+        beta, alpha = Q.gdn_gates_fwd(proj[:, C + VG : C + VG + Hv], proj[:, C + VG + Hv :], att.log_A, att.dt_bias)
+        o, _, fin = Q.gated_delta_rule_fwd(qn, kn, y[:, 2 * QK :], beta, alpha, B, S, Hqk, Hv, Dk, Dv, keep=False, want_state=True,
+                                           state=cache.get_recurrent_state(i))
+        cache.set_recurrent_state(i, fin)
+        mix, _ = Q.gated_rmsnorm_fwd(o, att.post_norm.weight, proj[:, C : C + VG], Hv, Dv, eps=att.post_norm.eps)
+        return mix
+    H, G, D, QG, KV = ops_q35._att_dims(att)
+    proj = st.lin(h1, arena.fused(att.w_queries_gate.weight, att.w_values.weight))
+    q, _ = Q.headnorm_rope_fwd(proj[:, :QG], H, D, 2 * D, Q.zc_weight(att.q_norm.scale), st.cos_t, st.sin_t, st.pos, eps=att.q_norm.eps)
+    k, _ = Q.headnorm_rope_fwd(proj[:, QG : QG + KV], G, D, D, Q.zc_weight(att.k_norm.scale), st.cos_t, st.sin_t, st.pos, eps=att.k_norm.eps)
+    v = proj[:, QG + KV :]
+    had_rows = cache.kv_cache.start_pos > 0
+    kc, vc, end = cache.append_kv_rows(k, v, i, B, S)
+    if decode:  # every cached key is visible: causal for the newest query, and upstream un-masks padded keys (SURVEY 9.6)
+        ctx = attn_decode(q, kc, vc, end, H, G, D)
+    else:
+        if had_rows:
+            raise NotImplementedError("a filled Qwen3_5Cache takes one new token per sequence (use_precomputed_states, qwen3_5_text_model.py:106)")
+        ctx, _ = Q.attn_generic_fwd(q, k, v, B, S, H, G, D, key_mask=st.km)
+    return Q.sigmoid_gate_fwd(ctx, proj[:, D:QG], H, D, 2 * D)
+
+
+@torch.no_grad()
+def q35_block_cached(blk, h, st):
+    """``Qwen3_5TransformerBlock`` on token-major rows ``h`` [B*S, d] with the hybrid cache (reference qwen3_5_text_model.py:296-325)."""
+    from . import kernels_q35 as Q
+    from . import ops_q35
+
+    arena = ops_q35.arena_for_bf16(blk)
+    att, ffn = blk.att, blk.ffn
+    h1, _ = K.rmsnorm_fwd(h, Q.zc_weight(blk.norm1.scale), eps=blk.norm1.eps, want_rstd=False)
+    mix = q35_mixer_cached(att, arena, h1, st, att.layer_idx)
+    h = st.lin(mix, att.out_proj.weight, residual=h)
+    h2, _ = K.rmsnorm_fwd(h, Q.zc_weight(blk.norm2.scale), eps=blk.norm2.eps, want_rstd=False)
+    gu = st.lin(h2, arena.fused(ffn.lin1.weight, ffn.lin_gate.weight))
+    return st.lin(K.swiglu_fwd(gu, ffn.lin1.weight.shape[0]), ffn.lin2.weight, residual=h)
+
+
 @torch.no_grad()
 def qwen35_forward_cached(model, x, cache, attn_mask=None, inputs_embs=None, position_ids=None):
     """Logits (b, s, vocab) of ``Qwen3_5TextModel`` with a ``Qwen3_5Cache`` (reference: qwen3_5_text_model.py:96-191, 206-267, 388-417).
@@ -267,7 +354,6 @@ def qwen35_forward_cached(model, x, cache, attn_mask=None, inputs_embs=None, pos
     the final recurrent state, per full-attention layer the K / V rows; a one-token step then costs one conv update, ONE recurrence step
     from the carried state (the forward delta-rule kernel with S = 1), resp. one decode-attention pass, with GEMV projections."""
     from . import kernels_q35 as Q
-    from . import ops_q35
 
     model._build_arenas()
     if inputs_embs is not None:
@@ -280,55 +366,8 @@ def qwen35_forward_cached(model, x, cache, attn_mask=None, inputs_embs=None, pos
     decode = cache.has_previous_state
     if decode and S != 1:
         raise NotImplementedError("with a filled Qwen3_5Cache one new token per sequence is decoded (use_precomputed_states, qwen3_5_text_model.py:106)")
-    start = cache.kv_cache.start_pos
-    if position_ids is None:  # text-only: 1-D rotary rows start .. start+S-1 of the model's table
-        cos_t, sin_t = model.cos, model.sin
-        pos = (start + torch.arange(S, dtype=torch.int32, device=h.device)).repeat(B)
-    else:
-        cos_t, sin_t = Q.mrope_table(model.cos, model.sin, position_ids.to(h.device), model.mrope_section)
-        pos = torch.arange(B * S, dtype=torch.int32, device=h.device)
-    km = None if attn_mask is None else attn_mask.to(device=h.device, dtype=torch.uint8).contiguous()
-    lin = gemv if decode else (lambda a, w, residual=None: K.gemm(L.GEMM_NT, a, w, residual=residual))
-    for i, blk in enumerate(model.trf_blocks):
-        arena = ops_q35.arena_for_bf16(blk)
-        att, ffn = blk.att, blk.ffn
-        h1, _ = K.rmsnorm_fwd(h, Q.zc_weight(blk.norm1.scale), eps=blk.norm1.eps, want_rstd=False)
-        if blk.is_linear:
-            Hqk, Hv, Dk, Dv, QK, VG, C = ops_q35._gdn_dims(att)
-            if km is not None:
-                h1 = Q.rowmask(h1, km[:, -S:].reshape(-1).contiguous())
-            proj = lin(h1, arena.fused(att.w_qkv.weight, att.w_alpha.weight))
-            if decode:
-                y = Q.causal_conv_silu_step(proj[:, :C], cache.get_conv_state(i), att.conv1d.weight)
-            else:
-                ks = att.conv_kernel_size
-                state = torch.zeros((B, ks, C), dtype=BF16, device=h.device)  # F.pad(fused_qkv, (k - s, 0)): zeros on the left if s < k
-                n = min(ks, S)
-                for b in range(B):
-                    K.copy2d(proj[b * S + S - n : (b + 1) * S, :C], state[b, ks - n :])
-                cache.set_conv_state(i, state)
-                y = Q.causal_conv_silu_fwd(proj[:, :C], att.conv1d.weight, B, S)
-            qn, kn = Q.l2norm_fwd(y[:, :QK], Hqk, Dk), Q.l2norm_fwd(y[:, QK : 2 * QK], Hqk, Dk)
-            beta, alpha = Q.gdn_gates_fwd(proj[:, C + VG : C + VG + Hv], proj[:, C + VG + Hv :], att.log_A, att.dt_bias)
-            o, _, fin = Q.gated_delta_rule_fwd(qn, kn, y[:, 2 * QK :], beta, alpha, B, S, Hqk, Hv, Dk, Dv, keep=False, want_state=True,
-                                               state=cache.get_recurrent_state(i))
-            cache.set_recurrent_state(i, fin)
-            mix, _ = Q.gated_rmsnorm_fwd(o, att.post_norm.weight, proj[:, C : C + VG], Hv, Dv, eps=att.post_norm.eps)
-        else:
-            H, G, D, QG, KV = ops_q35._att_dims(att)
-            proj = lin(h1, arena.fused(att.w_queries_gate.weight, att.w_values.weight))
-            q, _ = Q.headnorm_rope_fwd(proj[:, :QG], H, D, 2 * D, Q.zc_weight(att.q_norm.scale), cos_t, sin_t, pos, eps=att.q_norm.eps)
-            k, _ = Q.headnorm_rope_fwd(proj[:, QG : QG + KV], G, D, D, Q.zc_weight(att.k_norm.scale), cos_t, sin_t, pos, eps=att.k_norm.eps)
-            v = proj[:, QG + KV :]
-            kc, vc, end = cache.append_kv_rows(k, v, i, B, S)
-            if decode:  # every cached key is visible: causal for the newest query, and upstream un-masks padded keys
-                ctx = attn_decode(q, kc, vc, end, H, G, D)
-            else:
-                ctx, _ = Q.attn_generic_fwd(q, k, v, B, S, H, G, D, key_mask=km)
-            mix = Q.sigmoid_gate_fwd(ctx, proj[:, D:QG], H, D, 2 * D)
-        h = lin(mix, att.out_proj.weight, residual=h)
-        h2, _ = K.rmsnorm_fwd(h, Q.zc_weight(blk.norm2.scale), eps=blk.norm2.eps, want_rstd=False)
-        gu = lin(h2, arena.fused(ffn.lin1.weight, ffn.lin_gate.weight))
-        h = lin(K.swiglu_fwd(gu, ffn.lin1.weight.shape[0]), ffn.lin2.weight, residual=h)
+    st = Q35Step(cache, B, S, h.device, model.cos, model.sin, model.mrope_section, attn_mask, position_ids, decode=decode)
+    for blk in model.trf_blocks:
+        h = q35_block_cached(blk, h, st)
     hn, _ = K.rmsnorm_fwd(h, Q.zc_weight(model.final_norm.scale), eps=model.final_norm.eps, want_rstd=False)
-    return lin(hn, model.out_head.weight).view(B, S, -1)
+    return st.lin(hn, model.out_head.weight).view(B, S, -1)

@@ -110,12 +110,13 @@ def gated_attention_forward(att, arena, h1, rt):
     drop = None
     p_drop = float(getattr(att, "p_dropout", 0.0))
     if p_drop > 0.0:  # SDPA's dropout_p (qwen3_next_attention.py:245-253): Philox masks inside the kernels, regenerated in the backward
-        if rt.key_mask is not None:
-            raise NotImplementedError("GatedAttention: attention dropout together with a padding mask is not built on the HIP path (causal mask only)")
         from . import rng
 
         drop = (p_drop,) + rng.draw()
-        ctx, lse = K.attn_dropout_fwd(q, k, proj[:, QG + KV :], rt.B, rt.S, H, G, D, *drop, causal=True)
+        if rt.key_mask is not None:  # padded batch: the quirk-mask kernels with the dropout arguments set
+            ctx, lse = K.attn_generic_dropout_fwd(q, k, proj[:, QG + KV :], rt.B, rt.S, H, G, D, *drop, key_mask=rt.key_mask)
+        else:
+            ctx, lse = K.attn_dropout_fwd(q, k, proj[:, QG + KV :], rt.B, rt.S, H, G, D, *drop, causal=True)
     else:
         ctx, lse = Q.attn_generic_fwd(q, k, proj[:, QG + KV :], rt.B, rt.S, H, G, D, key_mask=rt.key_mask)
     gated = Q.sigmoid_gate_fwd(ctx, proj[:, D:QG], H, D, 2 * D)
@@ -128,7 +129,9 @@ def gated_attention_backward(att, arena, h1, saved, dgated, rt, defer=None):
     dproj = torch.empty_like(proj)
     dctx = Q.sigmoid_gate_bwd(ctx, proj[:, D:QG], H, D, 2 * D, dgated, dproj[:, D:QG], 2 * D)
     dq, dk = torch.empty_like(q), torch.empty_like(k)
-    if drop is not None:
+    if drop is not None and rt.key_mask is not None:
+        K.attn_generic_dropout_bwd(q, k, proj[:, QG + KV :], ctx, dctx, lse, rt.B, rt.S, H, G, D, dq, dk, dproj[:, QG + KV :], *drop, key_mask=rt.key_mask)
+    elif drop is not None:
         K.attn_dropout_bwd(q, k, proj[:, QG + KV :], ctx, dctx, lse, rt.B, rt.S, H, G, D, dq, dk, dproj[:, QG + KV :], *drop, causal=True)
     else:
         Q.attn_generic_bwd(q, k, proj[:, QG + KV :], ctx, dctx, lse, rt.B, rt.S, H, G, D, dq, dk, dproj[:, QG + KV :], key_mask=rt.key_mask)

@@ -2,8 +2,9 @@
 SURVEY.md section 8 row a24): ``FusedGatedDeltaNet``, ``MRoPEGatedAttention``, ``Qwen3_5TransformerBlock``, ``Qwen3_5TextModel``
 with the reference's constructor keys, forward signatures and ``state_dict`` keys.
 
-One autograd node per block (llm_quest_amd/ops_q35.py).  ``Qwen3_5TextModel.forward(..., cache=Qwen3_5Cache)`` decodes through
-``ops_decode.qwen35_forward_cached``; the ``cache`` arguments of the individual layers still raise.  Extensions as on Qwen3Model: ``forward_hidden`` / ``lm_loss`` (LM head + cross entropy on
+One autograd node per block (llm_quest_amd/ops_q35.py).  ``cache=Qwen3_5Cache`` decodes through ``ops_decode`` at every level
+the reference takes it: the model (``qwen35_forward_cached``), a block, or a token mixer called on its own (``q35_block_cached`` / ``q35_mixer_cached``:
+the same kernels, so the layers composed by hand equal the model bit for bit).  Extensions as on Qwen3Model: ``forward_hidden`` / ``lm_loss`` (LM head + cross entropy on
 just the rows that feed the loss).
 """
 
@@ -20,9 +21,14 @@ from llm_quest_amd.qwen.qwen3.qwen3_transformer_block import FFN
 from llm_quest_amd.qwen.qwen3_next.qwen3_next_attention import GatedAttention, ZeroCenteredRMSNorm
 
 
-def _no_cache(cache):
-    if cache is not None:
-        raise NotImplementedError("Qwen3_5Cache decoding is outside the training hot path (SURVEY.md section 8 f4)")
+def _cached_step(x, cache, cos, sin, mrope_section, attn_mask, position_ids):
+    """(rows [b*s, d], ops_decode.Q35Step) of a layer called with a ``Qwen3_5Cache`` (inference: no autograd graph is built)."""
+    from llm_quest_amd import ops_decode
+
+    L.require_gpu(x)
+    b, s, d = x.shape
+    st = ops_decode.Q35Step(cache, b, s, x.device, cos, sin, mrope_section, attn_mask, position_ids)
+    return x.detach().reshape(b * s, d).contiguous(), st
 
 
 class FusedGatedDeltaNet(nn.Module):
@@ -60,8 +66,13 @@ class FusedGatedDeltaNet(nn.Module):
     def forward(self, x, attn_mask=None, cache=None):
         """x (b, s, d_in); attn_mask (b, s), 1 = real token.  Unlike upstream, ``x`` is not modified in place (the mask is applied
         to a copy; inside the block the masked tensor is the block's own temporary either way)."""
-        _no_cache(cache)
         b, s, _ = x.shape
+        if cache is not None:  # conv state + recurrent state of layer ``layer_idx`` (reference :104-106, 131-160)
+            from llm_quest_amd import ops_decode
+
+            rows, st = _cached_step(x, cache, None, None, None, attn_mask, None)
+            mix = ops_decode.q35_mixer_cached(self, ops_q35.arena_for_bf16(self), rows, st, self.layer_idx)
+            return st.lin(mix, self.out_proj.weight).view(b, s, -1)
         rt = ops_q35.Runtime(b, s, None if attn_mask is None else attn_mask.to(device=x.device, dtype=torch.uint8).contiguous(), None, None, None)
         return ops_q35.run_mixer(self, x, rt)
 
@@ -75,8 +86,13 @@ class MRoPEGatedAttention(GatedAttention):
         self.mrope_section = cfg["mrope_section"]
 
     def forward(self, x, mask, cos, sin, position_ids=None, attn_mask=None, cache=None):
-        _no_cache(cache)
         b, s, _ = x.shape
+        if cache is not None:  # K / V rows of layer ``layer_idx`` (reference :236-238)
+            from llm_quest_amd import ops_decode
+
+            rows, st = _cached_step(x, cache, cos, sin, self.mrope_section, attn_mask, position_ids)
+            mix = ops_decode.q35_mixer_cached(self, ops_q35.arena_for_bf16(self), rows, st, self.layer_idx)
+            return st.lin(mix, self.out_proj.weight).view(b, s, -1)
         rt = ops_q35.make_runtime(b, s, x.device, cos, sin, attn_mask=attn_mask, position_ids=position_ids, mrope_section=self.mrope_section)
         return ops_q35.run_mixer(self, x, rt)
 
@@ -96,8 +112,12 @@ class Qwen3_5TransformerBlock(nn.Module):
         self.mrope_section = cfg["mrope_section"]
 
     def forward(self, x, mask, cos, sin, position_ids=None, attn_mask=None, cache=None, _runtime=None):
-        _no_cache(cache)
         b, s, _ = x.shape
+        if cache is not None:  # reference :296-325 with the hybrid cache
+            from llm_quest_amd import ops_decode
+
+            rows, st = _cached_step(x, cache, cos, sin, self.mrope_section, attn_mask, position_ids)
+            return ops_decode.q35_block_cached(self, rows, st).view(b, s, -1)
         rt = _runtime
         if rt is None:
             rt = ops_q35.make_runtime(b, s, x.device, cos, sin, attn_mask=attn_mask, position_ids=position_ids, mrope_section=self.mrope_section)

@@ -601,8 +601,8 @@ def test_rccl_gradsync_qwen35_single_rank():
 def test_gated_attention_with_attention_dropout_given_the_mask():
     """``GatedAttention`` with ``p_dropout`` > 0 under ``training`` (reference qwen3_next_attention.py:181,245-253: SDPA's ``dropout_p``): the weights are
     dropped inside the attention kernels by Philox masks that the backward regenerates.  Output and every gradient against the oracle's fp32 twin
-    evaluated with the SAME mask (oracle/dropout.py); a repeat with the same (seed, offset) is bit-identical, another offset is not; with a padding mask
-    the combination raises instead of silently ignoring the dropout."""
+    evaluated with the SAME mask (oracle/dropout.py); a repeat with the same (seed, offset) is bit-identical, another offset is not; the same on a padded
+    batch (padding mask + dropout in one SDPA call: mi355_attn_generic_dropout_fwd / _bwd)."""
     from llm_quest_amd import rng
     from llm_quest_amd.common.buffers import GlobalBuffers
     from llm_quest_amd.qwen.qwen3_next.qwen3_next_attention import GatedAttention
@@ -652,10 +652,34 @@ def test_gated_attention_with_attention_dropout_given_the_mask():
     assert rel_l2(dx, xf.grad) < 3e-2, rel_l2(dx, xf.grad)
     for n_, gr in grads.items():
         assert rel_l2(gr, tw["a." + n_].grad) < 4e-2, (n_, rel_l2(gr, tw["a." + n_].grad))
+    # ... and on a padded batch (SDPA gets the padding mask AND dropout_p, qwen3_next_attention.py:240-253): the same masks over the quirk-mask kernels
     am = torch.ones(b, s, dtype=torch.bool)
     am[0, 15:] = False
-    with pytest.raises(NotImplementedError):
-        att(x.cuda(), allow.cuda(), cos.cuda(), sin.cuda(), attn_mask=am.cuda())
+
+    def run_padded(offset):
+        rng.manual(seed, offset)
+        try:
+            xd = x.cuda().requires_grad_(True)
+            for p_ in att.parameters():
+                p_.grad = None
+            y_ = att(xd, allow.cuda(), cos.cuda(), sin.cuda(), attn_mask=am.cuda())
+            y_.backward(g.cuda())
+        finally:
+            rng.follow_torch()
+        return y_.detach(), xd.grad.clone(), {n_: p_.grad.detach().float().clone() for n_, p_ in att.named_parameters()}
+
+    yp, dxp, gp = run_padded(0)
+    yp2, dxp2, _ = run_padded(0)
+    assert torch.equal(yp, yp2) and torch.equal(dxp, dxp2) and not torch.equal(yp, y)
+    tw = {k: (v.float().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    xf = x.float().requires_grad_(True)
+    refp = OT.gated_attention(tw, "a.", cfg, xf, allow, cos, sin, None, am, att_mul=mul)
+    refp.backward(g.float())
+    assert rel_l2(yp, refp) < 2e-2, rel_l2(yp, refp)
+    assert rel_l2(refp, OT.gated_attention(tw, "a.", cfg, xf, allow, cos, sin, None, am)) > 5e-2
+    assert rel_l2(dxp, xf.grad) < 3e-2, rel_l2(dxp, xf.grad)
+    for n_, gr in gp.items():
+        assert rel_l2(gr, tw["a." + n_].grad) < 4e-2, (n_, rel_l2(gr, tw["a." + n_].grad))
 
 
 @pytest.mark.parametrize("dk,dv,s1,s2", [(16, 16, 12, 9), (128, 128, 21, 20)])
