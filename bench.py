@@ -178,12 +178,15 @@ def dominant_kernel_rate(batch, device):
     x = torch.randn(M, 1024, device=device).to(torch.bfloat16)
     w = torch.randn(6144, 1024, device=device).to(torch.bfloat16)
     dy = torch.randn(M, 6144, device=device).to(torch.bfloat16)
+    shapes = [(4096, 1024), (1024, 2048), (6144, 1024), (1024, 3072)]  # [out, in] of the block's four weight matrices
+    group = [(torch.randn(M, o, device=device).to(torch.bfloat16), torch.randn(M, i, device=device).to(torch.bfloat16), torch.zeros(o, i, device=device, dtype=torch.bfloat16), None)
+             for o, i in shapes]
     out = {}
     for name, fn, flops in (
         ("NT gate-up fwd", lambda: K.gemm(L.GEMM_NT, x, w), 2.0 * M * 6144 * 1024),
         ("NT gate-up dgrad on W^T (the step's form, transpose included)", lambda: K.dgrad(dy, w), 2.0 * M * 6144 * 1024),
         ("NN gate-up dgrad (form not used by the step)", lambda: K.gemm(L.GEMM_NN, dy, w), 2.0 * M * 6144 * 1024),
-        ("TN gate-up wgrad", lambda: K.gemm(L.GEMM_TN, dy, x), 2.0 * M * 6144 * 1024),
+        ("TN block weight gradients, grouped (the step's launch: QKV, out_proj, gate-up, down = 240 tiles)", lambda: K.gemm_grouped(L.GEMM_TN, group), 2.0 * M * sum(o * i for o, i in shapes)),
     ):
         for _ in range(3):
             fn()
@@ -366,6 +369,26 @@ def _other_cpu_baseline(state, n_samples, unit, budget_s=300):
             "sample": f"{n_samples} full-size sample(s) forward + backward through the CPU oracle in {dt:.1f} s on {cores} threads, torch {torch.__version__} CPU, oracle loss {loss:.4f}"}
 
 
+def _config_traffic(config, batch):
+    """``traffic`` of `bench.py --config N`: memory-side bytes per step from the committed counter passes (profiles/<round>_pmc_tcc_step_config<N>.json), shown only when
+    they were taken on the library sources this run uses (fingerprint over every kernel source) and at this batch."""
+    from llm_quest_amd import fingerprint as F
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"{F.EVIDENCE_ROUND}_pmc_tcc_step_config{config}.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return {"traffic": None, "traffic_note": f"no counter passes are committed for this configuration ({os.path.basename(path)})"}
+    if d.get("all_sources_sha") != F.all_sources_sha():
+        return {"traffic": None, "traffic_note": "traffic withheld: the committed counter passes were taken on other kernel sources (re-collect: tools/collect_evidence.sh)"}
+    if d.get("per_gpu_batch") != batch:
+        return {"traffic": None, "traffic_note": f"the committed counter passes were taken at per-GPU batch {d.get('per_gpu_batch')}"}
+    return {"traffic": d["per_step"]["total_bytes"],
+            "traffic_note": "memory-side bytes PER STEP: 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE over every kernel of one step, separate rocprofv3 --pmc passes over "
+                            f"`bench.py --config {config}` ({os.path.basename(path)}, per-kernel table inside; fingerprint of all kernel sources checked)"}
+
+
 def run_other_config(args):
     from llm_quest_amd import _lib, ddp
 
@@ -415,8 +438,7 @@ def run_other_config(args):
             "rccl_ranks": world if world > 1 else 0, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": spec["workload"], "per_gpu_batch": batch, "global_batch": batch * world, "parallelism": f"dp{world}", "units_per_sample": spec["units_per_sample"]},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                         "traffic_note": "no counter passes are kept for this configuration (the headline's are: --config 4)",
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), **_config_traffic(args.config, batch),
                          "basis": f"algorithmic {spec['flop'] / 1e9:.1f} GFLOP/sample (SURVEY 8d) x per-GPU batch / step time; device-side (HIP events) {dev_ms / args.steps:.3f} ms/step"},
             "loss": round(float(loss.detach()), 5), "peak_memory_gib": round(torch.cuda.max_memory_allocated(device) / 2**30, 1),
         }
@@ -607,7 +629,7 @@ def main():
         if train_step is not None:
             line["with_optimizer_step"] = train_step
         if world == 1:
-            line["roofline"]["dominant_kernel"] = {"name": "gemm_nt_persist_kernel / gemm_bf16_kernel (NT projections on the persistent form of tile 2; weight gradients on tile 5)", "hip_event_timing": dominant_kernel_rate(args.batch, device)}
+            line["roofline"]["dominant_kernel"] = {"name": "gemm_nt_persist_kernel / gemm_grouped_kernel (NT projections on the persistent form of tile 2; the block's weight gradients as one grouped launch on tile 5)", "hip_event_timing": dominant_kernel_rate(args.batch, device)}
             pmc, why_gemm = pmc_traffic()
             step_pmc, why_step = pmc_step_traffic()
             pmc_batch = step_pmc.get("per_gpu_batch") if step_pmc else None

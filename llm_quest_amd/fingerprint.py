@@ -14,7 +14,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-EVIDENCE_ROUND = "r04"  # profiles/<EVIDENCE_ROUND>_* are the counter files bench.py reads
+EVIDENCE_ROUND = "r05"  # profiles/<EVIDENCE_ROUND>_* are the counter files bench.py reads
 FILES = ("attention.hip", "attn_common.h", "elementwise.hip", "gemm.hip", "norm_rope.hip", "common.h")
 _FLAG_LINES = re.compile(r"^(CXXFLAGS|ARCH|FLAGS_(?:attention|elementwise|gemm|norm_rope))\s*\??=")
 
@@ -39,6 +39,20 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
+def all_sources_sha():
+    """Every kernel source of the library (all csrc/*.hip and *.h) + every flag line: the stamp the counter files of the OTHER configurations carry
+    (``bench.py --config 2 / 3 / 5`` run kernels outside FILES: qwen35.hip, attention_generic.hip, rope_dropout.hip, ...)."""
+    h = hashlib.sha256()
+    d = os.path.join(_HERE, "csrc")
+    for n in sorted(f for f in os.listdir(d) if f.endswith((".hip", ".h")) and not f.startswith("_")):
+        h.update(n.encode())
+        with open(os.path.join(d, n), "rb") as fh:
+            h.update(fh.read())
+    with open(os.path.join(d, "Makefile")) as fh:
+        h.update("\n".join(" ".join(line.split()) for line in fh if re.match(r"^(CXXFLAGS|ARCH|FLAGS_\w+)\s*\??=", line)).encode())
+    return h.hexdigest()[:16]
+
+
 def library_sha():
     with open(os.path.join(_HERE, "libmi355vlm.so"), "rb") as fh:
         return hashlib.sha256(fh.read()).hexdigest()[:16]
@@ -53,5 +67,5 @@ def collection_stamp(evidence_dir):
 if __name__ == "__main__":  # python -m llm_quest_amd.fingerprint <git sha> <batch>  (collection time, on the GPU box)
     import sys
 
-    print(json.dumps({"kernel_sources_sha": kernel_sources_sha(), "library_sha": library_sha(), "git_sha": sys.argv[1] if len(sys.argv) > 1 else "unknown",
+    print(json.dumps({"kernel_sources_sha": kernel_sources_sha(), "all_sources_sha": all_sources_sha(), "library_sha": library_sha(), "git_sha": sys.argv[1] if len(sys.argv) > 1 else "unknown",
                       "per_gpu_batch": int(sys.argv[2]) if len(sys.argv) > 2 else None}))

@@ -38,8 +38,10 @@ for name in set(fetch) | set(write):
 rows.sort(key=lambda r: -(r["fetch_bytes"] + r["write_bytes"]))
 tot_f, tot_w = sum(r["fetch_bytes"] for r in rows), sum(r["write_bytes"] for r in rows)
 stamp = collection_stamp(sys.argv[5])  # written on the GPU box when the counters were collected
+config = sys.argv[6] if len(sys.argv) > 6 else None  # "config2" / "config3" / "config5": `bench.py --config N` at its default batch (no optimizer re-run: warm-up + timed steps only)
 out = {
-    "kernel_sources_sha": stamp["kernel_sources_sha"], "library_sha": stamp["library_sha"], "git_sha": stamp["git_sha"], "per_gpu_batch": stamp["per_gpu_batch"],
+    "kernel_sources_sha": stamp["kernel_sources_sha"], "all_sources_sha": stamp.get("all_sources_sha"), "library_sha": stamp["library_sha"], "git_sha": stamp["git_sha"],
+    "per_gpu_batch": {"config2": 332, "config3": 64, "config5": 32}[config] if config else stamp["per_gpu_batch"], **({"config": config} if config else {}),
     "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, TCC slots) with --kernel-trace over `python3 bench.py --steps 1 --warmup 1 "
             "--cpu-baseline off` (per-GPU batch as stamped: 4 steps in each trace -- warm-up + timed, without and with the optimizer); figures are PER STEP = per-launch "
             "average x launches per step, so the bench's 13 stand-alone launches of each gate-up GEMM form drop out, and the optimizer's own kernels are left out (the headline step has none).  KiB units from rocprofv3; gfx950 correction: FETCH_SIZE doubled (128-byte requests "
