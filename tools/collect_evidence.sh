@@ -4,9 +4,11 @@
 set -e
 ROUND=${ROUND:-r05}
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${ROUND}ev; rm -rf $O; mkdir -p $O  # (in the container: delete gpurun_out/${ROUND}ev before the call too -- gpurun MERGES what comes back into what is there)
+PART=${PART:-all}  # all | headline | configs  (a gpurun call is limited to 20 minutes: run the two halves as two calls; "configs" adds to the same directory)
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${ROUND}ev; [ "$PART" = configs ] || rm -rf $O; mkdir -p $O  # (in the container: delete gpurun_out/${ROUND}ev before the call too -- gpurun MERGES what comes back into what is there)
 B=${BATCH:-160}; M=$((B * 709))
 (cd $R && python3 -m llm_quest_amd.fingerprint ${GIT_SHA:-unknown} $B > $O/stamp.json)
+if [ "$PART" != configs ]; then
 SQ1="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
 SQ2="SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --batch $B --steps 4 --warmup 2 --cpu-baseline off > $O/bench_trace.log 2>&1
@@ -31,6 +33,8 @@ echo tn_group done
 rocprofv3 --pmc $SQ1 --kernel-trace --output-format csv -d $O/attn_sq1 -- python3 $R/tools/attn_one.py $B 3 > $O/attn_sq1.log 2>&1
 rocprofv3 --pmc $SQ2 --kernel-trace --output-format csv -d $O/attn_sq2 -- python3 $R/tools/attn_one.py $B 3 > $O/attn_sq2.log 2>&1
 echo attn done
+fi
+if [ "$PART" != headline ]; then
 # the other BASELINE configurations: whole-step memory-side traffic + kernel table of `bench.py --config N` (same passes as the headline's)
 for cfg in 2 3 5; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg${cfg}_trace -- python3 $R/bench.py --config $cfg --steps 3 --warmup 2 --cpu-baseline off > $O/cfg${cfg}_trace.log 2>&1
@@ -38,3 +42,4 @@ for cfg in 2 3 5; do
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/cfg${cfg}_write -- python3 $R/bench.py --config $cfg --steps 1 --warmup 1 --cpu-baseline off > $O/cfg${cfg}_write.log 2>&1
   echo config $cfg done
 done
+fi
