@@ -1152,400 +1152,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int B, int S, int 
 #endif
 }
 
-// ---- dK/dV pass, software-pipelined ACROSS query tiles (head_dim 128, the workspace form: LEAN row constants, dS spilled).
-// attn_bwd_dkv_kernel runs a tile as A(0) A(1) C(0) C(1) with the softmax-gradient arithmetic B(0) riding on A(1) and B(1) on C(0): its lone wave
-// per SIMD pays ~29 extra cycles per MFMA in those two phases (three dependent vector instructions per gap), nothing rides on A(0) and C(1), and
-// every tile pays the fill and drain of its fragment pipeline (in-kernel stamps, batch 160: 5 740 cycles per tile for 2 048 of MFMA).  Here the tile
-// stream is ONE pipeline: an iteration is
-//       A(1) of tile t | C(0) of t | A(0) of tile t+1 | C(1) of t              (64 MFMAs, "virtual steps" v = 0 .. 63)
-// so B(1) of t spreads over C(0) [exp2, multiply] and A(0) of t+1 [packs], B(0) of t+1 over C(1) of t [exp2, multiply] and A(1) of t+1 [packs]:
-// at most two vector instructions in any MFMA gap, and the fragment prefetch (PD steps ahead, one ring) runs across iteration boundaries.  Tile t+1
-// must have landed when its first fragments are requested (v = 26): ONE counted wait + barrier per iteration at v = 24, behind which the DMA of tile
-// t+3 is requested into the stage tile t-1 left at the end of the previous iteration -- four LDS stages instead of three.  Masks are VALUES, not code:
-// a masked (query, key) pair starts its S chain from -inf instead of -lse log2(e) (exp2(-inf) = 0, so P and dS vanish), hence boundary and interior
-// tiles run the same body, and a wave whose keys all follow a tile's queries simply multiplies zeros (it waited at the barrier for the others before).
-// Same MFMA order per accumulator, same arithmetic per element as attn_bwd_dkv_kernel<128, true>: bit-identical dK, dV and dS scratch.
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(int B, int S, int Hq, int Hkv, const bf16_t* __restrict__ q, int64_t ldq,
-                                                               const bf16_t* __restrict__ k, int64_t ldk, const bf16_t* __restrict__ v, int64_t ldv,
-                                                               const bf16_t* __restrict__ d_o, int64_t lddo, const float* __restrict__ nl2,
-                                                               const float* __restrict__ ndl, bf16_t* __restrict__ dk, int64_t lddk,
-                                                               bf16_t* __restrict__ dv, int64_t lddv, const uint8_t* __restrict__ key_mask, int causal,
-                                                               float scale, float scale_log2, int bpw, bf16_t* __restrict__ ds_out) {
-    constexpr int D = 128;
-    using C = Cfg<D>;
-    constexpr int KS = C::KS, DT = C::DT;
-    constexpr int OWNED = 32 * DT + 8 * KS, DK0 = 16 * DT, KF0 = 32 * DT, VF0 = KF0 + 4 * KS;  // dV^T | dK^T | K rows | V rows
-    constexpr int NST = 4, STAGE = 2 * C::TILE, OIMG = C::TILE, PIECES = 2 * C::PPW;
-    constexpr int RING = 8, PD = 6;
-    static_assert(KS == 8 && DT == 4 && OWNED == 192, "written for head_dim 128");
-    causal &= 0xff;
-    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE + NST * 512];
-    char* rowc = smem + NST * STAGE;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    [[maybe_unused]] const bool prof_on = threadIdx.x == 0;
-    [[maybe_unused]] unsigned long long prof_acc[16] = {};
-    [[maybe_unused]] const unsigned long long t_wg = PROF_T();
-    const int nkb = (S + 127) / 128, nchunk = (nkb + bpw - 1) / bpw;
-    const int chunk = blockIdx.x % nchunk, bh = blockIdx.x / nchunk;
-    const int hkv = bh % Hkv, b = bh / Hkv;
-    const int rep = Hq / Hkv;
-    const int kb_lo = chunk * bpw, kb_hi = min(nkb, kb_lo + bpw);
-    const int nqt_all = (S + 63) / 64;
-    auto qt0_of = [&](int kb) { return causal ? kb * 2 : 0; };
-
-    // ---- the request side: Q / dO tiles over (key block, head, query tile), NST stages; vm_ops counts this wave's vector-memory operations in issue order
-    int ikb = kb_lo, ih = 0, iq = 0, istage = 0;
-    int vm_ops = 0, mark[NST] = {0, 0, 0, 0};  // mark[s]: vm_ops right behind the requests of the tile in stage s
-    auto issue_next = [&]() -> bool {
-        if (ikb < kb_hi && iq >= nqt_all - qt0_of(ikb)) { iq = 0; ++ih; }
-        if (ikb < kb_hi && ih >= rep) { ih = 0; ++ikb; }
-        if (ikb >= kb_hi) return false;
-        const int hq = hkv * rep + ih;
-        const int qt = qt0_of(ikb) + iq;
-        char* st_ = smem + istage * STAGE;
-        const bf16_t* qb_ = q + ((int64_t)b * S + (int64_t)qt * 64) * ldq + (int64_t)hq * D;
-        const bf16_t* ob_ = d_o + ((int64_t)b * S + (int64_t)qt * 64) * lddo + (int64_t)hq * D;
-        dma_tile<D, IMG_UNI>(qb_, ldq, S - qt * 64, st_, wave, lane);
-        dma_tile<D, IMG_UNI>(ob_, lddo, S - qt * 64, st_ + OIMG, wave, lane);
-        {
-            const float* src = ((wave & 1) == 0 ? nl2 : ndl) + ((int64_t)b * Hq + hq) * S + (int64_t)qt * 64;
-            auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 0x7fffffff, 0x00020000);
-            const unsigned voff = qt * 64 + lane < S ? (unsigned)(lane * 4) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(rowc + istage * 512 + (wave & 1) * 256), 4, voff, 0, 0, 0);
-        }
-        vm_ops += PIECES + 1;
-        mark[istage] = vm_ops;
-        ++iq;
-        istage = istage == NST - 1 ? 0 : istage + 1;
-        return true;
-    };
-    // all but the operations issued behind the requests of the tile in `stage` have completed (any N <= the true count is safe: it only waits longer)
-    auto wait_tile = [&](int stage) {
-        const int younger = vm_ops - mark[stage];
-        if (younger >= 30) wait_vmcnt<30>();
-        else if (younger >= 26) wait_vmcnt<26>();
-        else if (younger >= 22) wait_vmcnt<22>();
-        else if (younger >= 18) wait_vmcnt<18>();
-        else if (younger >= 14) wait_vmcnt<14>();
-        else if (younger >= 9) wait_vmcnt<9>();
-        else if (younger >= 4) wait_vmcnt<4>();
-        else wait_vmcnt<0>();
-    };
-    issue_next();
-    issue_next();
-    issue_next();
-
-    const LaneOff<D> lo = lane_offsets<D>(lane);
-    const unsigned lds0 = (unsigned)(unsigned long long)LDS_PTR(smem);
-    bf16x8 tk[KS], tv[KS];
-    auto request_kv = [&](int kb_) {
-        const int kg_ = kb_ * 128 + wave * 32 + (lane & 31);
-        load_rows_frag<D>(k + (int64_t)b * S * ldk + (int64_t)hkv * D, ldk, kg_, kg_ < S, lane, tk);
-        load_rows_frag<D>(v + (int64_t)b * S * ldv + (int64_t)hkv * D, ldv, kg_, kg_ < S, lane, tv);
-        // (predicated loads -- a wave beyond S issues none -- are NOT counted in vm_ops, nor are the block's dK / dV stores: counting too few only makes wait_tile stricter)
-    };
-    if (kb_lo < kb_hi) request_kv(kb_lo);
-
-    // ---- per-tile state.  "cur" is the tile whose A(1), C(0), C(1) the iteration runs, "nxt" the one whose A(0) it runs
-    struct Tile {
-        int qt, hq, stage;
-        bool vis, bnd;
-        unsigned aq[KS];          // row fragments: lds0 + ((lane row + stage) ^ (ks << 5)); the dO image is OIMG further (immediate)
-        unsigned at[DT], at2[DT]; // transposing reads: lds0 + lane column[dt] + stage, and the second half's address
-    };
-    int cstage = 0;
-    f32x16 sacc0, pacc0, sacc1, pacc1;          // S / dP of sub-tiles 0 and 1; B turns them into P and dS / scale in place
-    unsigned pw0[8] = {}, dsw0[8] = {}, pw1[8] = {}, dsw1[8] = {};  // packed P / dS: words 4 sd .. 4 sd + 3 are the B operand of k-step sd
-    u32x4 fr[RING] = {};
-    TrHalves ftr[RING] = {};
-    u32x4 rcl[4], rcd[4];                        // row constants of a sub-tile, requested by asm reads
-
-    for (int kb = kb_lo; kb < kb_hi; ++kb) {
-        [[maybe_unused]] const unsigned long long t_pro = PROF_T();
-        const int k0 = kb * 128;
-        const int kg = k0 + wave * 32 + (lane & 31);
-        const bool kvalid = kg < S;
-        const bool kreal = kvalid && (key_mask == nullptr || key_mask[(int64_t)b * S + kg] != 0);
-        const bool any_unreal = __any(!kreal);
-        const int kgc = causal ? kg : -0x7fffffff;
-        owned_zero<OWNED, 0, 32 * DT>();
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {  // k * log2(e) / sqrt(d), rounded to bf16 again: the S chain delivers the exponent of P
-            u32x4 w = __builtin_bit_cast(u32x4, tk[ks]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) w[e] = pack_bf2(__uint_as_float(w[e] << 16) * scale_log2, __uint_as_float(w[e] & 0xffff0000u) * scale_log2);
-            tk[ks] = __builtin_bit_cast(bf16x8, w);
-        }
-        static_for<KS>([&](auto ks) { owned_write4<OWNED, KF0 + 4 * ks.value>(tk[ks.value]); });
-        static_for<KS>([&](auto ks) { owned_write4<OWNED, VF0 + 4 * ks.value>(tv[ks.value]); });
-        const int qt0 = qt0_of(kb);
-        const int per_head = nqt_all - qt0;
-        const int nit = per_head * rep;
-        int ch = 0, cq = 0;
-        auto make_tile = [&](int ch_, int cq_, int stage) {
-            Tile t;
-            t.qt = qt0 + cq_;
-            t.hq = hkv * rep + ch_;
-            t.stage = stage;
-            t.vis = !(causal && t.qt * 64 + 63 < k0 + wave * 32);
-            t.bnd = (causal && t.qt * 64 < k0 + wave * 32 + 31) || (t.qt * 64 + 64 > S) || any_unreal;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) t.aq[ks] = lds0 + (unsigned)((lo.rowu + stage * STAGE) ^ (ks << 5));
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                t.at[dt] = lds0 + (unsigned)(lo.colu[dt] + stage * STAGE);
-                t.at2[dt] = lds0 + (unsigned)((lo.colu[dt] ^ 0x20) + stage * STAGE);
-            }
-            return t;
-        };
-        // ---- pieces of the pipeline
-        // row constants of sub-tile ST of tile t: requested (8 LDS reads) ...
-        auto rc_issue = [&](const Tile& t, auto stc) {
-            constexpr int ST = decltype(stc)::value;
-            const unsigned a = lds0 + (unsigned)(NST * STAGE + t.stage * 512 + 16 * (lane >> 5));
-            static_for<4>([&](auto g4) { rowfrag_issue<(ST * 32 + 8 * g4.value) * 4>(rcl[g4.value], a); });
-            static_for<4>([&](auto g4) { rowfrag_issue<(64 + ST * 32 + 8 * g4.value) * 4>(rcd[g4.value], a); });
-        };
-        // ... and turned into the chains' initial accumulators; a masked (query, key) pair starts its S chain from -inf
-        auto rc_finish = [&](const Tile& t, auto stc, auto nc, f32x16& linit, f32x16& dinit) {
-            constexpr int ST = decltype(stc)::value, N = decltype(nc)::value;
-            asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(rcl[0]), "+v"(rcl[1]), "+v"(rcl[2]), "+v"(rcl[3]), "+v"(rcd[0]), "+v"(rcd[1]), "+v"(rcd[2]), "+v"(rcd[3]) : "n"(N) : "memory");
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    linit[4 * g4 + e] = __uint_as_float(rcl[g4][e]);
-                    dinit[4 * g4 + e] = __uint_as_float(rcd[g4][e]);
-                }
-            if (t.bnd) {  // (wave-uniform)
-                const int r0 = t.qt * 64 + ST * 32 + 4 * (lane >> 5);
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int qq = r0 + (e & 3) + 8 * (e >> 2);
-                    const bool masked = qq < kgc || !kreal || qq >= S;
-                    linit[e] = masked ? -INFINITY : linit[e];
-                }
-            }
-        };
-        // the dS / scale words of sub-tile ST of tile t -> scratch (layout of attn_bwd_dkv_kernel; a wave that sees nothing of the tile writes nothing, as there)
-        auto store_ds = [&](const Tile& t, auto stc, const unsigned (&dsw)[8]) {
-            constexpr int ST = decltype(stc)::value;
-            if (!t.vis) return;
-            const int nqb_ = (S + 127) / 128;
-            char* blk = reinterpret_cast<char*>(ds_out) + ((((int64_t)b * Hq + t.hq) * (2 * nqb_) + t.qt) * 2 * (4 * nqb_) + (kb * 4 + wave)) * 2048 + lane * 16;
-            static_for<2>([&](auto c2) {
-                const u32x4 w4 = {dsw[4 * c2.value], dsw[4 * c2.value + 1], dsw[4 * c2.value + 2], dsw[4 * c2.value + 3]};
-                *reinterpret_cast<u32x4*>(blk + (int64_t)ST * (4 * nqb_) * 2048 + c2.value * 1024) = w4;
-            });
-            vm_ops += 2;
-        };
-        // virtual step v of an iteration: 0-15 A(1) of cur, 16-31 C(0) of cur, 32-47 A(0) of nxt, 48-63 C(1) of cur.  LDS operations of its fragment: 1 (row read) or 2
-        // (transposing halves)
-        auto frag_load = [&](const Tile& cur, const Tile& nxt, auto vc) {
-            constexpr int v = decltype(vc)::value;
-            if constexpr (v < 16 || (v >= 32 && v < 48)) {
-                constexpr int st = v < 16 ? 1 : 0, ks = (v % 16) / 2, which = v % 2;
-                constexpr int imm = st * 32 * C::ROWB + (which ? OIMG : 0);
-                rowfrag_issue<imm>(fr[v % RING], v < 16 ? cur.aq[ks] : nxt.aq[ks]);
-            } else {
-                constexpr int st = v < 32 ? 0 : 1, h = v < 32 ? v - 16 : v - 48, sd = h / (2 * DT), dt = (h % (2 * DT)) / 2, which = h % 2;
-                constexpr int imm = (st * 32 + 16 * sd) * C::ROWB + (which ? 0 : OIMG);  // which 0: dO^T (for dV), 1: Q^T (for dK)
-                tr_issue<imm, imm + 8 * C::ROWB>(ftr[v % RING], cur.at[dt], cur.at2[dt]);
-            }
-        };
-        auto mfma_step = [&](auto vc, auto nc, const f32x16& linit, const f32x16& dinit) {
-            constexpr int v = decltype(vc)::value, N = decltype(nc)::value;
-            if constexpr (v < 16 || (v >= 32 && v < 48)) {
-                constexpr int ks = (v % 16) / 2, which = v % 2;
-                const bf16x8 f = rowfrag_wait<N>(fr[v % RING]);
-                auto run = [&](f32x16& acc) {
-                    if constexpr (ks == 0) {
-                        if constexpr (which == 0) mfma_ownedB_init<OWNED, KF0>(acc, f, linit);
-                        else mfma_ownedB_init<OWNED, VF0>(acc, f, dinit);
-                    } else if constexpr (which == 0) mfma_ownedB<OWNED, KF0 + 4 * ks, false>(acc, f);
-                    else mfma_ownedB<OWNED, VF0 + 4 * ks, false>(acc, f);
-                };
-                if constexpr (v < 16 && which == 0) run(sacc1);
-                else if constexpr (v < 16) run(pacc1);
-                else if constexpr (which == 0) run(sacc0);
-                else run(pacc0);
-            } else {
-                constexpr int h = v < 32 ? v - 16 : v - 48, sd = h / (2 * DT), dt = (h % (2 * DT)) / 2, which = h % 2;
-                const bf16x8 fa = tr_wait<N>(ftr[v % RING]);
-                u32x4 w;
-                if constexpr (v < 32 && which == 0) w = (u32x4){pw0[4 * sd], pw0[4 * sd + 1], pw0[4 * sd + 2], pw0[4 * sd + 3]};
-                else if constexpr (v < 32) w = (u32x4){dsw0[4 * sd], dsw0[4 * sd + 1], dsw0[4 * sd + 2], dsw0[4 * sd + 3]};
-                else if constexpr (which == 0) w = (u32x4){pw1[4 * sd], pw1[4 * sd + 1], pw1[4 * sd + 2], pw1[4 * sd + 3]};
-                else w = (u32x4){dsw1[4 * sd], dsw1[4 * sd + 1], dsw1[4 * sd + 2], dsw1[4 * sd + 3]};
-                if constexpr (which == 0) mfma_owned<OWNED, 16 * dt, false>(fa, __builtin_bit_cast(bf16x8, w));
-                else mfma_owned<OWNED, DK0 + 16 * dt, false>(fa, __builtin_bit_cast(bf16x8, w));
-            }
-        };
-        // the vector work that rides in the gap behind step v: exp2 of element e, multiply of element e - 1 (P, then dS / scale in place), packs
-        auto b_exp = [&](f32x16& s_, auto ec) { constexpr int e = decltype(ec)::value; s_[e] = __builtin_amdgcn_exp2f(s_[e]); asm volatile("" : "+v"(s_[e])); };
-        auto b_mul = [&](f32x16& p_, const f32x16& s_, auto ec) { constexpr int e = decltype(ec)::value; p_[e] = p_[e] * s_[e]; asm volatile("" : "+v"(p_[e])); };
-        auto b_pack = [&](unsigned (&pw)[8], unsigned (&dsw)[8], const f32x16& s_, const f32x16& p_, auto jc) {
-            constexpr int j = decltype(jc)::value;
-            if constexpr (j < 8) { pw[j] = pack_bf2(s_[2 * j], s_[2 * j + 1]); asm volatile("" : "+v"(pw[j])); }
-            else { dsw[j - 8] = pack_bf2(p_[2 * (j - 8)], p_[2 * (j - 8) + 1]); asm volatile("" : "+v"(dsw[j - 8])); }
-        };
-        auto ride = [&](auto vc, auto lastc) {
-            constexpr int v = decltype(vc)::value;
-            constexpr bool LAST = decltype(lastc)::value;
-            if constexpr (v < 16) {                      // B(0) of cur: the last multiply, then the packs
-                if constexpr (v == 0) b_mul(pacc0, sacc0, std::integral_constant<int, 15>{});
-                b_pack(pw0, dsw0, sacc0, pacc0, std::integral_constant<int, v>{});
-            } else if constexpr (v < 32) {               // B(1) of cur: exp2 / multiply
-                b_exp(sacc1, std::integral_constant<int, v - 16>{});
-                if constexpr (v > 16) b_mul(pacc1, sacc1, std::integral_constant<int, v - 17>{});
-            } else if constexpr (v < 48) {               // B(1) of cur: the last multiply, then the packs
-                if constexpr (v == 32) b_mul(pacc1, sacc1, std::integral_constant<int, 15>{});
-                b_pack(pw1, dsw1, sacc1, pacc1, std::integral_constant<int, v - 32>{});
-            } else if constexpr (!LAST) {                // B(0) of nxt: exp2 / multiply
-                b_exp(sacc0, std::integral_constant<int, v - 48>{});
-                if constexpr (v > 48) b_mul(pacc0, sacc0, std::integral_constant<int, v - 49>{});
-            }
-        };
-        // LDS operations of the fragment of virtual step v
-        // (constexpr helpers cannot be lambdas with templates in C++17: spelled out where used)
-#define DKV2_NOPS(v) (((v) < 16 || ((v) >= 32 && (v) < 48)) ? 1 : 2)
-
-        // ---- the block's first tile: landed? (the first block waits here; later blocks were covered by the previous iteration's barrier)
-        Tile cur = make_tile(ch, cq, cstage), nxt = cur;
-        f32x16 linit, dinit;
-        if (kb == kb_lo) {
-            wait_tile(cur.stage);
-            __builtin_amdgcn_s_barrier();
-        }
-        {   // A(0) of the first tile, from a cold ring: steps 32 .. 47, then the first PD requests of the iteration that follows
-            rc_issue(cur, std::integral_constant<int, 0>{});
-            static_for<PD>([&](auto i) { frag_load(cur, cur, std::integral_constant<int, 32 + i.value>{}); });
-            rc_finish(cur, std::integral_constant<int, 0>{}, std::integral_constant<int, PD>{}, linit, dinit);
-            rc_issue(cur, std::integral_constant<int, 1>{});  // consumed at step 0 of the iteration
-            static_for<16>([&](auto i) {
-                constexpr int v = 32 + i.value, tv_ = v + PD;  // target of this step's request
-                if constexpr (tv_ < 48) frag_load(cur, cur, std::integral_constant<int, tv_>{});
-                else frag_load(cur, cur, std::integral_constant<int, tv_ - 48>{});  // A(1) of the same tile: steps 0 .. PD - 1 of the iteration
-                // younger LDS operations: the PD requests behind this fragment (all row reads here), + the 8 row-constant reads for those issued before them
-                constexpr int n = PD + (i.value < PD ? 8 : 0);
-                mfma_step(std::integral_constant<int, v>{}, std::integral_constant<int, (n > 15 ? 15 : n)>{}, linit, dinit);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            // B(0) of the first tile has no C(1) to ride on: exp2 / multiply here (the last multiply and the packs ride on A(1) as always)
-            tiles_settle(sacc0, pacc0);
-            static_for<16>([&](auto e) { b_exp(sacc0, e); });
-            static_for<15>([&](auto e) { b_mul(pacc0, sacc0, e); });
-        }
-        PROF_ADD(3, t_pro);
-        for (int it = 0; it < nit; ++it) {
-            [[maybe_unused]] const unsigned long long t_it = PROF_T();
-            [[maybe_unused]] unsigned long long t_seg = PROF_T();
-            const bool last = it + 1 == nit;
-            int nch = ch, ncq = cq + 1;
-            if (ncq == per_head) { ncq = 0; ++nch; }
-            const int nstage = cur.stage == NST - 1 ? 0 : cur.stage + 1;
-            if (!last) nxt = make_tile(nch, ncq, nstage);
-            const bool more_tiles = !last || kb + 1 < kb_hi;  // a tile follows in this workgroup's stream (in the next key block if `last`)
-            auto iteration = [&](auto lastc) {
-                constexpr bool LAST = decltype(lastc)::value;
-                // positions of the iteration: v = 0 .. 63, without 32 .. 47 when LAST (no next tile in this key block)
-                static_for<64>([&](auto vc) {
-                    constexpr int v = decltype(vc)::value;
-                    if constexpr (LAST && v >= 32 && v < 48) {
-                        if constexpr (v == 32) {  // B(1)'s last multiply and packs have no A(0) to ride on
-                            ride(std::integral_constant<int, 32>{}, lastc);
-                            static_for<15>([&](auto j) { ride(std::integral_constant<int, 33 + j.value>{}, lastc); });
-                        }
-                        return;
-                    }
-                    // the request PD positions ahead (positions skip 32 .. 47 when LAST; beyond the iteration: the next one's A(1), unless LAST)
-                    constexpr int raw = v + PD + ((LAST && v < 32 && v + PD >= 32) ? 16 : 0);
-                    if constexpr (raw < 64) frag_load(cur, nxt, std::integral_constant<int, raw>{});
-                    else if constexpr (!LAST) {  // A(1) of nxt = step raw - 64 of the next iteration, where nxt is cur
-                        constexpr int w = raw - 64, ks = w / 2, which = w % 2;
-                        rowfrag_issue<32 * C::ROWB + (which ? OIMG : 0)>(fr[w % RING], nxt.aq[ks]);
-                    }
-                    // younger LDS operations = those of the PD requests behind this step's fragment (as far as they were issued)
-                    constexpr int n = [] {
-                        int c = 0, pos = v;
-                        for (int i = 0; i < PD; ++i) {
-                            ++pos;
-                            if (LAST && pos == 32) pos = 48;
-                            if (pos >= 64) { if (LAST) break; c += 1; continue; }  // wrapped requests are row reads
-                            c += DKV2_NOPS(pos);
-                        }
-                        if (!LAST && ((v >= 25 && v <= 24 + PD) || (v >= 57 && v <= 56 + PD))) c += 8;  // requested before, consumed behind the 8 row-constant reads of steps 24 / 56
-                        return c > 15 ? 15 : c;
-                    }();
-                    if constexpr (v == 0) rc_finish(cur, std::integral_constant<int, 1>{}, std::integral_constant<int, PD>{}, linit, dinit);
-                    if constexpr (v == 32) rc_finish(nxt, std::integral_constant<int, 0>{}, std::integral_constant<int, (PD + 2 > 15 ? 15 : PD + 2)>{}, linit, dinit);
-                    mfma_step(vc, std::integral_constant<int, n>{}, linit, dinit);
-                    ride(vc, lastc);
-                    if constexpr (v == 16) store_ds(cur, std::integral_constant<int, 0>{}, dsw0);
-                    if constexpr (v == 48) store_ds(cur, std::integral_constant<int, 1>{}, dsw1);
-                    if constexpr (v == 24) {  // the next tile of the stream has landed, for every wave; its successor's requests go into the stage tile t-1 left
-                        PROF_ADD(8, t_seg);
-                        if (more_tiles) {
-                            [[maybe_unused]] unsigned long long t_s = PROF_T();
-                            wait_tile(nstage);
-                            PROF_ADD(1, t_s);
-                            t_s = PROF_T();
-                            __builtin_amdgcn_s_barrier();
-                            PROF_ADD(6, t_s);
-                            t_s = PROF_T();
-                            issue_next();
-                            PROF_ADD(7, t_s);
-                        }
-                        t_seg = PROF_T();
-                        if constexpr (!LAST) rc_issue(nxt, std::integral_constant<int, 0>{});
-                    }
-                    if constexpr (v == 56 && !LAST) rc_issue(nxt, std::integral_constant<int, 1>{});
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-            };
-            if (last) iteration(std::true_type{});
-            else {
-                iteration(std::false_type{});
-                PROF_ADD(9, t_seg);
-                cur = nxt;
-                ch = nch;
-                cq = ncq;
-            }
-            PROF_ADD(2, t_it);
-            if (prof_on) prof_acc[5] += 1;
-        }
-        [[maybe_unused]] const unsigned long long t_epi = PROF_T();
-#undef DKV2_NOPS
-        // ---- write-out of the block (as attn_bwd_dkv_kernel)
-        owned_settle<OWNED>();
-        if (kb + 1 < kb_hi) request_kv(kb + 1);
-        bf16_t* krow = dk + ((int64_t)b * S + kg) * lddk + (int64_t)hkv * D + 8 * (lane >> 5);
-        bf16_t* vrow = dv + ((int64_t)b * S + kg) * lddv + (int64_t)hkv * D + 8 * (lane >> 5);
-        static_for<DT * 2>([&](auto i) {
-            constexpr int dt = i.value / 2, gp = i.value % 2, rv = 16 * dt + 8 * gp, rk = DK0 + rv;
-            const unsigned ka0 = pack_bf2(owned_read<OWNED, rk>() * scale, owned_read<OWNED, rk + 1>() * scale), ka1 = pack_bf2(owned_read<OWNED, rk + 2>() * scale, owned_read<OWNED, rk + 3>() * scale);
-            const unsigned kb0 = pack_bf2(owned_read<OWNED, rk + 4>() * scale, owned_read<OWNED, rk + 5>() * scale), kb1 = pack_bf2(owned_read<OWNED, rk + 6>() * scale, owned_read<OWNED, rk + 7>() * scale);
-            const unsigned va0 = pack_bf2(owned_read<OWNED, rv>(), owned_read<OWNED, rv + 1>()), va1 = pack_bf2(owned_read<OWNED, rv + 2>(), owned_read<OWNED, rv + 3>());
-            const unsigned vb0 = pack_bf2(owned_read<OWNED, rv + 4>(), owned_read<OWNED, rv + 5>()), vb1 = pack_bf2(owned_read<OWNED, rv + 6>(), owned_read<OWNED, rv + 7>());
-            const auto k0s = __builtin_amdgcn_permlane32_swap(ka0, kb0, false, false), k1s = __builtin_amdgcn_permlane32_swap(ka1, kb1, false, false);
-            const auto v0s = __builtin_amdgcn_permlane32_swap(va0, vb0, false, false), v1s = __builtin_amdgcn_permlane32_swap(va1, vb1, false, false);
-            const u32x4 wk = {k0s[0], k1s[0], k0s[1], k1s[1]}, wv = {v0s[0], v1s[0], v0s[1], v1s[1]};
-            if (kvalid) {
-                *reinterpret_cast<u32x4*>(krow + dt * 32 + 16 * gp) = wk;
-                *reinterpret_cast<u32x4*>(vrow + dt * 32 + 16 * gp) = wv;
-            }
-        });
-        cstage = cur.stage == NST - 1 ? 0 : cur.stage + 1;
-        PROF_ADD(4, t_epi);
-    }
-    PROF_ADD(0, t_wg);
-#if ATTN_ABL & 16
-    if (prof_on)
-        for (int i = 0; i < 16; ++i) atomicAdd(&g_prof[i], prof_acc[i]);
-#endif
-}
-
 // ---- dQ from the spilled dS:  dQ^T[d x q] = scale * K^T[d x key] dS^T[key x q].  One workgroup = 128 queries of one (batch, head), a
 // wave = 32 of them = one (query tile, st) stream of the scratch buffer.  Per 64-key tile the K tile (transposed-read image, shared) and
 // each wave's own two 2-KiB dS blocks arrive by LDS-DMA, double-buffered; both MFMA operands are transposing reads in the same k order,
@@ -2114,10 +1720,7 @@ static int attn_bwd_impl(int B, int S, int Hq, int Hkv, int D, const void* q, in
 #define BWD_LAUNCH(DD)                                                                                                              \
     if (!delta_ready)                                                                                                               \
         hipLaunchKernelGGL(attn_delta_kernel<DD>, dim3(dgrid), dim3(256), 0, s, B, S, Hq, (const bf16_t*)o, ldo, (const bf16_t*)d_o, lddo, delta, lse, nl2, ndl); \
-    if (spill && DD == 128 && ((causal >> 8) & 16384))  /* ablation bit 14: the pipelined dK/dV pass */                             \
-        hipLaunchKernelGGL(attn_bwd_dkv2_kernel, dim3((unsigned)gk), dim3(256), 0, s, B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, \
-                           (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, nl2, ndl, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, key_mask, causal, scale, sl2, bpw_k, ds_ws); \
-    else if (spill && DD == 128)                                                                                                    \
+    if (spill && DD == 128)                                                                                                         \
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, true>), dim3((unsigned)gk), dim3(256), 0, s, B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, \
                            (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, nl2, ndl, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, key_mask, causal, scale, sl2, bpw_k, ds_ws); \
     else                                                                                                                             \
