@@ -201,6 +201,65 @@ def dominant_kernel_rate(batch, device):
     return out
 
 
+class BoardPower:
+    """Board power and shader clock over the timed steps, from the amdgpu hwmon files (power1_input uW, freq1_input Hz: readable without privileges, sampled every 10 ms
+    by a thread that touches nothing else).  A box shows the hwmon directories of cards that are not this job's: the card is the one whose power follows the warm-up
+    steps.  Reported beside the roofline because the step runs AT the board's cap (profiles/r05_power.json): what the matrix pipe sustains there, not at 2.4 GHz, is
+    what the step is up against."""
+
+    def __init__(self):
+        import glob
+        import threading
+
+        self.dirs = [os.path.dirname(p) for p in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input")]
+        self.idle = {d: self._read(d)[0] for d in self.dirs}
+        self.peak = dict(self.idle)
+        self.chosen, self.samples, self._stop = None, [], threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        if self.dirs:
+            self._thread.start()
+
+    @staticmethod
+    def _read(d):
+        try:
+            return int(open(d + "/power1_input").read()) / 1e6, int(open(d + "/freq1_input").read()) / 1e6
+        except (OSError, ValueError):
+            return 0.0, 0.0
+
+    def _run(self):
+        while not self._stop.is_set():
+            if self.chosen is None:
+                for d in self.dirs:
+                    self.peak[d] = max(self.peak[d], self._read(d)[0])
+            else:
+                self.samples.append(self._read(self.chosen))
+            time.sleep(0.01)
+
+    def choose(self):  # after the warm-up steps, before the timed region
+        rise = {d: self.peak[d] - self.idle[d] for d in self.dirs}
+        best = max(rise, key=rise.get) if rise else None
+        if best is not None and rise[best] >= 150.0:
+            self.samples = []
+            self.chosen = best
+
+    def mark(self):  # the timed region starts here
+        self.samples = []
+
+    def result(self):
+        self._stop.set()
+        if self.chosen is None:
+            return {"mean_W": None, "note": "no visible amdgpu hwmon followed the warm-up steps (telemetry of this card not exposed)"}
+        s = [x for x in self.samples if x[0] > 0]
+        if not s:
+            return {"mean_W": None, "note": "no samples"}
+        try:
+            cap = int(open(self.chosen + "/power1_cap").read()) / 1e6
+        except (OSError, ValueError):
+            cap = None
+        return {"mean_W": round(sum(x[0] for x in s) / len(s), 1), "cap_W": cap, "sclk_mean_MHz": round(sum(x[1] for x in s) / len(s)), "samples": len(s),
+                "source": "amdgpu hwmon power1_input / freq1_input every 10 ms over the timed steps; the dense peak in `roofline` assumes 2 400 MHz"}
+
+
 def launch_ranks(n):
     """``python bench.py --gpus N`` without a torchrun environment: run the N ranks as a child ``torch.distributed.run`` job (a fresh
     process tree; nothing in THIS process has initialised the GPU yet) and pass its output and exit status through."""
@@ -408,6 +467,7 @@ def run_other_config(args):
     device = torch.device("cuda", local)
     _lib.load()
     batch = args.batch if args.batch_given else spec["batch"]
+    power = BoardPower() if rank == 0 else None
     step, sync, state = _other_config_step(args.config, batch, device, rank)
 
     def fence():
@@ -418,6 +478,9 @@ def run_other_config(args):
     for _ in range(args.warmup):
         loss = step()
     fence()
+    if power is not None:
+        power.choose()
+        power.mark()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
@@ -426,6 +489,7 @@ def run_other_config(args):
     ev1.record()
     fence()
     elapsed = time.perf_counter() - t0
+    board_power = power.result() if power is not None else None
     dev_ms = ev0.elapsed_time(ev1)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -440,6 +504,7 @@ def run_other_config(args):
             "config": {"workload": spec["workload"], "per_gpu_batch": batch, "global_batch": batch * world, "parallelism": f"dp{world}", "units_per_sample": spec["units_per_sample"]},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), **_config_traffic(args.config, batch),
                          "basis": f"algorithmic {spec['flop'] / 1e9:.1f} GFLOP/sample (SURVEY 8d) x per-GPU batch / step time; device-side (HIP events) {dev_ms / args.steps:.3f} ms/step"},
+            "board_power": board_power,
             "loss": round(float(loss.detach()), 5), "peak_memory_gib": round(torch.cuda.max_memory_allocated(device) / 2**30, 1),
         }
         if world == 1 and args.cpu_baseline == "auto":
@@ -503,6 +568,7 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     _lib.load()
+    power = BoardPower() if rank == 0 else None
 
     vit, vit_cfg, ad, llm, llm_cfg = build_models(device)
     if args.tower != "default":
@@ -546,7 +612,11 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     fence()
+    if power is not None:
+        power.choose()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if power is not None:
+        power.mark()
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(args.steps):
@@ -554,6 +624,7 @@ def main():
     ev1.record()
     fence()
     elapsed = time.perf_counter() - t0
+    board_power = power.result() if power is not None else None
     dev_ms = ev0.elapsed_time(ev1)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -620,6 +691,7 @@ def main():
                 "basis": "algorithmic 2.566 TFLOP/sample (SURVEY 8d) x per-GPU batch / step time; device-side (HIP events) "
                          f"{dev_ms / args.steps:.3f} ms/step",
             },
+            "board_power": board_power,
             "loss": round(loss_gpu, 5), "peak_memory_gib": round(torch.cuda.max_memory_allocated(device) / 2**30, 1),
         }
         if world > 1:  # how the N > 1 step's large NT GEMMs were launched: on the persistent kernel, or on the per-tile kernel inside a window behind a bucket group (ddp.GradSync)

@@ -1,0 +1,101 @@
+// What v_mfma_f32_32x32x16_bf16 sustains on all 256 CUs under the board's power cap, by operand DATA: the dense "peak" (2.5 PFLOP/s at 2.4 GHz) assumes a clock
+// the chip only holds on operands that do not toggle.  No memory traffic at all in modes 0-1; mode 2 re-reads its fragments from LDS every K step as a GEMM does.
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_power tools/microbench/mfma_power.hip && /tmp/mfma_power MODE SECONDS
+//   MODE 0: all-zero operands   1: random operands held in registers   2: random operands, eight ds_read_b128 per sixteen MFMAs (a 128 x 128 wave tile's K step)
+// Prints `WINDOW t0 t1 us_per_launch` (for tools/power_trace.py) and the rate.
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
+typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
+
+__device__ __forceinline__ unsigned mix(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+// a bf16 pair with random sign and mantissa, exponents spread over 2^-3 .. 2^0 (what a normalised activation x weight product sees)
+__device__ __forceinline__ unsigned rnd_pair(unsigned s) {
+    const unsigned r = mix(s);
+    const unsigned lo = (r & 0x807fu) | ((124u + ((r >> 8) & 3u)) << 7);
+    const unsigned hi = ((r >> 16) & 0x807fu) | ((124u + ((r >> 24) & 3u)) << 7);
+    return lo | (hi << 16);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void k(float* out, int reps) {
+    __shared__ u32x4 lds[8 * 256 * 2];  // 64 KiB: two K steps of eight fragments per thread
+    u32x4 fr[8];
+    for (int j = 0; j < 8; ++j)
+        for (int e = 0; e < 4; ++e) fr[j][e] = MODE == 0 ? 0u : rnd_pair((blockIdx.x * 256 + threadIdx.x) * 64 + j * 4 + e);
+    if constexpr (MODE == 2) {
+        for (int s = 0; s < 2; ++s)
+            for (int j = 0; j < 8; ++j) {
+                u32x4 v;
+                for (int e = 0; e < 4; ++e) v[e] = rnd_pair(0x9e3779b9u * (s + 1) + (blockIdx.x * 256 + threadIdx.x) * 64 + j * 4 + e);
+                lds[(s * 8 + j) * 256 + threadIdx.x] = v;
+            }
+        __syncthreads();
+    }
+    f32x16 acc[16];
+    for (int t = 0; t < 16; ++t)
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    for (int r = 0; r < reps; ++r) {
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fr[j] = lds[((r & 1) * 8 + j) * 256 + threadIdx.x];
+        } else {
+            asm volatile("" : "+v"(fr[0]), "+v"(fr[1]), "+v"(fr[2]), "+v"(fr[3]), "+v"(fr[4]), "+v"(fr[5]), "+v"(fr[6]), "+v"(fr[7]));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[i]), __builtin_bit_cast(bf16x8, fr[4 + j]), acc[i * 4 + j], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int t = 0; t < 16; ++t)
+        for (int e = 0; e < 16; ++e) s += acc[t][e];
+    if (reps == -1) out[blockIdx.x * 256 + threadIdx.x] = s;
+    else if (s == 12345.678f) out[0] = s;
+}
+
+static double now() { return std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count(); }
+
+template <int MODE>
+void run(double seconds) {
+    float* out;
+    hipMalloc(&out, 256 * 256 * 4);
+    const int blocks = 256, reps = 20000;  // 20 000 K steps x 16 MFMAs per wave: ~ 2.5 ms a launch
+    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, reps);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0), hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, reps);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const int n = (int)(seconds * 1e3 / ms) + 1;
+    const double t0 = now();
+    hipEventRecord(e0);
+    for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, reps);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    const double t1 = now();
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flop = 2.0 * 32 * 32 * 16 * 16.0 * reps * 4 * blocks;
+    printf("mode %d: %.1f us per launch, %.1f TFLOP/s (%.1f %% of 2 500)\n", MODE, ms / n * 1e3, flop / (ms / n * 1e-3) / 1e12, flop / (ms / n * 1e-3) / 2.5e13);
+    printf("WINDOW %.6f %.6f %.2f\n", t0, t1, ms / n * 1e3);
+}
+
+int main(int argc, char** argv) {
+    const int mode = argc > 1 ? atoi(argv[1]) : 1;
+    const double sec = argc > 2 ? atof(argv[2]) : 4.0;
+    if (mode == 0) run<0>(sec);
+    else if (mode == 1) run<1>(sec);
+    else run<2>(sec);
+    return 0;
+}
