@@ -410,12 +410,30 @@ int mi355_pad_tokens(int B, int L, const int64_t* flat_ids, const int64_t* offse
  * stream, one wave per output column.  bf16 in / out, fp32 accumulate. */
 int mi355_gemv_bf16(int M, int64_t N, int K, const void* x, int64_t ldx, const void* W, int64_t ldw, void* y, int64_t ldy, const void* residual,
                     int64_t ldr, void* stream);
+/* The same weight stream with the row operation that feeds it folded in -- a one-token step is bound by its launch count (12 -> 6 per
+ * block): prologue 1 = x rows are RMS-normalised with weight norm_w / eps first (PytorchRMSNorm, qwen3_attention.py:19-29, in front of the QKV,
+ * gate-up and head projections); prologue 2 = x holds the fused lin1 | lin_gate rows [M, 2K] and the operand is lin1 * silu(lin_gate)
+ * (FFN.forward, qwen3_transformer_block.py:48-53).  Same arithmetic and rounding as mi355_rmsnorm_fwd / mi355_swiglu_fwd followed by
+ * mi355_gemv_bf16 (bit-identical); M * K * 2 bytes <= 64 KiB. */
+int mi355_gemv_bf16_pro(int M, int64_t N, int K, const void* x, int64_t ldx, int prologue, const void* norm_w, float eps, const void* W, int64_t ldw,
+                        void* y, int64_t ldy, const void* residual, int64_t ldr, void* stream);
 /* One query row per (batch, head) against `len` cached keys / values (qwen3_attention.py:117-146 with a KV cache and q_seq_len 1):
  * q, o bf16 [B, Hq*D]; caches bf16 token-major, sequence b at k_cache + b*batch_stride, key j at + j*ld, kv head g at + g*D.
  * key_mask uint8 [B, >= len] row pitch ldm (1 = real token) or NULL; masked keys take the reference's finite fill. D in {64,128,256}.
  * len_dev != NULL: the number of valid keys is min(len, *len_dev) read on the device (hipGraph replay), len is then the capacity bound. */
 int mi355_attn_decode(int B, int Hq, int Hkv, int D, const void* q, const void* k_cache, const void* v_cache, int64_t batch_stride, int64_t ld,
                       int len, const int32_t* len_dev, const uint8_t* key_mask, int64_t ldm, void* o, float scale, void* stream);
+/* mi355_attn_decode started from the fused QKV stream's raw rows qkv bf16 [B, (Hq + 2 Hkv) * D] of ONE new token per sequence
+ * (GroupedQueryAttention.forward with a KV cache, qwen3_attention.py:100-146): QK-RMSNorm + RoPE of each head's query and of its kv head's
+ * new key inside the launch (arithmetic of mi355_qknorm_rope_fwd), the new key and value heads written to cache row *write_pos, attention
+ * over min(capacity, *len_dev) keys -- mi355_qknorm_rope_fwd + mi355_kv_append + mi355_attn_decode in one launch, bit-identical.
+ * pos int32 [B] rotary positions; write_pos, len_dev int32 [1] on the device. D in {64,128}. */
+int mi355_attn_decode_qkv(int B, int Hq, int Hkv, int D, const void* qkv, int64_t ldqkv, const void* q_norm_w, const void* k_norm_w, const float* cos,
+                          const float* sin, const int32_t* pos, void* k_cache, void* v_cache, int64_t batch_stride, int64_t ld, int capacity,
+                          const int32_t* write_pos, const int32_t* len_dev, const uint8_t* key_mask, int64_t ldm, void* o, float scale, float eps, void* stream);
+/* The tail of a greedy step under hipGraph replay: tok[b] = next_ids[b], rope_pos[b] += 1, *write_pos += 1, *length += 1 (generate.py:139-148's
+ * bookkeeping, kept on the device). */
+int mi355_decode_advance(int B, const int64_t* next_ids, int64_t* tok, int32_t* rope_pos, int32_t* write_pos, int32_t* length, void* stream);
 /* KVCache append of ONE decoded token per sequence with the write position on the device (so a captured hipGraph of the decode
  * step can be replayed): cache[b, *pos, :] = rows[b, :] for keys and values; width = kv_heads * head_dim. */
 int mi355_kv_append(int B, int width, const void* k_rows, int64_t ldk, const void* v_rows, int64_t ldv, void* k_cache, void* v_cache,

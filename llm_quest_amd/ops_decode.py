@@ -31,6 +31,57 @@ def gemv(x2d, w, residual=None):
     return y
 
 
+def gemv_pro(x2d, w, prologue, norm_w=None, eps=1e-6, residual=None):
+    """The decode step's weight stream with the row operation in front of it folded in (``mi355_gemv_bf16_pro``): prologue "rmsnorm" = ``gemv(rmsnorm_fwd(x, norm_w), w)``,
+    "swiglu" = ``gemv(swiglu_fwd(x, K), w)`` with x = fused lin1 | lin_gate rows [M, 2K]; bit-identical to the two launches, one launch fewer each."""
+    M = x2d.shape[0]
+    Kd = w.shape[1]
+    L.require_gpu(x2d, w, norm_w, residual)
+    code = {"rmsnorm": 1, "swiglu": 2}[prologue]
+    if M > 8 or x2d.dtype != BF16 or w.dtype != BF16 or x2d.stride(1) != 1 or w.stride(1) != 1 or x2d.shape[1] != (2 * Kd if code == 2 else Kd):
+        raise ValueError("gemv_pro: <= 8 bf16 rows with unit inner stride, K (rmsnorm) or 2K (swiglu) wide")
+    if code == 1 and (norm_w is None or norm_w.dtype != BF16 or norm_w.numel() != Kd or not norm_w.is_contiguous()):
+        raise ValueError("gemv_pro: rmsnorm prologue needs a contiguous bf16 weight of K elements")
+    y = torch.empty((M, w.shape[0]), dtype=BF16, device=x2d.device)
+    L.call("mi355_gemv_bf16_pro", M, w.shape[0], Kd, L.ptr(x2d), x2d.stride(0), code, L.ptr(norm_w), eps, L.ptr(w), w.stride(0), L.ptr(y), y.stride(0),
+           L.ptr(residual), residual.stride(0) if residual is not None else 0)
+    return y
+
+
+def fused_rows(M, Kd):
+    """Whether a one-token step of M sequences takes the fused streams (the operand rows must fit the kernel's 64-KiB LDS image)."""
+    return M <= 8 and M * Kd * 2 <= 65536
+
+
+def attn_decode_qkv(qkv, qw, kw, cos, sin, pos, Hq, Hkv, D, kc, vc, write_pos_dev, len_dev, key_mask=None, scale=None, eps=1e-6):
+    """One new token per sequence from the fused QKV stream's raw rows to the attention context (``mi355_attn_decode_qkv``): QK-norm + RoPE of the query and the new key
+    inside the launch, key and value heads written into cache row ``*write_pos_dev``, attention over ``*len_dev`` keys -- ``qknorm_rope_fwd`` + ``kv_append_dev`` +
+    ``attn_decode`` in one launch, bit-identical."""
+    L.require_gpu(qkv, qw, kw, cos, sin, pos, kc, vc, write_pos_dev, len_dev, key_mask)
+    B = qkv.shape[0]
+    if (qkv.dtype != BF16 or qkv.stride(1) != 1 or qkv.shape[1] != (Hq + 2 * Hkv) * D or kc.shape != vc.shape or kc.stride() != vc.stride() or kc.shape[0] != B
+            or kc.shape[2] != Hkv * D or kc.stride(2) != 1 or pos.dtype != torch.int32 or pos.numel() != B or write_pos_dev.dtype != torch.int32 or len_dev.dtype != torch.int32):
+        raise ValueError("attn_decode_qkv: qkv bf16 [B, (Hq + 2 Hkv) D], caches [B, capacity, Hkv D] of one layout, int32 positions / length on the device")
+    ldm = 0
+    if key_mask is not None:
+        if key_mask.dtype != torch.uint8 or key_mask.shape[0] != B or key_mask.shape[1] < kc.shape[1] or key_mask.stride(1) != 1:
+            raise ValueError("attn_decode_qkv: key_mask uint8 [B, >= capacity]")
+        ldm = key_mask.stride(0)
+    o = torch.empty((B, Hq * D), dtype=BF16, device=qkv.device)
+    L.call("mi355_attn_decode_qkv", B, Hq, Hkv, D, L.ptr(qkv), qkv.stride(0), L.ptr(qw), L.ptr(kw), L.ptr(cos), L.ptr(sin), L.ptr(pos), L.ptr(kc), L.ptr(vc), kc.stride(0),
+           kc.stride(1), kc.shape[1], L.ptr(write_pos_dev), L.ptr(len_dev), L.ptr(key_mask), ldm, L.ptr(o), D ** -0.5 if scale is None else scale, eps)
+    return o
+
+
+def decode_advance(next_ids, tok, rope_pos, write_pos, length):
+    """tok <- next_ids; every device-side counter of the step + 1 (one launch: the tail of ``GraphDecoder``'s captured step)."""
+    L.require_gpu(next_ids, tok, rope_pos, write_pos, length)
+    B = tok.numel()
+    if next_ids.dtype != torch.int64 or tok.dtype != torch.int64 or next_ids.numel() != B or rope_pos.numel() != B or not (next_ids.is_contiguous() and tok.is_contiguous()):
+        raise ValueError("decode_advance: int64 ids of one size, int32 counters")
+    L.call("mi355_decode_advance", B, L.ptr(next_ids), L.ptr(tok), L.ptr(rope_pos), L.ptr(write_pos), L.ptr(length))
+
+
 def attn_decode(q, kc, vc, length, Hq, Hkv, D, key_mask=None, scale=None, len_dev=None):
     """q [B, Hq*D]; kc / vc [B, capacity, Hkv*D]; attends to keys [0, length) -- or [0, min(length, *len_dev)) with the length read
     on the device (graph replay)."""
@@ -94,17 +145,25 @@ def cached_key_mask(attn_mask, kv_cache, B, S, device):
 
 
 @torch.no_grad()
-def attention_cached(att, h1, B, S, cos, sin, pos, km, kv_cache, dev_state=None, residual=None):
+def attention_cached(att, h1, B, S, cos, sin, pos, km, kv_cache, dev_state=None, residual=None, pre_norm=None):
     """``GroupedQueryAttention.forward(..., kv_cache=...)`` (reference qwen3_attention.py:91-148) on rows h1 bf16 [B*S, d_in]: fused QKV
     projection, QK-norm + RoPE, cache append, attention over the cache (prefill: flash attention over the prompt; decode: one query row per
-    head), output projection (+ residual)."""
+    head), output projection (+ residual).  ``pre_norm``: h1 is the block's residual stream and this RMSNorm weight is applied inside the QKV
+    stream (one-token steps, ``gemv_pro``)."""
     arena = ops.arena_for(att)
     Hq, Hkv, D = att.num_heads, att.num_kv_groups, att.head_dim
     decode = kv_cache.start_pos > 0
     if decode and S != 1:
         raise NotImplementedError("with a filled KV cache one new token per sequence is decoded (q_seq_len 1, generate.py:139-148)")
     lin = _lin(decode)
-    qkv = lin(h1, arena.fused(att.w_queries.weight, att.w_values.weight))
+    wqkv = arena.fused(att.w_queries.weight, att.w_values.weight)
+    qkv = gemv_pro(h1, wqkv, "rmsnorm", pre_norm) if pre_norm is not None else lin(h1, wqkv)
+    if dev_state is not None and D in (64, 128) and (km is None or km.shape[1] >= kv_cache.keys_cache[att.layer_idx].shape[1]):
+        # graph replay, one launch from the raw QKV rows to the context: the new key / value go into the cache row at the device-side position
+        _, write_pos, len_dev = dev_state
+        kc, vc = kv_cache.keys_cache[att.layer_idx], kv_cache.values_cache[att.layer_idx]
+        ctx = attn_decode_qkv(qkv, att.q_norm.weight, att.k_norm.weight, cos, sin, pos, Hq, Hkv, D, kc, vc, write_pos, len_dev, key_mask=km, scale=att.att_scaling)
+        return lin(ctx, att.out_proj.weight, residual=residual)
     q, k, _ = K.qknorm_rope_fwd(qkv, att.q_norm.weight, att.k_norm.weight, cos, sin, pos, Hq, Hkv, D)
     v = qkv[:, (Hq + Hkv) * D :]
     if dev_state is not None:  # graph replay: position and length are read on the device, the cache object is advanced by the caller
@@ -128,11 +187,16 @@ def block_cached(blk, h, B, S, cos, sin, pos, km, kv_cache, dev_state=None):
     ffn = blk.ffn
     decode = kv_cache.start_pos > 0
     lin = _lin(decode)
+    F = ffn.lin1.weight.shape[0]
+    if decode and fused_rows(B * S, max(h.shape[1], F)):  # one-token step: 6 launches instead of 10 (the norms and the activation ride in the weight streams)
+        h = attention_cached(blk.att, h, B, S, cos, sin, pos, km, kv_cache, dev_state, residual=h, pre_norm=blk.norm1.weight)
+        gu = gemv_pro(h, arena.fused(ffn.lin1.weight, ffn.lin_gate.weight), "rmsnorm", blk.norm2.weight)
+        return gemv_pro(gu, ffn.lin2.weight, "swiglu", residual=h)
     h1, _ = K.rmsnorm_fwd(h, blk.norm1.weight, want_rstd=False)
     h = attention_cached(blk.att, h1, B, S, cos, sin, pos, km, kv_cache, dev_state, residual=h)
     h2, _ = K.rmsnorm_fwd(h, blk.norm2.weight, want_rstd=False)
     gu = lin(h2, arena.fused(ffn.lin1.weight, ffn.lin_gate.weight))
-    return lin(K.swiglu_fwd(gu, ffn.lin1.weight.shape[0]), ffn.lin2.weight, residual=h)
+    return lin(K.swiglu_fwd(gu, F), ffn.lin2.weight, residual=h)
 
 
 
@@ -171,6 +235,8 @@ def qwen3_forward_cached(model, x, kv_cache, attn_mask=None, position_ids=None, 
             raise ValueError(f"attn_mask must cover the cached sequence: (b, >= {start + S}), got {tuple(km.shape)}")
     for blk in model.trf_blocks:
         h = block_cached(blk, h, B, S, model.cos, model.sin, pos, km, kv_cache, dev_state)
+    if decode and fused_rows(B * S, h.shape[1]):
+        return gemv_pro(h, model.out_head.weight, "rmsnorm", model.final_norm.weight).view(B, S, -1)
     lin = _lin(decode)
     hn, _ = K.rmsnorm_fwd(h, model.final_norm.weight, want_rstd=False)
     return lin(hn, model.out_head.weight).view(B, S, -1)
@@ -204,10 +270,7 @@ class GraphDecoder:
     def _step(self):
         logits = qwen3_forward_cached(self.model, self.tok, self.kv, dev_state=(self.rope_pos, self.write_pos, self.length))
         nxt = argmax_rows(logits.view(logits.shape[0], -1))
-        self.tok.copy_(nxt.unsqueeze(-1))
-        self.rope_pos.add_(1)
-        self.write_pos.add_(1)
-        self.length.add_(1)
+        decode_advance(nxt, self.tok, self.rope_pos, self.write_pos, self.length)
 
     def step(self):
         """Consumes ``self.tok`` (the token chosen last), leaves the next greedy token in ``self.tok`` and returns a copy of it."""

@@ -137,6 +137,8 @@ def main():
         else:
             if w.startswith("mfma"):  # tools/microbench/mfma_power.hip built to /tmp/mfma_power: mfma0 / mfma1 / mfma2
                 cmd = ["/tmp/mfma_power", w[4:], "6"]
+            elif w.startswith("exe="):  # any binary that prints a WINDOW line: exe=/tmp/stream_power,2048,5
+                cmd = w[4:].split(",")
             else:
                 cmd = [sys.executable, os.path.abspath(__file__), "--child", w, "6"]
             p = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT)
