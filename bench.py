@@ -532,6 +532,8 @@ def main():
     ap.add_argument("--ragged", action="store_true", help="text lengths ~ U[256, 512] (padding mask active in attention and loss) instead of all-ones masks")
     ap.add_argument("--optimizer", choices=["on", "off"], default="on", help="also time the same steps with clip + AdamW (reported beside the fwd+bwd metric)")
     ap.add_argument("--vision-ahead", choices=["on", "off"], default="on", help="frozen ViT of the next step's batch on a second stream (vlm_engine.VisionAhead), as the training loop runs it")
+    ap.add_argument("--pipe-probe", choices=["on", "off"], default="on", help="N = 1: also time the matrix pipe alone on random operands for 2 s (kernels.mfma_pipe_rate) -- the rate this board's "
+                    "power cap allows, printed beside the dense peak the roofline is priced against")
     ap.add_argument("--tower", choices=["default", "fp32", "bf16"], default="default", help="arithmetic of the frozen vision tower (vit_model.tower_precision): fp32 = the reference's "
                     "(vlm_engine.py:99-104 runs the ViT outside autocast; split-bf16 GEMMs + exact-fp32 attention), bf16 = bf16 MFMA operands on an fp32 residual stream; default = the package's default")
     args = ap.parse_args()
@@ -700,6 +702,14 @@ def main():
             line["gemm_windows"] = dict(K_._WINDOW.stats, bucket_blocks=sync.bucket_blocks, window_launches=sync.window_launches)
         if train_step is not None:
             line["with_optimizer_step"] = train_step
+        if world == 1 and args.pipe_probe == "on":
+            from llm_quest_amd import kernels as K_
+
+            pipe = K_.mfma_pipe_rate(2.0)
+            line["roofline"]["power_capped_pipe"] = {
+                "rate": round(pipe, 1), "unit": "TFLOP/s", "achieved_over_rate": round(achieved / pipe, 4),
+                "what": "v_mfma_f32_32x32x16_bf16 on every SIMD, random bf16 operands in registers, no memory traffic, measured on this board right after the timed steps: on random data the "
+                        "board's power cap holds the pipe itself below the 2 500 TFLOP/s of `peak` (DESIGN.md section 5)"}
         if world == 1:
             line["roofline"]["dominant_kernel"] = {"name": "gemm_nt_persist_kernel / gemm_grouped_kernel (NT projections on the persistent form of tile 2; the block's weight gradients as one grouped launch on tile 5)", "hip_event_timing": dominant_kernel_rate(args.batch, device)}
             pmc, why_gemm = pmc_traffic()

@@ -443,6 +443,13 @@ int mi355_kv_append(int B, int width, const void* k_rows, int64_t ldk, const voi
 int mi355_argmax_rows(int64_t rows, int64_t V, const void* logits, int64_t ld, int64_t* out, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------------
+ * Measurement aid (csrc/probe.hip), no reference counterpart: `blocks` workgroups of four waves run reps x 16 v_mfma_f32_32x32x16_bf16 on random
+ * bf16 operands held in registers (2 * 32*32*16 * 16 * reps * 4 * blocks FLOP, no memory traffic) -- the rate the board's power cap leaves the
+ * matrix pipe, which bench.py reports beside the dense peak.  out: blocks * 256 floats (a checksum sink).
+ * ------------------------------------------------------------------------------------------------------------------- */
+int mi355_mfma_pipe_probe(int blocks, int reps, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------------
  * Stand-alone rotary embedding and dropout (csrc/rope_dropout.hip, csrc/attention_generic.hip).
  * ------------------------------------------------------------------------------------------------------------------- */
 

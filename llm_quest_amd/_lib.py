@@ -98,6 +98,8 @@ SIGNATURES = {
     "mi355_attn_decode": [_I, _I, _I, _I, _P, _P, _P, _L, _L, _I, _P, _P, _L, _P, _F, _P],
     "mi355_kv_append": [_I, _I, _P, _L, _P, _L, _P, _P, _L, _L, _I, _P, _P],
     "mi355_argmax_rows": [_L, _L, _P, _L, _P, _P, _P],
+    # measurement aid (csrc/probe.hip)
+    "mi355_mfma_pipe_probe": [_I, _I, _P, _P],
     # stand-alone RoPE and dropout (csrc/rope_dropout.hip, csrc/attention_generic.hip)
     "mi355_rope_apply": [_I, _I, _I, _I, _I, _P, _I, _L, _L, _L, _P, _P, _L, _P, _P, _L, _L, _L, _I, _P],
     "mi355_dropout": [_L, _P, _I, _P, _P, _I, _F, _U, _U, _P],

@@ -994,3 +994,29 @@ def attn_generic_dropout_bwd(q, k, v, o, do, lse, B, S, Hq, Hkv, D, dq, dk, dv, 
     L.call("mi355_attn_generic_dropout_bwd", B, S, Hq, Hkv, D, L.ptr(q), q.stride(0), L.ptr(k), k.stride(0), L.ptr(v), v.stride(0), L.ptr(o), o.stride(0),
            L.ptr(do), do.stride(0), L.ptr(lse), L.ptr(delta), L.ptr(dq), dq.stride(0), L.ptr(dk), dk.stride(0), L.ptr(dv), dv.stride(0),
            L.ptr(key_mask), scale, float(p), int(seed), int(offset))
+
+
+def mfma_pipe_rate(seconds=2.0, blocks=256):
+    """TFLOP/s the matrix pipe alone sustains on this board (``mi355_mfma_pipe_probe``: random bf16 operands in registers, no memory traffic), timed with HIP events over the
+    second half of ``seconds`` of back-to-back launches -- the board's power cap needs about a second to settle the clock.  A measurement aid for ``bench.py``."""
+    import torch
+
+    out = torch.empty(blocks * 256, dtype=torch.float32, device="cuda")
+    L.require_gpu(out)
+    reps = 8000  # ~ 1 ms a launch
+    flop = 2.0 * 32 * 32 * 16 * 16 * reps * 4 * blocks
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+
+    def run(n):
+        ev[0].record()
+        for _ in range(n):
+            L.call("mi355_mfma_pipe_probe", blocks, reps, L.ptr(out))
+        ev[1].record()
+        torch.cuda.synchronize()
+        return ev[0].elapsed_time(ev[1]) / n  # ms per launch
+
+    per = run(20)
+    n = max(20, int(seconds * 500 / per))
+    run(n)  # first half: the clock settles
+    per = run(n)
+    return flop / (per * 1e-3) / 1e12

@@ -2,6 +2,7 @@
 // the chip only holds on operands that do not toggle.  No memory traffic at all in modes 0-1; mode 2 re-reads its fragments from LDS every K step as a GEMM does.
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_power tools/microbench/mfma_power.hip && /tmp/mfma_power MODE SECONDS
 //   MODE 0: all-zero operands   1: random operands held in registers   2: random operands, eight ds_read_b128 per sixteen MFMAs (a 128 x 128 wave tile's K step)
+//   MODE 3: mode 1 on v_mfma_f32_16x16x32_bf16 (64 accumulators of 16 x 16, 8 + 8 fragments: the same 128 x 128 wave tile, K step 32) -- joules per FLOP by MFMA shape
 // Prints `WINDOW t0 t1 us_per_launch` (for tools/power_trace.py) and the rate.
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -61,19 +62,48 @@ __global__ __launch_bounds__(256, 1) void k(float* out, int reps) {
     else if (s == 12345.678f) out[0] = s;
 }
 
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
+__global__ __launch_bounds__(256, 1) void k16(float* out, int reps) {
+    u32x4 fr[16];
+    for (int j = 0; j < 16; ++j)
+        for (int e = 0; e < 4; ++e) fr[j][e] = rnd_pair((blockIdx.x * 256 + threadIdx.x) * 64 + j * 4 + e);
+    f32x4 acc[64];
+    for (int t = 0; t < 64; ++t)
+        for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
+    for (int r = 0; r < reps; ++r) {
+        asm volatile("" : "+v"(fr[0]), "+v"(fr[1]), "+v"(fr[2]), "+v"(fr[3]), "+v"(fr[4]), "+v"(fr[5]), "+v"(fr[6]), "+v"(fr[7]));
+        asm volatile("" : "+v"(fr[8]), "+v"(fr[9]), "+v"(fr[10]), "+v"(fr[11]), "+v"(fr[12]), "+v"(fr[13]), "+v"(fr[14]), "+v"(fr[15]));
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                acc[i * 8 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fr[i]), __builtin_bit_cast(bf16x8, fr[8 + j]), acc[i * 8 + j], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int t = 0; t < 64; ++t)
+        for (int e = 0; e < 4; ++e) s += acc[t][e];
+    if (reps == -1) out[blockIdx.x * 256 + threadIdx.x] = s;
+    else if (s == 12345.678f) out[0] = s;
+}
+
 static double now() { return std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count(); }
 
+template <int MODE>
+void launch(int blocks, float* out, int reps) {
+    if constexpr (MODE == 3) hipLaunchKernelGGL(k16, dim3(blocks), dim3(256), 0, 0, out, reps / 2);  // a K step of 32: half as many for the same FLOP
+    else hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, reps);
+}
 template <int MODE>
 void run(double seconds) {
     float* out;
     hipMalloc(&out, 256 * 256 * 4);
     const int blocks = 256, reps = 20000;  // 20 000 K steps x 16 MFMAs per wave: ~ 2.5 ms a launch
-    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, reps);
+    for (int w = 0; w < 3; ++w) launch<MODE>(blocks, out, reps);
     hipDeviceSynchronize();
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, reps);
+    launch<MODE>(blocks, out, reps);
     hipEventRecord(e1);
     hipDeviceSynchronize();
     float ms;
@@ -81,7 +111,7 @@ void run(double seconds) {
     const int n = (int)(seconds * 1e3 / ms) + 1;
     const double t0 = now();
     hipEventRecord(e0);
-    for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, reps);
+    for (int i = 0; i < n; ++i) launch<MODE>(blocks, out, reps);
     hipEventRecord(e1);
     hipDeviceSynchronize();
     const double t1 = now();
@@ -96,6 +126,7 @@ int main(int argc, char** argv) {
     const double sec = argc > 2 ? atof(argv[2]) : 4.0;
     if (mode == 0) run<0>(sec);
     else if (mode == 1) run<1>(sec);
-    else run<2>(sec);
+    else if (mode == 2) run<2>(sec);
+    else run<3>(sec);
     return 0;
 }
