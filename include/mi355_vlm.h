@@ -420,9 +420,11 @@ int mi355_gemv_bf16_pro(int M, int64_t N, int K, const void* x, int64_t ldx, int
 /* One query row per (batch, head) against `len` cached keys / values (qwen3_attention.py:117-146 with a KV cache and q_seq_len 1):
  * q, o bf16 [B, Hq*D]; caches bf16 token-major, sequence b at k_cache + b*batch_stride, key j at + j*ld, kv head g at + g*D.
  * key_mask uint8 [B, >= len] row pitch ldm (1 = real token) or NULL; masked keys take the reference's finite fill. D in {64,128,256}.
- * len_dev != NULL: the number of valid keys is min(len, *len_dev) read on the device (hipGraph replay), len is then the capacity bound. */
+ * len_dev != NULL: the number of valid keys is min(len, *len_dev) read on the device (hipGraph replay), len is then the capacity bound.
+ * splits > 1 (long caches: one workgroup streams about 256 keys per memory round trip): the keys of a (sequence, head) are dealt to `splits`
+ * workgroups, whose partial results (workspace: B * Hq * splits * (D + 2) floats) a second launch folds in split order. */
 int mi355_attn_decode(int B, int Hq, int Hkv, int D, const void* q, const void* k_cache, const void* v_cache, int64_t batch_stride, int64_t ld,
-                      int len, const int32_t* len_dev, const uint8_t* key_mask, int64_t ldm, void* o, float scale, void* stream);
+                      int len, const int32_t* len_dev, const uint8_t* key_mask, int64_t ldm, void* o, float scale, int splits, float* workspace, void* stream);
 /* mi355_attn_decode started from the fused QKV stream's raw rows qkv bf16 [B, (Hq + 2 Hkv) * D] of ONE new token per sequence
  * (GroupedQueryAttention.forward with a KV cache, qwen3_attention.py:100-146): QK-RMSNorm + RoPE of each head's query and of its kv head's
  * new key inside the launch (arithmetic of mi355_qknorm_rope_fwd), the new key and value heads written to cache row *write_pos, attention
@@ -430,7 +432,8 @@ int mi355_attn_decode(int B, int Hq, int Hkv, int D, const void* q, const void* 
  * pos int32 [B] rotary positions; write_pos, len_dev int32 [1] on the device. D in {64,128}. */
 int mi355_attn_decode_qkv(int B, int Hq, int Hkv, int D, const void* qkv, int64_t ldqkv, const void* q_norm_w, const void* k_norm_w, const float* cos,
                           const float* sin, const int32_t* pos, void* k_cache, void* v_cache, int64_t batch_stride, int64_t ld, int capacity,
-                          const int32_t* write_pos, const int32_t* len_dev, const uint8_t* key_mask, int64_t ldm, void* o, float scale, float eps, void* stream);
+                          const int32_t* write_pos, const int32_t* len_dev, const uint8_t* key_mask, int64_t ldm, void* o, float scale, float eps, int splits,
+                          float* workspace, void* stream);
 /* The tail of a greedy step under hipGraph replay: tok[b] = next_ids[b], rope_pos[b] += 1, *write_pos += 1, *length += 1 (generate.py:139-148's
  * bookkeeping, kept on the device). */
 int mi355_decode_advance(int B, const int64_t* next_ids, int64_t* tok, int32_t* rope_pos, int32_t* write_pos, int32_t* length, void* stream);

@@ -93,9 +93,9 @@ SIGNATURES = {
     # KV-cache decoding (csrc/decode.hip)
     "mi355_gemv_bf16": [_I, _L, _I, _P, _L, _P, _L, _P, _L, _P, _L, _P],
     "mi355_gemv_bf16_pro": [_I, _L, _I, _P, _L, _I, _P, _F, _P, _L, _P, _L, _P, _L, _P],
-    "mi355_attn_decode_qkv": [_I, _I, _I, _I, _P, _L, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P, _P, _P, _L, _P, _F, _F, _P],
+    "mi355_attn_decode_qkv": [_I, _I, _I, _I, _P, _L, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P, _P, _P, _L, _P, _F, _F, _I, _P, _P],
     "mi355_decode_advance": [_I, _P, _P, _P, _P, _P, _P],
-    "mi355_attn_decode": [_I, _I, _I, _I, _P, _P, _P, _L, _L, _I, _P, _P, _L, _P, _F, _P],
+    "mi355_attn_decode": [_I, _I, _I, _I, _P, _P, _P, _L, _L, _I, _P, _P, _L, _P, _F, _I, _P, _P],
     "mi355_kv_append": [_I, _I, _P, _L, _P, _L, _P, _P, _L, _L, _I, _P, _P],
     "mi355_argmax_rows": [_L, _L, _P, _L, _P, _P, _P],
     # measurement aid (csrc/probe.hip)

@@ -190,7 +190,7 @@ struct HeadOperands {
 template <int D, int WAVES, bool POST>
 __global__ __launch_bounds__(64 * WAVES) void attn_decode_kernel(int Hq, int Hkv, const bf16_t* __restrict__ q, const bf16_t* kc, const bf16_t* vc, int64_t batch_stride,
                                                                  int64_t ld, int len, const int32_t* __restrict__ len_dev, const uint8_t* __restrict__ key_mask, int64_t ldm,
-                                                                 bf16_t* __restrict__ o, float scale_log2, QkvPost post) {
+                                                                 bf16_t* __restrict__ o, float scale_log2, QkvPost post, float* __restrict__ ws) {
     // One mapping for both products: lane = (key group kg, 16-byte feature chunk ch); a load instruction covers KG whole key rows, coalesced.  Scores: 8 features per lane,
     // folded over the CH lanes of a key by a butterfly, so every lane of a key group holds the scores of its NT keys and the probabilities never leave registers.
     // A one-token step is a chain of memory round trips, so the chain is kept at two: (1) the device-side length / positions, (2) EVERYTHING else at once -- the wave's
@@ -198,13 +198,17 @@ __global__ __launch_bounds__(64 * WAVES) void attn_decode_kernel(int Hq, int Hkv
     // come back from memory (POST: they are used from LDS, the cache row is written for the later steps only).
     constexpr int CH = D / 8, KG = 64 / CH;
     constexpr int NT = CH < 8 ? CH : 8;    // keys per lane and chunk: 2 x NT 16-byte rows in flight per lane
-    constexpr int CK = NT * KG;           // keys per chunk; chunk c belongs to wave c % WAVES
+    constexpr int CK = NT * KG;           // keys per chunk; chunk c belongs to split c % S (blockIdx.z of S = gridDim.z), there to wave (c / S) % WAVES
+    // S > 1 (long caches; a workgroup streams ~ 256 keys per memory round trip): every split leaves its un-normalised context, maximum and sum in `ws`
+    // ([B, Hq, S, D + 2] floats), attn_decode_combine_kernel folds them in split order.
     __shared__ float qs[D];
     __shared__ float ksn[POST ? D : 1], vsn[POST ? D : 1];
     __shared__ float part[WAVES][D + 2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kg = lane / CH, ch = lane % CH;
     const int h = blockIdx.x, b = blockIdx.y, hk = h / (Hq / Hkv);
+    const int S = gridDim.z, sp = blockIdx.z;
+    const int c0 = sp + S * wave, cstep = S * WAVES;
     if (len_dev) len = min(len, *len_dev);  // graph replay: the current length lives on the device, `len` is the capacity bound
     int wp = -1;                            // POST: the cache row of the new token (its key / value are taken from LDS)
     int64_t p = 0;
@@ -241,8 +245,8 @@ __global__ __launch_bounds__(64 * WAVES) void attn_decode_kernel(int Hq, int Hkv
         if (wave == 0) hop.load<D>(row + (int64_t)h * D, post.qw, post.cosT, post.sinT, p, lane);
         else if (wave == 1) hop.load<D>(row + (int64_t)(Hq + hk) * D, post.kw, post.cosT, post.sinT, p, lane);
         else if (wave == 2 && lane < D / 8) vnew = *reinterpret_cast<const u32x4*>(row + (int64_t)(Hq + Hkv + hk) * D + lane * 8);
-        request_k(wave * CK);
-        request_v(wave * CK);
+        request_k(c0 * CK);
+        request_v(c0 * CK);
         if (wave == 0) {
             float y1[8], y2[8];
             hop.finish<D>(post.eps, y1, y2);
@@ -273,8 +277,8 @@ __global__ __launch_bounds__(64 * WAVES) void attn_decode_kernel(int Hq, int Hkv
         }
     } else {
         for (int i = threadIdx.x; i < D; i += 64 * WAVES) qs[i] = bf2f(q[((int64_t)b * Hq + h) * D + i]);
-        request_k(wave * CK);
-        request_v(wave * CK);
+        request_k(c0 * CK);
+        request_v(c0 * CK);
     }
     __syncthreads();
     const uint8_t* km = key_mask ? key_mask + b * ldm : nullptr;
@@ -284,8 +288,8 @@ __global__ __launch_bounds__(64 * WAVES) void attn_decode_kernel(int Hq, int Hkv
     float m = -__builtin_huge_valf(), l = 0.f, acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    for (int base = wave * CK; base < len; base += WAVES * CK) {
-        const int nb = base + WAVES * CK;
+    for (int base = c0 * CK; base < len; base += cstep * CK) {
+        const int nb = base + cstep * CK;
         float sc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -364,8 +368,30 @@ __global__ __launch_bounds__(64 * WAVES) void attn_decode_kernel(int Hq, int Hkv
             lg += part[w][D + 1] * f;
             out += part[w][i] * f;
         }
-        o[((int64_t)b * Hq + h) * D + i] = f2bf(out / lg);
+        if (S == 1) {
+            o[((int64_t)b * Hq + h) * D + i] = f2bf(out / lg);
+        } else {
+            float* dst = ws + (((int64_t)b * Hq + h) * S + sp) * (D + 2);
+            dst[i] = out;
+            if (i == 0) { dst[D] = mg; dst[D + 1] = lg; }
+        }
     }
+}
+
+// The splits of one (sequence, head) folded in split order: grid (Hq, B), D threads.
+__global__ void attn_decode_combine_kernel(int Hq, int D, int S, const float* __restrict__ ws, bf16_t* __restrict__ o) {
+    const int h = blockIdx.x, b = blockIdx.y, i = threadIdx.x;
+    const float* src = ws + ((int64_t)b * Hq + h) * S * (D + 2);
+    float mg = -__builtin_huge_valf();
+    for (int s = 0; s < S; ++s) mg = fmaxf(mg, src[s * (D + 2) + D]);
+    float lg = 0.f, out = 0.f;
+    for (int s = 0; s < S; ++s) {
+        const float ms = src[s * (D + 2) + D];
+        const float f = ms == -__builtin_huge_valf() ? 0.f : exp2f(ms - mg);  // a split without keys
+        lg += src[s * (D + 2) + D + 1] * f;
+        out += src[s * (D + 2) + i] * f;
+    }
+    o[((int64_t)b * Hq + h) * D + i] = f2bf(out / lg);
 }
 
 // The tail of a greedy step: the chosen ids become the next input ids, every counter of the device-side bookkeeping moves on by one (one launch instead of four).
@@ -482,40 +508,45 @@ extern "C" int mi355_kv_append(int B, int width, const void* k_rows, int64_t ldk
 }
 
 static int attn_decode_launch(const char* who, int B, int Hq, int Hkv, int D, const void* q, const void* k_cache, const void* v_cache, int64_t batch_stride, int64_t ld, int len,
-                              const int32_t* len_dev, const uint8_t* key_mask, int64_t ldm, void* o, float scale, const QkvPost* post, void* stream) {
+                              const int32_t* len_dev, const uint8_t* key_mask, int64_t ldm, void* o, float scale, const QkvPost* post, int splits, float* workspace,
+                              void* stream) {
     MI355_REQUIRE(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && len > 0, "%s: bad sizes", who);
     MI355_REQUIRE(k_cache && v_cache && o && ld >= (int64_t)Hkv * D && ld % 8 == 0 && batch_stride >= (int64_t)len * ld, "%s: cache pitch / stride too small", who);
     MI355_REQUIRE(!key_mask || ldm >= len, "%s: key mask pitch smaller than the cache length", who);
     MI355_REQUIRE(B <= 65535, "%s: grid limits", who);
-    dim3 grid(Hq, B);
+    MI355_REQUIRE(splits >= 1 && splits <= 64 && (splits == 1 || workspace), "%s: 1..64 splits, and a workspace of B * Hq * splits * (D + 2) floats for more than one", who);
+    dim3 grid(Hq, B, splits);
     const QkvPost none = {};
-#define LAUNCH(DD, WV, PP) attn_decode_kernel<DD, WV, PP><<<grid, 64 * WV, 0, ST(stream)>>>(Hq, Hkv, (const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)v_cache, batch_stride, ld, len, len_dev, key_mask, ldm, (bf16_t*)o, scale * LOG2E, PP ? *post : none)
+#define LAUNCH(DD, WV, PP) attn_decode_kernel<DD, WV, PP><<<grid, 64 * WV, 0, ST(stream)>>>(Hq, Hkv, (const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)v_cache, batch_stride, ld, len, len_dev, key_mask, ldm, (bf16_t*)o, scale * LOG2E, PP ? *post : none, workspace)
     if (post) {
         if (D == 64) LAUNCH(64, 8, true); else LAUNCH(128, 8, true);
     } else {
         if (D == 32) LAUNCH(32, 8, false); else if (D == 64) LAUNCH(64, 8, false); else if (D == 128) LAUNCH(128, 8, false); else LAUNCH(256, 8, false);
     }
 #undef LAUNCH
+    if (splits > 1) attn_decode_combine_kernel<<<dim3(Hq, B), D, 0, ST(stream)>>>(Hq, D, splits, workspace, (bf16_t*)o);
     return 0;
 }
 
 extern "C" int mi355_attn_decode(int B, int Hq, int Hkv, int D, const void* q, const void* k_cache, const void* v_cache, int64_t batch_stride,
-                                 int64_t ld, int len, const int32_t* len_dev, const uint8_t* key_mask, int64_t ldm, void* o, float scale, void* stream) {
+                                 int64_t ld, int len, const int32_t* len_dev, const uint8_t* key_mask, int64_t ldm, void* o, float scale, int splits, float* workspace,
+                                 void* stream) {
     MI355_REQUIRE(D == 32 || D == 64 || D == 128 || D == 256, "attn_decode: head_dim %d not built (32, 64, 128, 256)", D);
     MI355_REQUIRE(q != nullptr, "attn_decode: null query");
-    if (int rc = attn_decode_launch("attn_decode", B, Hq, Hkv, D, q, k_cache, v_cache, batch_stride, ld, len, len_dev, key_mask, ldm, o, scale, nullptr, stream)) return rc;
+    if (int rc = attn_decode_launch("attn_decode", B, Hq, Hkv, D, q, k_cache, v_cache, batch_stride, ld, len, len_dev, key_mask, ldm, o, scale, nullptr, splits, workspace, stream)) return rc;
     MI355_LAUNCH_CHECK("attn_decode");
     return 0;
 }
 
 extern "C" int mi355_attn_decode_qkv(int B, int Hq, int Hkv, int D, const void* qkv, int64_t ldqkv, const void* q_norm_w, const void* k_norm_w, const float* cos,
                                      const float* sin, const int32_t* pos, void* k_cache, void* v_cache, int64_t batch_stride, int64_t ld, int capacity,
-                                     const int32_t* write_pos, const int32_t* len_dev, const uint8_t* key_mask, int64_t ldm, void* o, float scale, float eps, void* stream) {
+                                     const int32_t* write_pos, const int32_t* len_dev, const uint8_t* key_mask, int64_t ldm, void* o, float scale, float eps, int splits,
+                                     float* workspace, void* stream) {
     MI355_REQUIRE(D == 128 || D == 64, "attn_decode_qkv: head_dim must be 64 or 128 (got %d)", D);
     MI355_REQUIRE(Hq > 0 && Hkv > 0 && ldqkv >= (int64_t)(Hq + 2 * Hkv) * D && ldqkv % 8 == 0, "attn_decode_qkv: the qkv row holds (Hq + 2 Hkv) * D elements, pitch a multiple of 8");
     MI355_REQUIRE(qkv && q_norm_w && k_norm_w && cos && sin && pos && write_pos && len_dev, "attn_decode_qkv: null pointer (the write position and the length live on the device)");
     const QkvPost post = {(const bf16_t*)qkv, ldqkv, (const bf16_t*)q_norm_w, (const bf16_t*)k_norm_w, cos, sin, pos, write_pos, capacity, eps};
-    if (int rc = attn_decode_launch("attn_decode_qkv", B, Hq, Hkv, D, nullptr, k_cache, v_cache, batch_stride, ld, capacity, len_dev, key_mask, ldm, o, scale, &post, stream)) return rc;
+    if (int rc = attn_decode_launch("attn_decode_qkv", B, Hq, Hkv, D, nullptr, k_cache, v_cache, batch_stride, ld, capacity, len_dev, key_mask, ldm, o, scale, &post, splits, workspace, stream)) return rc;
     MI355_LAUNCH_CHECK("attn_decode_qkv");
     return 0;
 }

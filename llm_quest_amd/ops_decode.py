@@ -53,7 +53,19 @@ def fused_rows(M, Kd):
     return M <= 8 and M * Kd * 2 <= 65536
 
 
-def attn_decode_qkv(qkv, qw, kw, cos, sin, pos, Hq, Hkv, D, kc, vc, write_pos_dev, len_dev, key_mask=None, scale=None, eps=1e-6):
+def decode_splits(n_keys, B, Hq):
+    """Workgroups per (sequence, head) of the decode attention: one streams about 256 keys per memory round trip (3.4 us), so longer caches are dealt to several -- their
+    partial results cost a second, tiny launch (measured at batch 1: 1 868 keys 1.65 -> 1.13 ms per token) -- as many as keep the chip's 256 CUs busy once."""
+    if n_keys <= 320:
+        return 1
+    return max(1, min((n_keys + 255) // 256, 16, max(1, 256 // (B * Hq))))
+
+
+def _split_ws(splits, B, Hq, D, device):
+    return torch.empty(B * Hq * splits * (D + 2), dtype=torch.float32, device=device) if splits > 1 else None
+
+
+def attn_decode_qkv(qkv, qw, kw, cos, sin, pos, Hq, Hkv, D, kc, vc, write_pos_dev, len_dev, key_mask=None, scale=None, eps=1e-6, splits=1):
     """One new token per sequence from the fused QKV stream's raw rows to the attention context (``mi355_attn_decode_qkv``): QK-norm + RoPE of the query and the new key
     inside the launch, key and value heads written into cache row ``*write_pos_dev``, attention over ``*len_dev`` keys -- ``qknorm_rope_fwd`` + ``kv_append_dev`` +
     ``attn_decode`` in one launch, bit-identical."""
@@ -68,8 +80,9 @@ def attn_decode_qkv(qkv, qw, kw, cos, sin, pos, Hq, Hkv, D, kc, vc, write_pos_de
             raise ValueError("attn_decode_qkv: key_mask uint8 [B, >= capacity]")
         ldm = key_mask.stride(0)
     o = torch.empty((B, Hq * D), dtype=BF16, device=qkv.device)
+    ws = _split_ws(splits, B, Hq, D, qkv.device)
     L.call("mi355_attn_decode_qkv", B, Hq, Hkv, D, L.ptr(qkv), qkv.stride(0), L.ptr(qw), L.ptr(kw), L.ptr(cos), L.ptr(sin), L.ptr(pos), L.ptr(kc), L.ptr(vc), kc.stride(0),
-           kc.stride(1), kc.shape[1], L.ptr(write_pos_dev), L.ptr(len_dev), L.ptr(key_mask), ldm, L.ptr(o), D ** -0.5 if scale is None else scale, eps)
+           kc.stride(1), kc.shape[1], L.ptr(write_pos_dev), L.ptr(len_dev), L.ptr(key_mask), ldm, L.ptr(o), D ** -0.5 if scale is None else scale, eps, splits, L.ptr(ws))
     return o
 
 
@@ -82,7 +95,7 @@ def decode_advance(next_ids, tok, rope_pos, write_pos, length):
     L.call("mi355_decode_advance", B, L.ptr(next_ids), L.ptr(tok), L.ptr(rope_pos), L.ptr(write_pos), L.ptr(length))
 
 
-def attn_decode(q, kc, vc, length, Hq, Hkv, D, key_mask=None, scale=None, len_dev=None):
+def attn_decode(q, kc, vc, length, Hq, Hkv, D, key_mask=None, scale=None, len_dev=None, splits=None):
     """q [B, Hq*D]; kc / vc [B, capacity, Hkv*D]; attends to keys [0, length) -- or [0, min(length, *len_dev)) with the length read
     on the device (graph replay)."""
     L.require_gpu(q, kc, vc, key_mask)
@@ -97,8 +110,11 @@ def attn_decode(q, kc, vc, length, Hq, Hkv, D, key_mask=None, scale=None, len_de
             raise ValueError("attn_decode: key_mask uint8 [B, >= length]")
         ldm = key_mask.stride(0)
     o = torch.empty_like(q)
+    if splits is None:
+        splits = decode_splits(length, B, Hq) if len_dev is None else 1  # with the length on the device the caller knows how long the cache will get
+    ws = _split_ws(splits, B, Hq, D, q.device)
     L.call("mi355_attn_decode", B, Hq, Hkv, D, L.ptr(q), L.ptr(kc), L.ptr(vc), kc.stride(0), kc.stride(1), length, L.ptr(len_dev), L.ptr(key_mask), ldm, L.ptr(o),
-           D ** -0.5 if scale is None else scale)
+           D ** -0.5 if scale is None else scale, splits, L.ptr(ws))
     return o
 
 
@@ -160,14 +176,15 @@ def attention_cached(att, h1, B, S, cos, sin, pos, km, kv_cache, dev_state=None,
     qkv = gemv_pro(h1, wqkv, "rmsnorm", pre_norm) if pre_norm is not None else lin(h1, wqkv)
     if dev_state is not None and D in (64, 128) and (km is None or km.shape[1] >= kv_cache.keys_cache[att.layer_idx].shape[1]):
         # graph replay, one launch from the raw QKV rows to the context: the new key / value go into the cache row at the device-side position
-        _, write_pos, len_dev = dev_state
+        write_pos, len_dev = dev_state[1], dev_state[2]
+        splits = dev_state[3] if len(dev_state) > 3 else 1
         kc, vc = kv_cache.keys_cache[att.layer_idx], kv_cache.values_cache[att.layer_idx]
-        ctx = attn_decode_qkv(qkv, att.q_norm.weight, att.k_norm.weight, cos, sin, pos, Hq, Hkv, D, kc, vc, write_pos, len_dev, key_mask=km, scale=att.att_scaling)
+        ctx = attn_decode_qkv(qkv, att.q_norm.weight, att.k_norm.weight, cos, sin, pos, Hq, Hkv, D, kc, vc, write_pos, len_dev, key_mask=km, scale=att.att_scaling, splits=splits)
         return lin(ctx, att.out_proj.weight, residual=residual)
     q, k, _ = K.qknorm_rope_fwd(qkv, att.q_norm.weight, att.k_norm.weight, cos, sin, pos, Hq, Hkv, D)
     v = qkv[:, (Hq + Hkv) * D :]
     if dev_state is not None:  # graph replay: position and length are read on the device, the cache object is advanced by the caller
-        _, write_pos, len_dev = dev_state
+        write_pos, len_dev = dev_state[1], dev_state[2]
         kc, vc = kv_cache.keys_cache[att.layer_idx], kv_cache.values_cache[att.layer_idx]
         kv_append_dev(k, v, kc, vc, write_pos)
         ctx = attn_decode(q, kc, vc, kc.shape[1], Hq, Hkv, D, key_mask=km, scale=att.att_scaling, len_dev=len_dev)
@@ -223,7 +240,7 @@ def qwen3_forward_cached(model, x, kv_cache, attn_mask=None, position_ids=None, 
     if dev_state is not None:
         if not decode:
             raise ValueError("device-side bookkeeping applies to one-token decode steps only")
-        pos, write_pos, len_dev = dev_state
+        pos, write_pos, len_dev = dev_state[:3]
     elif position_ids is not None:
         pos = position_ids.to(device=h.device, dtype=torch.int32).expand(B, S).reshape(-1).contiguous()
     else:
@@ -265,10 +282,11 @@ class GraphDecoder:
         self.rope_pos = torch.full((B,), start, dtype=torch.int32, device=dev)
         self.write_pos = torch.tensor([start], dtype=torch.int32, device=dev)
         self.length = torch.tensor([start + 1], dtype=torch.int32, device=dev)
+        self.splits = decode_splits(need, B, model.trf_blocks[0].att.num_heads)  # fixed for the captured graph: sized for the longest cache it will see
         self.graph = None
 
     def _step(self):
-        logits = qwen3_forward_cached(self.model, self.tok, self.kv, dev_state=(self.rope_pos, self.write_pos, self.length))
+        logits = qwen3_forward_cached(self.model, self.tok, self.kv, dev_state=(self.rope_pos, self.write_pos, self.length, self.splits))
         nxt = argmax_rows(logits.view(logits.shape[0], -1))
         decode_advance(nxt, self.tok, self.rope_pos, self.write_pos, self.length)
 
