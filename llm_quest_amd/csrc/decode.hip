@@ -76,38 +76,75 @@ __global__ __launch_bounds__(256) void gemv_pro_kernel(int M, int64_t N, int K, 
     const int nvec = K >> 3;
     if constexpr (PRO == 1) {
         __shared__ float rs[8];
-        for (int m = wave; m < M; m += 4) {  // the row kernel's sum, in its order: one wave per row
-            const bf16_t* xr = x + m * ldx;
-            float ss = 0.f;
+        {  // the row kernel's sum, in its order: one wave per row, rows wave and wave + 4 side by side
+            const int m0 = wave, m1 = wave + 4;
+            float ss0 = 0.f, ss1 = 0.f;
             for (int i = lane; i < nvec; i += 64) {
-                float v[8];
-                unpack8(*reinterpret_cast<const u32x4*>(xr + i * 8), v);
+                float v0[8], v1[8];
+                const u32x4 r0 = m0 < M ? *reinterpret_cast<const u32x4*>(x + m0 * ldx + i * 8) : (u32x4){0u, 0u, 0u, 0u};
+                const u32x4 r1 = m1 < M ? *reinterpret_cast<const u32x4*>(x + m1 * ldx + i * 8) : (u32x4){0u, 0u, 0u, 0u};
+                unpack8(r0, v0);
+                unpack8(r1, v1);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
+                for (int e = 0; e < 8; ++e) { ss0 += v0[e] * v0[e]; ss1 += v1[e] * v1[e]; }
             }
-            ss = wave_sum(ss);
-            if (lane == 0) rs[m] = rsqrtf(ss / (float)K + eps);
+            ss0 = wave_sum(ss0);
+            ss1 = wave_sum(ss1);
+            if (lane == 0 && m0 < M) rs[m0] = rsqrtf(ss0 / (float)K + eps);
+            if (lane == 0 && m1 < M) rs[m1] = rsqrtf(ss1 / (float)K + eps);
         }
         __syncthreads();
-        for (int idx = threadIdx.x; idx < M * nvec; idx += 256) {  // every thread a vector of some row
-            const int m = idx / nvec, i = idx - m * nvec;
-            const float r = rs[m];
-            float v[8], wv[8], o[8];
-            unpack8(*reinterpret_cast<const u32x4*>(x + m * ldx + i * 8), v);
-            unpack8(*reinterpret_cast<const u32x4*>(nw + i * 8), wv);
+        for (int idx0 = threadIdx.x; idx0 < M * nvec; idx0 += 1024) {  // every thread a vector of some row; four requested together (eight rows: a chain of four round trips otherwise)
+            u32x4 xv[4], nv[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = v[e] * r * wv[e];
-            *reinterpret_cast<u32x4*>(xs + m * K + i * 8) = pack8(o);
+            for (int u = 0; u < 4; ++u) {
+                const int idx = idx0 + u * 256;
+                if (idx < M * nvec) {
+                    const int m = idx / nvec, i = idx - m * nvec;
+                    xv[u] = *reinterpret_cast<const u32x4*>(x + m * ldx + i * 8);
+                    nv[u] = *reinterpret_cast<const u32x4*>(nw + i * 8);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = idx0 + u * 256;
+                if (idx < M * nvec) {
+                    const int m = idx / nvec, i = idx - m * nvec;
+                    const float r = rs[m];
+                    float v[8], wv[8], o[8];
+                    unpack8(xv[u], v);
+                    unpack8(nv[u], wv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = v[e] * r * wv[e];
+                    *reinterpret_cast<u32x4*>(xs + m * K + i * 8) = pack8(o);
+                }
+            }
         }
     } else {
-        for (int idx = threadIdx.x; idx < M * nvec; idx += 256) {
-            const int m = idx / nvec, i = idx - m * nvec;
-            float u[8], g[8], o[8];
-            unpack8(*reinterpret_cast<const u32x4*>(x + m * ldx + i * 8), u);
-            unpack8(*reinterpret_cast<const u32x4*>(x + m * ldx + K + i * 8), g);
+        for (int idx0 = threadIdx.x; idx0 < M * nvec; idx0 += 1024) {
+            u32x4 uv[4], gv[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = swiglu_act(u[e], g[e]);
-            *reinterpret_cast<u32x4*>(xs + m * K + i * 8) = pack8(o);
+            for (int u = 0; u < 4; ++u) {
+                const int idx = idx0 + u * 256;
+                if (idx < M * nvec) {
+                    const int m = idx / nvec, i = idx - m * nvec;
+                    uv[u] = *reinterpret_cast<const u32x4*>(x + m * ldx + i * 8);
+                    gv[u] = *reinterpret_cast<const u32x4*>(x + m * ldx + K + i * 8);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = idx0 + u * 256;
+                if (idx < M * nvec) {
+                    const int m = idx / nvec, i = idx - m * nvec;
+                    float uf[8], g[8], o[8];
+                    unpack8(uv[u], uf);
+                    unpack8(gv[u], g);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = swiglu_act(uf[e], g[e]);
+                    *reinterpret_cast<u32x4*>(xs + m * K + i * 8) = pack8(o);
+                }
+            }
         }
     }
     __syncthreads();
