@@ -55,3 +55,18 @@ def test_every_extension_is_still_needed():
         sig = ours[module][name]
         for e in extra:
             assert e in sig, (module, name, e)
+
+
+def test_global_buffers_are_keyed_by_the_device_they_are_built_on():
+    """The table cache must not hand a model built under ``with torch.device(...)`` the tables of a model built on another device (the reference's cache would)."""
+    import torch
+
+    from llm_quest_amd.common.buffers import GlobalBuffers
+
+    cpu_cos, _ = GlobalBuffers.get_rope_params(48, 10_000, 16)
+    with torch.device("meta"):
+        meta_cos, _ = GlobalBuffers.get_rope_params(48, 10_000, 16)
+        meta_mask = GlobalBuffers.get_causal_mask(48)
+    again, _ = GlobalBuffers.get_rope_params(48, 10_000, 16)
+    assert cpu_cos.device.type == "cpu" and meta_cos.device.type == "meta" and meta_mask.device.type == "meta"
+    assert again is cpu_cos and GlobalBuffers.get_causal_mask(48).device.type == "cpu"
