@@ -32,6 +32,9 @@ namespace {
 #ifndef GEMM_SWAP
 #define GEMM_SWAP 0
 #endif
+#ifndef MI355_GEMM_PP_DEFAULT
+#define MI355_GEMM_PP_DEFAULT 0  // see pp_mask()
+#endif
 #if GEMM_SWAP
 #define MFMA_CT(af, bf, c) (c) = __builtin_amdgcn_mfma_f32_16x16x32_bf16((bf), (af), (c), 0, 0, 0)
 #else
@@ -1525,6 +1528,432 @@ int launch_persist(GemmParams p, hipStream_t s) {
 }
 #endif  // part 2
 
+// ---------------------------------------------------------------------------------------------- ping-pong persistent NT kernel (tile hint 8)
+// gemm_nt_persist_kernel's two waves per SIMD (w and w + 4: the upper and the lower 128 rows of the 256 x 256 tile) reach their write-out together, so the
+// matrix pipe of every SIMD idles for the whole write-out: 2.45 of a tile's 27.5 us with the plain epilogue at K = 1 024, a quarter of the tile with the SwiGLU
+// forms (round 5: 1.26 PF plain, 1.11 / 0.84 PF fused).  VALU / LDS / store issue and the matrix pipe are separate resources of a SIMD; what keeps them from
+// overlapping is only that both waves are in the same phase.  This kernel runs the two wave groups E K-tiles apart:
+//   * time is counted in SLOTS (one K-tile of the stream, one workgroup barrier each).  A group's tile takes NT = K / 64 multiplying slots and E write-out
+//     slots (the write-out cut into E chunks, one per slot); the lower group (waves 4-7) starts E slots late.  So whenever one group writes out, the other
+//     multiplies: the SIMD's matrix pipe belongs to the multiplying wave alone and the write-out's vector / LDS / store instructions issue beside it.
+//   * the stream stays ONE stream: a slot's stage holds the weight panel's K-tile k = slot mod NT (both groups use it), the upper 128 rows of the activation
+//     panel if the upper group multiplies in that slot and the lower 128 rows if the lower group does.  A tile therefore starts at whatever k the stream is
+//     at and wraps around: every output is the sum over all K-tiles in an order ROTATED by a multiple of E, so results equal the per-tile kernel's up to the
+//     fp32 summation order (bit-identical whenever the products are exact; tests/test_kernels_gpu.py), and are the same bits on every run.
+//   * requests: every wave asks for its own four pieces of the weight panel and, for slots in which its group multiplies, its own four pieces of the activation
+//     panel; waves 0-3 right behind the barrier that frees the stage, waves 4-7 half a slot later (the CU has one address unit: see gemm_nt_persist_kernel).
+// NT form, bf16 output, K % 64 == 0, K / 64 >= E, N % 8 == 0, no bias.
+#if GEMM_PART == 6 || !defined(GEMM_PART)
+template <int KIND, bool RES>
+__global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmParams p, int ntiles) {
+    using T = Cfg256;
+    constexpr int BK = 64, HM = T::FM / 2;
+    constexpr int E = KIND == MI355_EPI_ATTN_DELTA ? 5 : 4;  // write-out slots: one 32-row sub-block each (+ the row constants' combine)
+    static_assert(T::A_PPW == 4 && T::B_PPW == 4 && T::FM == 8 && T::FN == 4 && T::NS == 2, "written for 8 waves of 128x64 on two 64-KiB stages");
+    __shared__ __attribute__((aligned(16))) char smem[2 * T::STAGE + 32768];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool grpY = wave >= 4;
+    char* const stg = smem + 2 * T::STAGE + wave * 4096;
+    const int wr0 = (wave / T::WN) * T::WTM, wc0 = (wave % T::WN) * T::WTN;
+    const int NT = (int)(p.K / BK), P = NT + E;
+    // ---- the walk: weight-stationary per XCD.  The column panels are taken four at a time (a column group); an XCD owns a contiguous run of (column group, row
+    // panel) pairs; its 32 workgroups are 4 column panels x 8 row streams, stream r taking the run's pairs r, r + 8, ...  In a slot the XCD's workgroups therefore
+    // ask for 4 weight K-tiles and 8 activation K-tiles between them (the slot number is the same K-tile for all of them), and at K = 1 024 the four weight panels
+    // (2 MB) stay in the 4-MB L2 for the whole run: only the activation panels stream.  blockIdx.x & 7 names the XCD under round-robin dispatch (speed only).
+    const int nsr = p.tiles_m, ncp = p.tiles_n, ncg = (ncp + 3) >> 2;
+    const int xcd = blockIdx.x & 7, wlx = blockIdx.x >> 3, ci = wlx & 3;
+    const int64_t pairs = (int64_t)ncg * nsr;
+    const int lo = (int)(pairs * xcd / 8) + (wlx >> 2), hi = (int)(pairs * (xcd + 1) / 8);
+    struct Walk {
+        int p, sr, cg;
+    };
+    auto settle = [&](Walk& w) {  // skip pairs whose column group has no panel for this workgroup's column
+        while (w.p < hi && w.cg * 4 + ci >= ncp) {
+            w.p += 8;
+            w.sr += 8;
+            while (w.sr >= nsr) w.sr -= nsr, ++w.cg;
+        }
+    };
+    auto walk_init = [&](Walk& w) {
+        w.p = lo;
+        w.cg = lo / nsr;
+        w.sr = lo - w.cg * nsr;
+        settle(w);
+    };
+    auto walk_next = [&](Walk& w) {
+        w.p += 8;
+        w.sr += 8;
+        while (w.sr >= nsr) w.sr -= nsr, ++w.cg;
+        settle(w);
+    };
+    int J = 0;  // tiles of this workgroup
+    {
+        Walk w;
+        for (walk_init(w); w.p < hi; walk_next(w)) ++J;
+    }
+    if (J == 0) return;
+    auto tile_m0 = [&](const Walk& w) { return (int64_t)w.sr * T::BM; };
+    auto tile_n0 = [&](const Walk& w) { return (int64_t)(w.cg * 4 + ci) * T::BN; };
+
+    // ---- the request side, divided by OPERAND as in gemm_nt_persist_kernel: waves 0-3 ask for the activation panel (both halves: it comes from HBM, so early, right
+    // behind the barrier that frees the stage), waves 4-7 for the weight panel (L2) half a slot later.  A wave therefore follows two streams of four pieces each:
+    //   waves 0-3: stream 1 = rows 32 w .. + 31 of the upper group's tile (on the upper group's clock), stream 2 = the same rows of the lower half (lower group's clock: E behind);
+    //   waves 4-7: streams 1 / 2 = weight-panel rows 64 (w - 4) .. + 31 / + 32 .. + 63, both on the upper group's clock (the weight stream follows the upper group's tile
+    //              index: while the upper group writes out, the lower one is still on that tile).
+    // rstage / rkt = stage and K-tile of the slot the next call asks for; ph / tj = that slot's phase and tile on the stream's clock.  Per-lane piece offsets do not
+    // depend on the tile (rows r0 + 8 j + lane / 8, 16-byte chunk swizzled by the row): a tile contributes a scalar base and a scalar row limit.
+    // (Tried: the multiplying group asking for everything while the other one writes out, so that no request sits behind a chunk's stores in a wave's in-order
+    // vmcnt -- slower: the main loop pays for the extra scalar state, and the stores cost the same.)
+    unsigned voff1[4], voff2[4];
+    const int lr = lane >> 3;
+    const int wl = wave & 3;
+    {
+        int unused[4];
+        if (!grpY) {
+            piece_offsets<false, T::BM, BK, 4>(wl, lane, p.lda, 1 << 30, voff1, unused);
+            piece_offsets<false, T::BM, BK, 4>(wl + 4, lane, p.lda, 1 << 30, voff2, unused);
+        } else if constexpr (KIND == MI355_EPI_SWIGLU_FWD) {
+            // every 64 output columns of the tile are [32 lin1 rows | the 32 lin_gate rows of the SAME hidden units] of the fused weight (see gemm_tile): the tile's
+            // row r is weight row ((r >> 5) & 1) N/2 + n0 / 2 + (r >> 6) 32 + (r & 31); this wave's rows are 64 wl + 8 j + lr: stream 1 = lin1, stream 2 = lin_gate
+            const int64_t nh = p.N >> 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = wl * 64 + j * 8 + lr;
+                voff1[j] = (unsigned)((wl * 32 + j * 8 + lr) * p.ldb * 2 + swz_rowk<BK>(lane & 7, r) * 16);
+                voff2[j] = (unsigned)((nh + wl * 32 + j * 8 + lr) * p.ldb * 2 + swz_rowk<BK>(lane & 7, r + 32) * 16);
+            }
+        } else {
+            piece_offsets<false, T::BN, BK, 4>(2 * wl, lane, p.ldb, 1 << 30, voff1, unused);
+            piece_offsets<false, T::BN, BK, 4>(2 * wl + 1, lane, p.ldb, 1 << 30, voff2, unused);
+        }
+    }
+    const bf16_t *base1 = p.A, *base2 = p.A;
+    int lim1 = 0, lim2 = 0;  // rows of the stream's panel inside the matrix, minus the stream's first row: piece j is inside iff lr < lim - 8 j
+    Walk w1, w2, wC;
+    auto plan1 = [&]() {
+        if (!grpY) {
+            const int64_t m0 = tile_m0(w1);
+            base1 = uniform_ptr(p.A + m0 * p.lda);
+            lim1 = (int)min((int64_t)T::BM, p.M - m0) - wl * 32;
+        } else {
+            const int64_t n0 = tile_n0(w1);
+            if constexpr (KIND == MI355_EPI_SWIGLU_FWD) {
+                base1 = uniform_ptr(p.B + (n0 >> 1) * p.ldb);
+                lim1 = lim2 = (int)min((int64_t)32, (p.N >> 1) - (n0 >> 1) - wl * 32);  // hidden units n0 / 2 + 32 wl + 8 j + lr of either half
+            } else {
+                base1 = uniform_ptr(p.B + n0 * p.ldb);
+                lim1 = (int)min((int64_t)T::BN, p.N - n0) - wl * 64;
+                lim2 = lim1 - 32;
+            }
+            base2 = base1;
+        }
+    };
+    auto plan2 = [&]() {  // (waves 0-3 only)
+        const int64_t m0 = tile_m0(w2);
+        base2 = uniform_ptr(p.A + m0 * p.lda);
+        lim2 = (int)min((int64_t)T::BM, p.M - m0) - 128 - wl * 32;
+    };
+    int rstage = 0, rkt = 0, ph1 = 0, tj1 = 0, ph2 = -E, tj2 = 0;
+    auto request = [&]() __attribute__((always_inline)) {
+        char* st = smem + rstage * T::STAGE;
+        const int64_t kofs = (int64_t)rkt * BK;
+        if (!grpY) {
+            if (ph1 < NT && tj1 < J) {  // the upper group multiplies in that slot
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dma_piece(base1 + kofs, lr < lim1 - 8 * j ? voff1[j] : OOB, st + (wl * 4 + j) * 1024);
+            }
+            if (ph2 >= 0 && ph2 < NT && tj2 < J) {  // the lower group does
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dma_piece(base2 + kofs, lr < lim2 - 8 * j ? voff2[j] : OOB, st + (16 + wl * 4 + j) * 1024);
+            }
+            if (++ph2 == P) {
+                ph2 = 0;
+                if (++tj2 < J) {
+                    walk_next(w2);
+                    plan2();
+                }
+            }
+        } else if (tj1 < J) {  // somebody multiplies in that slot
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dma_piece(base1 + kofs, lr < lim1 - 8 * j ? voff1[j] : OOB, st + T::A_BYTES + (wl * 8 + j) * 1024);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dma_piece(base2 + kofs, lr < lim2 - 8 * j ? voff2[j] : OOB, st + T::A_BYTES + (wl * 8 + 4 + j) * 1024);
+        }
+        rstage ^= 1;
+        if (++rkt == NT) rkt = 0;
+        if (++ph1 == P) {
+            ph1 = 0;
+            if (++tj1 < J) {
+                walk_next(w1);
+                plan1();
+            }
+        }
+    };
+
+    // ---- the multiplying side (gemm_nt_persist_kernel's K-tile, unchanged)
+    f32x4 acc[T::FM][T::FN];
+    bf16x8 aE[HM], aO[HM], b0[T::FN], b1[T::FN];
+    auto loadA = [&](bf16x8 (&a)[HM], const char* sA, int kk, int mh) {
+#pragma unroll
+        for (int i = 0; i < HM; ++i) a[i] = frag_rowk<BK>(sA, wr0 + (mh * HM + i) * 16, kk, lane);
+    };
+    auto loadB = [&](bf16x8 (&b)[T::FN], const char* sB, int kk) {
+#pragma unroll
+        for (int j = 0; j < T::FN; ++j) b[j] = frag_rowk<BK>(sB, wc0 + j * 16, kk, lane);
+    };
+    auto mma = [&](bool zero, const bf16x8 (&a)[HM], const bf16x8 (&b)[T::FN], int mh) {
+        if (zero) {  // wave-uniform
+#pragma unroll
+            for (int i = 0; i < HM; ++i)
+#pragma unroll
+                for (int j = 0; j < T::FN; ++j) acc[mh * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < HM; ++i)
+#pragma unroll
+                for (int j = 0; j < T::FN; ++j) acc[mh * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[mh * HM + i][j], 0, 0, 0);
+        }
+    };
+    int cstage = 0;
+    bool started = false;  // a slot has passed (the lower group's requests run one slot behind the upper group's: none in slot 0)
+    // the end of every slot, whatever the wave did in it: own reads and requests complete, everybody's too, the upper group's requests into the stage just left,
+    // and -- if this wave multiplies in the next slot -- that slot's first fragments
+    auto slot_end = [&](bool prefetch, auto keep_c) __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);  // the slot's third MFMA group stays in front of the wait (hipcc otherwise sinks most of it below the barrier, and the requests behind it)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wait_vmcnt<decltype(keep_c)::value>();  // this wave's requests have landed; a write-out chunk's stores (its youngest operations) may stay in flight for another slot
+        __builtin_amdgcn_s_barrier();
+        if (!grpY) request();
+        if (prefetch) {
+            const char* nA = smem + (cstage ^ 1) * T::STAGE;
+            loadB(b0, nA + T::A_BYTES, 0);
+            loadA(aE, nA, 0, 0);
+        }
+        cstage ^= 1;
+        started = true;
+    };
+    auto compute_slot = [&](bool first, bool last) {  // 64 MFMAs in four phases (k-step, row half)
+        const char* sA = smem + cstage * T::STAGE;
+        const char* sB = sA + T::A_BYTES;
+        loadA(aO, sA, 0, 1);
+        mma(first, aE, b0, 0);
+        if (grpY) request();
+        loadB(b1, sB, 1);
+        loadA(aE, sA, 1, 0);
+        mma(first, aO, b0, 1);
+        loadA(aO, sA, 1, 1);
+        mma(false, aE, b1, 0);
+        slot_end(!last, std::integral_constant<int, 0>{});
+        mma(false, aO, b1, 1);
+    };
+
+    // ---- write-out chunk c of this group's tile cj: sub-block c (32 rows x 64 columns per wave) through the wave's own 4 KiB of packed bf16, as in gemm_nt_persist_kernel
+    [[maybe_unused]] float psum[4][4];  // attention delta: this wave's half-head row sums (sub-block, pass)
+    auto epi_chunk = [&](auto sb_c, const int cj) __attribute__((always_inline)) {
+        constexpr int sb = decltype(sb_c)::value;
+        int le = lane;
+        asm volatile("" : "+v"(le));  // derived per chunk, not kept across the main loop
+        const int g = le >> 4, r16 = le & 15;
+        const int wr_off = r16 * 128 + ((((g & 1) ^ (r16 >> 3)) & 1) << 3), wr_x = r16 & 7;
+        const int rd_row = le >> 3, rd_ch = le & 7;
+        const int rd_off = rd_row * 128 + ((rd_ch ^ (rd_row & 7)) << 4);
+        const int64_t m0 = tile_m0(wC), n0 = tile_n0(wC);
+        const int64_t rows_left = p.M - m0 - wr0;
+        const int hi4 = rd_ch >> 2;
+        int64_t cbase, cbase2 = 0;
+        bool col_ok;
+        if constexpr (KIND == MI355_EPI_SWIGLU_FWD) {
+            const int64_t nh = p.N >> 1, hid = (n0 >> 1) + (wc0 >> 6) * 32 + (rd_ch & 3) * 8;
+            col_ok = hid < nh;
+            cbase = (hi4 ? nh : 0) + hid;
+            cbase2 = hid + 4 * hi4;
+        } else {
+            cbase = n0 + wc0 + rd_ch * 8;
+            col_ok = cbase < p.N;
+        }
+        auto rsrc_c = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<bf16_t*>(p.C) + (m0 + wr0) * p.ldc, 0, 0x7fffffff, 0x00020000);
+        auto rsrc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(p.R)) + (m0 + wr0) * p.ldr, 0, 0x7fffffff, 0x00020000);
+        u32x4 rd[4];
+        [[maybe_unused]] u32x2 rres[2][T::FN];
+        [[maybe_unused]] u32x4 uv[4], gv[4];
+        [[maybe_unused]] u32x2 partner[4];
+        if constexpr (RES) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < T::FN; ++j) {
+                    const int row = sb * 32 + ii * 16 + r16;
+                    const int64_t col = n0 + wc0 + j * 16 + 4 * g;
+                    rres[ii][j] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_r, (row < rows_left && col < p.N) ? (unsigned)((row * p.ldr + col) * 2) : OOB, 0, 0));
+                }
+        }
+        if constexpr (KIND == MI355_EPI_SWIGLU_BWD || KIND == MI355_EPI_ATTN_DELTA) {
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int row = sb * 32 + pass * 8 + rd_row;
+                const bool ok = col_ok && row < rows_left;
+                uv[pass] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, ok ? (unsigned)((row * p.ldr + cbase) * 2) : OOB, 0, 0));
+                if constexpr (KIND == MI355_EPI_SWIGLU_BWD)
+                    gv[pass] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, ok ? (unsigned)((row * p.ldr + cbase + p.N) * 2) : OOB, 0, 0));
+            }
+        }
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < T::FN; ++j) {
+                f32x4 v = acc[sb * 2 + ii][j];
+                if constexpr (RES) {
+                    v[0] += __uint_as_float(rres[ii][j][0] << 16);
+                    v[1] += __uint_as_float(rres[ii][j][0] & 0xffff0000u);
+                    v[2] += __uint_as_float(rres[ii][j][1] << 16);
+                    v[3] += __uint_as_float(rres[ii][j][1] & 0xffff0000u);
+                }
+                const u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                *reinterpret_cast<u32x2*>(stg + ii * 2048 + wr_off + (((2 * j + (g >> 1)) ^ wr_x) << 4)) = pk;
+            }
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            rd[pass] = *reinterpret_cast<const u32x4*>(stg + pass * 1024 + rd_off);
+            if constexpr (KIND == MI355_EPI_SWIGLU_FWD)
+                partner[pass] = *reinterpret_cast<const u32x2*>(stg + pass * 1024 + rd_row * 128 + ((((rd_ch ^ 4) ^ (rd_row & 7))) << 4) + (((hi4 ^ pass) & 1) << 3));
+        }
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const u32x4 o = (pass & 1) ? (u32x4){rd[pass][2], rd[pass][3], rd[pass][0], rd[pass][1]} : rd[pass];  // rows 8-15 of a 16-row tile were written with their halves exchanged
+            const int row = sb * 32 + pass * 8 + rd_row;
+            const bool ok = col_ok && row < rows_left && !(p.ablate & 2);  // (profiling: bit 1 = no stores)
+            if constexpr (KIND == MI355_EPI_SWIGLU_BWD) {
+                u32x4 o0, o1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float du[2], dg[2];
+#pragma unroll
+                    for (int hlf = 0; hlf < 2; ++hlf) {
+                        const float d_ = hlf ? __uint_as_float(o[e] & 0xffff0000u) : __uint_as_float(o[e] << 16);
+                        const float u_ = hlf ? __uint_as_float(uv[pass][e] & 0xffff0000u) : __uint_as_float(uv[pass][e] << 16);
+                        const float g_ = hlf ? __uint_as_float(gv[pass][e] & 0xffff0000u) : __uint_as_float(gv[pass][e] << 16);
+                        swiglu_grads(d_, u_, g_, du[hlf], dg[hlf]);
+                    }
+                    o0[e] = pack_bf2(du[0], du[1]);
+                    o1[e] = pack_bf2(dg[0], dg[1]);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(o0, rsrc_c, ok ? (unsigned)((row * p.ldc + cbase) * 2) : OOB, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o1, rsrc_c, ok ? (unsigned)((row * p.ldc + cbase + p.N) * 2) : OOB, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(o, rsrc_c, ok ? (unsigned)((row * p.ldc + cbase) * 2) : OOB, 0, 0);
+                if constexpr (KIND == MI355_EPI_ATTN_DELTA) {
+                    float dsum = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        dsum += __uint_as_float(o[e] << 16) * __uint_as_float(uv[pass][e] << 16) + __uint_as_float(o[e] & 0xffff0000u) * __uint_as_float(uv[pass][e] & 0xffff0000u);
+                    dsum += __shfl_xor(dsum, 1, 64);
+                    dsum += __shfl_xor(dsum, 2, 64);
+                    dsum += __shfl_xor(dsum, 4, 64);
+                    psum[sb][pass] = dsum;
+                }
+                if constexpr (KIND == MI355_EPI_SWIGLU_FWD) {
+                    const u32x2 pv = partner[pass];
+                    const unsigned own0 = hi4 ? o[2] : o[0], own1 = hi4 ? o[3] : o[1];
+                    const unsigned uw[2] = {hi4 ? pv[0] : own0, hi4 ? pv[1] : own1}, gw[2] = {hi4 ? own0 : pv[0], hi4 ? own1 : pv[1]};
+                    float a4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float u_ = (e & 1) ? __uint_as_float(uw[e >> 1] & 0xffff0000u) : __uint_as_float(uw[e >> 1] << 16);
+                        const float g_ = (e & 1) ? __uint_as_float(gw[e >> 1] & 0xffff0000u) : __uint_as_float(gw[e >> 1] << 16);
+                        a4[e] = swiglu_act(u_, g_);
+                    }
+                    const u32x2 av = {pack_bf2(a4[0], a4[1]), pack_bf2(a4[2], a4[3])};
+                    __builtin_amdgcn_raw_buffer_store_b64(av, rsrc_r, ok ? (unsigned)((row * p.ldr + cbase2) * 2) : OOB, 0, 0);
+                }
+            }
+        }
+        if constexpr (KIND == MI355_EPI_ATTN_DELTA) {
+            if (sb == 3) {  // park the 128 row sums behind the last row reads (LDS operations of a wave execute in order); read by chunk 4, a slot barrier later
+                float* part = reinterpret_cast<float*>(stg);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int pass = 0; pass < 4; ++pass)
+                        if (rd_ch == 0) part[s4 * 32 + pass * 8 + rd_row] = psum[s4][pass];
+            }
+        }
+    };
+    auto delta_combine = [&](const int cj) {
+        // the row constants: a head's two halves sit in two neighbouring waves of the group, whose 128 row sums were parked in their staging regions in chunk 3
+        // (behind their last row reads; a slot barrier ago).  One thread per (row, head) of the group's 128 rows x 2 heads.
+        if constexpr (KIND == MI355_EPI_ATTN_DELTA) {
+            const int64_t m0 = tile_m0(wC), n0 = tile_n0(wC);
+            const int t_ = threadIdx.x & 255, row = t_ & 127, hsel = t_ >> 7;
+            const float* p0 = reinterpret_cast<const float*>(smem + 2 * T::STAGE + ((wave >> 2) * 4 + 2 * hsel) * 4096);
+            const float sum = p0[row] + p0[1024 + row];
+            const int64_t gm = m0 + wr0 + row, head = (n0 >> 7) + hsel;
+            if (gm < p.M && head < p.ad_Hq) {
+                const int64_t bb = gm / p.ad_S, sq = gm - bb * p.ad_S;
+                const int64_t di = (bb * p.ad_Hq + head) * p.ad_S + sq;
+                p.ad_delta[di] = sum;
+                p.ad_ndl[di] = -sum;
+                p.ad_nl2[di] = -p.ad_lse[di] * 1.4426950408889634f;
+            }
+        }
+    };
+    auto other_slot = [&](auto chunk_c, const int cj, bool next_is_compute) __attribute__((always_inline)) {  // a write-out chunk (chunk >= 0) or nothing at all
+        constexpr int chunk = decltype(chunk_c)::value;
+        if (grpY && started) request();
+        if constexpr (chunk >= 0 && chunk < 4) {
+            if (!(p.ablate & 1)) epi_chunk(chunk_c, cj);  // (profiling: bit 0 = no write-out at all)
+        }
+        if constexpr (chunk == 4) delta_combine(cj);
+        constexpr int STORES = (chunk < 0 || chunk >= 4) ? 0 : (KIND == MI355_EPI_SWIGLU_FWD || KIND == MI355_EPI_SWIGLU_BWD) ? 8 : 4;
+        slot_end(next_is_compute, std::integral_constant<int, STORES>{});
+    };
+
+    walk_init(w1);
+    walk_init(w2);
+    walk_init(wC);
+    plan1();
+    if (!grpY) plan2();
+    request();  // slots 0 and 1
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    request();
+    if (!grpY) {
+        loadB(b0, smem + T::A_BYTES, 0);
+        loadA(aE, smem, 0, 0);
+    }
+    const int lead = grpY ? E : 0;
+    using std::integral_constant;
+    for (int i = 0; i < lead; ++i) other_slot(integral_constant<int, -1>{}, 0, i == lead - 1);
+    for (int cj = 0; cj < J; ++cj) {
+        for (int t = 0; t < NT; ++t) compute_slot(t == 0, t + 1 == NT);
+        const bool more = cj + 1 < J;
+        other_slot(integral_constant<int, 0>{}, cj, false);
+        other_slot(integral_constant<int, 1>{}, cj, false);
+        other_slot(integral_constant<int, 2>{}, cj, false);
+        other_slot(integral_constant<int, 3>{}, cj, E == 4 && more);
+        if constexpr (E == 5) other_slot(integral_constant<int, 4>{}, cj, more);
+        walk_next(wC);
+    }
+    for (int i = 0; i < E - lead; ++i) other_slot(integral_constant<int, -1>{}, 0, false);
+}
+
+int launch_pp(GemmParams p, hipStream_t s) {
+    using T = Cfg256;
+    p.tiles_m = (int)((p.M + T::BM - 1) / T::BM);
+    p.tiles_n = (int)((p.N + T::BN - 1) / T::BN);
+    const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n;
+    MI355_REQUIRE(tiles < 0x7fffffffLL / 16, "mi355_gemm_bf16: grid too large");
+    const dim3 grid(256), block(T::NTHREADS);  // one workgroup per CU: 8 XCDs x (4 column panels x 8 row streams); workgroups without a tile leave at once
+    if (p.epilogue == MI355_EPI_SWIGLU_FWD) hipLaunchKernelGGL((gemm_nt_pp_kernel<MI355_EPI_SWIGLU_FWD, false>), grid, block, 0, s, p, (int)tiles);
+    else if (p.epilogue == MI355_EPI_SWIGLU_BWD) hipLaunchKernelGGL((gemm_nt_pp_kernel<MI355_EPI_SWIGLU_BWD, false>), grid, block, 0, s, p, (int)tiles);
+    else if (p.epilogue == MI355_EPI_ATTN_DELTA) hipLaunchKernelGGL((gemm_nt_pp_kernel<MI355_EPI_ATTN_DELTA, false>), grid, block, 0, s, p, (int)tiles);
+    else if (p.R) hipLaunchKernelGGL((gemm_nt_pp_kernel<MI355_EPI_NONE, true>), grid, block, 0, s, p, (int)tiles);
+    else hipLaunchKernelGGL((gemm_nt_pp_kernel<MI355_EPI_NONE, false>), grid, block, 0, s, p, (int)tiles);
+    MI355_LAUNCH_CHECK("mi355_gemm_bf16(ping-pong)");
+    return 0;
+}
+#endif  // part 6
+
 // Several independent problems of one operand form in ONE launch (the four weight gradients of a transformer block:
 // each alone has fewer output tiles than the chip has CUs, together they fill it).  The concatenated tile list is cut
 // into one contiguous chunk per XCD, so the tiles that share operand panels stay behind one L2.
@@ -1738,6 +2167,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(int64_t M, int64_t N, const
     }
 GEMM_BRIDGE_DECL(1) GEMM_BRIDGE_DECL(2) GEMM_BRIDGE_DECL(3) GEMM_BRIDGE_DECL(4) GEMM_BRIDGE_DECL(5)
 extern "C" __attribute__((visibility("hidden"))) int mi355_gemm_persist_part2(const void* params, void* stream);
+extern "C" __attribute__((visibility("hidden"))) int mi355_gemm_pp_part6(const void* params, void* stream);
+#if GEMM_PART == 6 || GEMM_PART == -1
+extern "C" int mi355_gemm_pp_part6(const void* params, void* stream) { return launch_pp(*static_cast<const GemmParams*>(params), (hipStream_t)stream); }
+#endif
 #if GEMM_PART == 2 || GEMM_PART == -1
 extern "C" int mi355_gemm_persist_part2(const void* params, void* stream) { return launch_persist(*static_cast<const GemmParams*>(params), (hipStream_t)stream); }
 #endif
@@ -1784,6 +2217,13 @@ static int64_t persist_min_tiles() {
     return e && *e ? atoll(e) : 512;
 }
 
+// which epilogue kinds of the persistent NT kernel take the ping-pong form (tile hint 8) by themselves: a bit mask, 1 plain, 2 + residual, 4 SwiGLU forward,
+// 8 SwiGLU backward, 16 attention delta (MI355_GEMM_PP; read per call: A/B runs and tests change it inside one process)
+static int pp_mask() {
+    const char* e = getenv("MI355_GEMM_PP");
+    return e && *e ? atoi(e) : MI355_GEMM_PP_DEFAULT;
+}
+
 extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                                int64_t ldb, void* C, int64_t ldc, int out_dtype, const float* bias,
                                const void* residual, int64_t ldr, int epilogue, void* workspace, int64_t workspace_bytes,
@@ -1808,7 +2248,7 @@ extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const 
                       "mi355_gemm_bf16(SwiGLU backward epilogue): bf16 output [M, 2N] (ldc >= 2N), residual = the forward gate-up output [M, 2N], N %% 8 == 0, no bias");
     const int ablate = tile_hint >> 8;
     tile_hint &= 0xff;
-    MI355_REQUIRE((tile_hint >= 0 && tile_hint <= 5) || tile_hint == 7, "mi355_gemm_bf16: tile_hint must be 0 (auto), 1 (128x128), 2 (256x256), 3 (256x256, alternating wave groups), 4 (3 with one barrier per phase), 5 (256x256, four waves of 128x128) or 7 (2 as a persistent workgroup per CU)");
+    MI355_REQUIRE((tile_hint >= 0 && tile_hint <= 5) || tile_hint == 7 || tile_hint == 8, "mi355_gemm_bf16: tile_hint must be 0 (auto), 1 (128x128), 2 (256x256), 3 (256x256, alternating wave groups), 4 (3 with one barrier per phase), 5 (256x256, four waves of 128x128), 7 (2 as a persistent workgroup per CU) or 8 (7 with the two wave groups a write-out apart)");
     GemmParams p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.bias = bias; p.R = residual;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
@@ -1842,7 +2282,14 @@ extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const 
     const bool persist_ok = form == MI355_GEMM_NT && out_dtype == MI355_DT_BF16 && (epilogue == MI355_EPI_NONE || epilogue == MI355_EPI_SWIGLU_FWD || epilogue == MI355_EPI_SWIGLU_BWD) &&
                             !bias && (K & 63) == 0 && K >= 128 && (N & 7) == 0 && (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 && M >= 256 && N >= 256 &&
                             (!residual || ((ldr & 7) == 0 && ((uintptr_t)residual & 15) == 0)) && ldc * 2 * 256 < 0x7fffffffLL && ldr * 2 * 256 < 0x7fffffffLL;
-    if (cfg == 2 && tile_hint == 0 && persist_ok && ((M + 255) / 256) * ((N + 255) / 256) >= persist_min_tiles()) cfg = 7;
+    if (cfg == 2 && tile_hint == 0 && persist_ok && ((M + 255) / 256) * ((N + 255) / 256) >= persist_min_tiles()) {
+        const int kind_bit = epilogue == MI355_EPI_SWIGLU_FWD ? 4 : epilogue == MI355_EPI_SWIGLU_BWD ? 8 : residual ? 2 : 1;
+        cfg = (pp_mask() & kind_bit) ? 8 : 7;
+    }
+    if (cfg == 8) {  // ping-pong form: needs at least as many K-tiles as write-out slots
+        if (persist_ok && K >= 64 * 5) return mi355_gemm_pp_part6(&p, s);
+        cfg = 7;
+    }
     if (cfg == 7) {
         const bool ok = persist_ok;
         if (ok) return mi355_gemm_persist_part2(&p, s);
@@ -1873,8 +2320,10 @@ extern "C" int mi355_gemm_bf16_attn_delta(int64_t M, int64_t N, int64_t K, const
     p.epilogue = MI355_EPI_ATTN_DELTA; p.tiles_m = p.tiles_n = 0; p.ksplit = 1; p.ws = nullptr; p.ablate = 0;
     p.ad_lse = lse; p.ad_delta = delta; p.ad_nl2 = neg_lse_log2e; p.ad_ndl = neg_delta; p.ad_S = S; p.ad_Hq = Hq;
     // the persistent form (same bits) from two rounds of tiles upward
-    if ((K & 63) == 0 && K >= 128 && ((M + 255) / 256) * ((N + 255) / 256) >= persist_min_tiles() && ldc * 2 * 256 < 0x7fffffffLL && ldctx * 2 * 256 < 0x7fffffffLL)
+    if ((K & 63) == 0 && K >= 128 && ((M + 255) / 256) * ((N + 255) / 256) >= persist_min_tiles() && ldc * 2 * 256 < 0x7fffffffLL && ldctx * 2 * 256 < 0x7fffffffLL) {
+        if ((pp_mask() & 16) && K >= 64 * 5) return mi355_gemm_pp_part6(&p, (hipStream_t)stream);
         return mi355_gemm_persist_part2(&p, (hipStream_t)stream);
+    }
     return mi355_gemm_part2(MI355_GEMM_NT, &p, MI355_DT_BF16, nullptr, 0, (hipStream_t)stream);
 }
 
