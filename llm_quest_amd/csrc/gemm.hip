@@ -32,6 +32,9 @@ namespace {
 #ifndef GEMM_SWAP
 #define GEMM_SWAP 0
 #endif
+#ifndef MI355_GEMM_WALK_DEFAULT
+#define MI355_GEMM_WALK_DEFAULT 2  // see walk_on()
+#endif
 #ifndef MI355_GEMM_PP_DEFAULT
 #define MI355_GEMM_PP_DEFAULT 0  // see pp_mask()
 #endif
@@ -1158,7 +1161,7 @@ __global__ __launch_bounds__(T::NTHREADS, T::MIN_WAVES) void gemm_bf16_kernel(Ge
 #else
 #define TLQ(q, i) do { } while (0)
 #endif
-template <int KIND, bool RES>  // KIND: MI355_EPI_NONE (RES: + bf16 residual, added in fp32 before the rounding), MI355_EPI_SWIGLU_FWD, MI355_EPI_SWIGLU_BWD (see gemm_tile's epilogue for both)
+template <int KIND, bool RES, bool WALK>  // KIND: MI355_EPI_NONE (RES: + bf16 residual, added in fp32 before the rounding), MI355_EPI_SWIGLU_FWD, MI355_EPI_SWIGLU_BWD (see gemm_tile's epilogue for both)
 __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmParams p, int ntiles) {
     using T = Cfg256;
     constexpr int BK = 64, HM = T::FM / 2;
@@ -1171,7 +1174,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmParams p, i
     const int nt = (int)(p.K / BK);
     const int G = gridDim.x;
 
+    // the walk: by default tile blockIdx.x + j G of the XCD-chunked order in 6-row groups.  WALK (ablate bit 3, MI355_GEMM_WALK): weight-stationary per XCD, as in
+    // gemm_nt_pp_kernel -- column panels four at a time, an XCD owns a contiguous run of (column group, row panel) pairs, its 32 workgroups are 4 column panels x 8 row
+    // streams, stream r takes the run's pairs r, r + 8, ...; at K = 1 024 an XCD's four weight panels (2 MB) stay in its L2 for the whole launch.  A column group's
+    // missing panels (N / 256 not a multiple of 4) are walked as empty tiles (everything beyond the matrix: zero operands, no stores).  Needs the full grid of 256.
+    constexpr bool walk = WALK;
+    const int wk_xcd = blockIdx.x & 7, wk_l = blockIdx.x >> 3, wk_ci = wk_l & 3;
+    const int64_t wk_pairs = (int64_t)((p.tiles_n + 3) >> 2) * p.tiles_m;
+    const int wk_lo = (int)(wk_pairs * wk_xcd / 8) + (wk_l >> 2), wk_hi = (int)(wk_pairs * (wk_xcd + 1) / 8);
+    const int wk_J = wk_hi > wk_lo ? (wk_hi - wk_lo + 7) / 8 : 0;
+    const int qend = walk ? (int)blockIdx.x + wk_J * G : ntiles;  // this workgroup's tiles: q = blockIdx.x + j G < qend
     auto origin = [&](int q, int64_t& m0, int64_t& n0) {
+        if (walk) {
+            const int pp = wk_lo + 8 * ((q - (int)blockIdx.x) / G);
+            const int cg = pp / p.tiles_m;
+            m0 = (int64_t)(pp - cg * p.tiles_m) * T::BM;
+            n0 = (int64_t)(cg * 4 + wk_ci) * T::BN;
+            return;
+        }
         const int pid = xcd_chunked(q, ntiles);
         constexpr int GROUP_M = 6;
         const int in_group = GROUP_M * p.tiles_n;
@@ -1242,7 +1262,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmParams p, i
     };
     int qi = blockIdx.x, ti = 0, si = 0;
     auto request_next = [&]() {  // this wave's operand of element si
-        if (qi < ntiles) {
+        if (qi < qend) {
             char* dst = smem + (si & 1) * T::STAGE + (a_side ? 0 : T::A_BYTES) + wlo * T::A_PPW * 1024;
             const bf16_t* px = baseX + (int64_t)ti * BK;
 #pragma unroll
@@ -1259,14 +1279,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmParams p, i
             if (++ti == nt) {
                 ti = 0;
                 qi += G;
-                if (qi < ntiles) plan(qi);
+                if (qi < qend) plan(qi);
             }
         }
         ++si;
     };
 
     int qc = blockIdx.x, sc = 0;  // the multiplying side: tile qc, element number sc
-    if (qc >= ntiles) return;
+    if (qc >= qend) return;
     plan(qi);
     f32x4 acc[T::FM][T::FN];
     bf16x8 aE[HM], aO[HM], b0[T::FN], b1[T::FN];
@@ -1327,7 +1347,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmParams p, i
     loadA(aE, smem, 0, 0);
     for (;;) {
         TLQ(qc, 0);
-        more_tiles = qc + G < ntiles;
+        more_tiles = qc + G < qend;
         for (int t = 0; t < nt; ++t) kstep(t);
         TLQ(qc, 2);
         // ---- write-out of tile qc: 4 sub-blocks of 32 rows x 64 columns per wave; packed bf16 through this wave's own 4 KiB.  LDS operations of a wave execute in
@@ -1504,7 +1524,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmParams p, i
         }
         TLQ(qc, 4);
         qc += G;
-        if (qc >= ntiles) break;
+        if (qc >= qend) break;
         const char* nA = smem + (sc & 1) * T::STAGE;
         loadB(b0, nA + T::A_BYTES, 0);
         loadA(aE, nA, 0, 0);
@@ -1517,12 +1537,18 @@ int launch_persist(GemmParams p, hipStream_t s) {
     p.tiles_n = (int)((p.N + T::BN - 1) / T::BN);
     const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n;
     MI355_REQUIRE(tiles < 0x7fffffffLL / 16, "mi355_gemm_bf16: grid too large");
-    const dim3 grid((unsigned)(tiles < 256 ? tiles : 256)), block(T::NTHREADS);  // one workgroup per CU
-    if (p.epilogue == MI355_EPI_SWIGLU_FWD) hipLaunchKernelGGL((gemm_nt_persist_kernel<MI355_EPI_SWIGLU_FWD, false>), grid, block, 0, s, p, (int)tiles);
-    else if (p.epilogue == MI355_EPI_SWIGLU_BWD) hipLaunchKernelGGL((gemm_nt_persist_kernel<MI355_EPI_SWIGLU_BWD, false>), grid, block, 0, s, p, (int)tiles);
-    else if (p.epilogue == MI355_EPI_ATTN_DELTA) hipLaunchKernelGGL((gemm_nt_persist_kernel<MI355_EPI_ATTN_DELTA, false>), grid, block, 0, s, p, (int)tiles);
-    else if (p.R) hipLaunchKernelGGL((gemm_nt_persist_kernel<MI355_EPI_NONE, true>), grid, block, 0, s, p, (int)tiles);
-    else hipLaunchKernelGGL((gemm_nt_persist_kernel<MI355_EPI_NONE, false>), grid, block, 0, s, p, (int)tiles);
+    const dim3 grid((unsigned)((tiles < 256 && !(p.ablate & 8)) ? tiles : 256)), block(T::NTHREADS);  // one workgroup per CU
+#define PERSIST_LAUNCH(KIND_, RES_)                                                                                                      \
+    do {                                                                                                                                 \
+        if (p.ablate & 8) hipLaunchKernelGGL((gemm_nt_persist_kernel<KIND_, RES_, true>), grid, block, 0, s, p, (int)tiles);               \
+        else hipLaunchKernelGGL((gemm_nt_persist_kernel<KIND_, RES_, false>), grid, block, 0, s, p, (int)tiles);                           \
+    } while (0)
+    if (p.epilogue == MI355_EPI_SWIGLU_FWD) PERSIST_LAUNCH(MI355_EPI_SWIGLU_FWD, false);
+    else if (p.epilogue == MI355_EPI_SWIGLU_BWD) PERSIST_LAUNCH(MI355_EPI_SWIGLU_BWD, false);
+    else if (p.epilogue == MI355_EPI_ATTN_DELTA) PERSIST_LAUNCH(MI355_EPI_ATTN_DELTA, false);
+    else if (p.R) PERSIST_LAUNCH(MI355_EPI_NONE, true);
+    else PERSIST_LAUNCH(MI355_EPI_NONE, false);
+#undef PERSIST_LAUNCH
     MI355_LAUNCH_CHECK("mi355_gemm_bf16(persistent)");
     return 0;
 }
@@ -2219,6 +2245,20 @@ static int64_t persist_min_tiles() {
 
 // which epilogue kinds of the persistent NT kernel take the ping-pong form (tile hint 8) by themselves: a bit mask, 1 plain, 2 + residual, 4 SwiGLU forward,
 // 8 SwiGLU backward, 16 attention delta (MI355_GEMM_PP; read per call: A/B runs and tests change it inside one process)
+static bool walk_on(int64_t N, int64_t K) {
+    // MI355_GEMM_WALK: the persistent NT kernel's weight-stationary walk (gemm_nt_persist_kernel<.., WALK>) for launches the library chooses by itself: 0 never, 1 always,
+    // 2 (default) by shape: few column panels under a long K (the dgrads into d = 1024, the out / down projections), or very many column panels (the LM head).  Round 6,
+    // batch 160, same-box bench.py runs: never 443.3 / 443.6 / 444.7 / 445.9 ms, by shape 438.5 / 438.6 / 441.4-441.8, always 441.6 / 440.6; per shape class (16 + mask):
+    // N <= 1024 with K >= 3072 -3.7 ms, + K = 2048 -0.2, the LM head 0 to -1.2, N = 2048 0, N = 3072 / 4096 / 6144 (K = 1024) +1.0 to +1.9 ms each.  Read per call.
+    const char* e = getenv("MI355_GEMM_WALK");
+    const int mode = e && *e ? atoi(e) : MI355_GEMM_WALK_DEFAULT;
+    if (mode >= 16) {  // exploration: 16 + a mask of shape classes
+        const int m = mode - 16;
+        return ((m & 1) && N <= 1024 && K >= 3072) || ((m & 2) && N >= 64 * 256) || ((m & 4) && N <= 1024 && K == 2048) || ((m & 8) && N == 2048) || ((m & 16) && N == 3072) ||
+               ((m & 32) && N == 4096) || ((m & 64) && N == 6144);
+    }
+    return mode == 1 || (mode == 2 && ((N <= 1024 && K >= 2048) || N >= 64 * 256));
+}
 static int pp_mask() {
     const char* e = getenv("MI355_GEMM_PP");
     return e && *e ? atoi(e) : MI355_GEMM_PP_DEFAULT;
@@ -2285,6 +2325,7 @@ extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const 
     if (cfg == 2 && tile_hint == 0 && persist_ok && ((M + 255) / 256) * ((N + 255) / 256) >= persist_min_tiles()) {
         const int kind_bit = epilogue == MI355_EPI_SWIGLU_FWD ? 4 : epilogue == MI355_EPI_SWIGLU_BWD ? 8 : residual ? 2 : 1;
         cfg = (pp_mask() & kind_bit) ? 8 : 7;
+        if (walk_on(N, K)) p.ablate |= 8;
     }
     if (cfg == 8) {  // ping-pong form: needs at least as many K-tiles as write-out slots
         if (persist_ok && K >= 64 * 5) return mi355_gemm_pp_part6(&p, s);
@@ -2322,6 +2363,7 @@ extern "C" int mi355_gemm_bf16_attn_delta(int64_t M, int64_t N, int64_t K, const
     // the persistent form (same bits) from two rounds of tiles upward
     if ((K & 63) == 0 && K >= 128 && ((M + 255) / 256) * ((N + 255) / 256) >= persist_min_tiles() && ldc * 2 * 256 < 0x7fffffffLL && ldctx * 2 * 256 < 0x7fffffffLL) {
         if ((pp_mask() & 16) && K >= 64 * 5) return mi355_gemm_pp_part6(&p, (hipStream_t)stream);
+        if (walk_on(N, K)) p.ablate |= 8;
         return mi355_gemm_persist_part2(&p, (hipStream_t)stream);
     }
     return mi355_gemm_part2(MI355_GEMM_NT, &p, MI355_DT_BF16, nullptr, 0, (hipStream_t)stream);
