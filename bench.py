@@ -536,6 +536,8 @@ def main():
                     "power cap allows, printed beside the dense peak the roofline is priced against")
     ap.add_argument("--tower", choices=["default", "fp32", "bf16"], default="default", help="arithmetic of the frozen vision tower (vit_model.tower_precision): fp32 = the reference's "
                     "(vlm_engine.py:99-104 runs the ViT outside autocast; split-bf16 GEMMs + exact-fp32 attention), bf16 = bf16 MFMA operands on an fp32 residual stream; default = the package's default")
+    ap.add_argument("--fp32-tower-leg", choices=["on", "off"], default="on", help="N = 1: also time the same steps with the frozen tower at the reference's fp32 precision (`with_fp32_tower`)")
+    ap.add_argument("--other-configs", choices=["on", "off"], default="on", help="N = 1, default batch: append BASELINE configs 2 / 3 / 5 (5 steps each, child processes) as `other_configs`")
     args = ap.parse_args()
     args.batch_given = args.batch is not None
     if args.batch is None:
@@ -668,6 +670,26 @@ def main():
         train_step = {"what": "the same steps including the optimizer: global-norm clip 1.0 + AdamW (ArenaAdamW, one fused launch per parameter arena)",
                       "ms_per_step": round(el2 / args.steps * 1e3, 3), "value": round(world * args.batch * UNITS_PER_SAMPLE * args.steps / el2, 1), "unit": "img+tok/s"}
 
+    # The reference's VLM loop runs the frozen tower in fp32 (vlm_engine.py:99-104, outside autocast); the package's default tower multiplies bf16 operands (DESIGN.md
+    # section 4).  So that the driver's line also carries the step at the reference's precision, the same K steps are timed once more with
+    # vit.tower_precision = "fp32" (split-bf16 GEMMs + exact-fp32 attention: hidden states within 1e-4 of the oracle's), reported beside `value`.
+    fp32_tower = None
+    if world == 1 and tower != "fp32" and args.fp32_tower_leg == "on":
+        vit.tower_precision = "fp32"
+        for _ in range(max(args.warmup, 2)):  # (the first step still takes hidden states submitted by the bf16 tower)
+            step()
+        fence()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            loss32 = step()
+        fence()
+        el3 = time.perf_counter() - t2
+        fp32_tower = {"what": "the same steps with the frozen tower at the reference's fp32 precision (vit.tower_precision = 'fp32'; bench.py --tower fp32 makes it the headline)",
+                      "ms_per_step": round(el3 / args.steps * 1e3, 3), "value": round(args.batch * UNITS_PER_SAMPLE * args.steps / el3, 1), "unit": "img+tok/s",
+                      "frac": round(ALGO_FLOP_PER_SAMPLE * args.batch / (el3 / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4), "loss": round(float(loss32.detach()), 5)}
+        vit.tower_precision = tower
+        step()  # (drains the fp32 hidden states in flight, so that the legs below run the default tower again)
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * args.batch * UNITS_PER_SAMPLE * args.steps / elapsed
@@ -702,6 +724,8 @@ def main():
             line["gemm_windows"] = dict(K_._WINDOW.stats, bucket_blocks=sync.bucket_blocks, window_launches=sync.window_launches)
         if train_step is not None:
             line["with_optimizer_step"] = train_step
+        if fp32_tower is not None:
+            line["with_fp32_tower"] = fp32_tower
         if world == 1 and args.pipe_probe == "on":
             from llm_quest_amd import kernels as K_
 
@@ -735,10 +759,37 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(vit, ad, llm, seed=123)
             except Exception as exc:  # the baseline is a reported number, never the measured path
                 line["cpu_baseline"] = {"value": None, "unit": "img+tok/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {exc!r}"}
+        if world == 1 and args.other_configs == "on" and not args.batch_given and not args.ragged:
+            # BASELINE configs 2, 3 and 5 beside the headline (a few steps each, own processes: this one first gives its memory back), so that the driver's record
+            # carries them too; `python bench.py --config N` prints each one's full line
+            vit = ad = llm = img = ids = mask = ahead = sync = loss = None  # (the closures above see the same cells)
+            if args.optimizer == "on":
+                opt = None
+            import gc
+
+            gc.collect()
+            torch.cuda.empty_cache()
+            line["other_configs"] = other_configs_block()
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def other_configs_block(steps=5, warmup=2, budget_s=150):
+    import subprocess
+
+    out = {}
+    for cfg in (2, 3, 5):
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", str(cfg), "--steps", str(steps), "--warmup", str(warmup), "--cpu-baseline", "off"]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=budget_s)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            out[str(cfg)] = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "frac": d["roofline"]["frac"],
+                             "per_gpu_batch": d["config"]["per_gpu_batch"], "steps": steps, "board_power_w": (d.get("board_power") or {}).get("mean_W")}
+        except Exception as exc:  # reported beside the headline, never instead of it
+            out[str(cfg)] = {"value": None, "error": repr(exc)[:200]}
+    return out
 
 
 if __name__ == "__main__":
