@@ -104,7 +104,7 @@ __device__ __forceinline__ void store_t_tiles(const f32x16 (&acc)[NDT], float mu
         }
 }
 
-template <int D, bool PLAIN>
+template <int D, bool PLAIN, bool DROP>
 __global__ __launch_bounds__(256) void ga_fwd_kernel(int B, int S, int Hq, int Hkv, const bf16_t* __restrict__ q, int64_t ldq,
                                                      const bf16_t* __restrict__ k, int64_t ldk, const bf16_t* __restrict__ v, int64_t ldv,
                                                      bf16_t* __restrict__ o, int64_t ldo, float* __restrict__ lse,
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void ga_fwd_kernel(int B, int S, int Hq, int H
         for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[dt][i] *= alpha;
-        if (da.thresh) {  // dropout on the weights that multiply V; the row sum above keeps every key
+        if (DROP && da.thresh) {  // (DROP is a template parameter: the p = 0 kernels of the Qwen3.5 training path carry no Philox code)  // dropout on the weights that multiply V; the row sum above keeps every key
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float mul[4];
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void ga_delta_kernel(int64_t tokens, int S, in
     }
 }
 
-template <int D, bool PLAIN>
+template <int D, bool PLAIN, bool DROP>
 __global__ __launch_bounds__(256) void ga_bwd_dq_kernel(int B, int S, int Hq, int Hkv, const bf16_t* __restrict__ q, int64_t ldq,
                                                         const bf16_t* __restrict__ k, int64_t ldk, const bf16_t* __restrict__ v, int64_t ldv,
                                                         const bf16_t* __restrict__ d_o, int64_t lddo, const float* __restrict__ lse,
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void ga_bwd_dq_kernel(int B, int S, int Hq, in
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(kimg, ks, lane), qf[ks], s, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<D>(vimg, ks, lane), gf[ks], dp, 0, 0, 0);
         }
-        if (da.thresh) {
+        if (DROP && da.thresh) {  // (DROP is a template parameter: the p = 0 kernels of the Qwen3.5 training path carry no Philox code)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float mul[4];
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void ga_bwd_dq_kernel(int B, int S, int Hq, in
 
 // key-major pass: a wave owns 32 keys of one kv head; NP = number of d-slices the dK^T / dV^T accumulators are split into
 // (blockIdx.x = key_block * NP + slice); all q heads of the group and all query tiles from the diagonal on are walked.
-template <int D, int NP, bool PLAIN>
+template <int D, int NP, bool PLAIN, bool DROP>
 __global__ __launch_bounds__(256) void ga_bwd_dkv_kernel(int B, int S, int Hq, int Hkv, const bf16_t* __restrict__ q, int64_t ldq,
                                                          const bf16_t* __restrict__ k, int64_t ldk, const bf16_t* __restrict__ v, int64_t ldv,
                                                          const bf16_t* __restrict__ d_o, int64_t lddo, const float* __restrict__ lse,
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void ga_bwd_dkv_kernel(int B, int S, int Hq, i
                 const bool ok = PLAIN ? (kvalid && qi < S && (!da.causal || key <= qi)) : (kvalid && qi < S && (key <= qi || padded));
                 const float p = ok ? exp2f(s[i] * scale_log2 - stat[0][r]) : 0.f;
                 float keep = 1.f;
-                if (da.thresh) {  // this lane's key inside its group of four, for attention row (b, hq, qi)
+                if (DROP && da.thresh) {  // (DROP is a template parameter: the p = 0 kernels of the Qwen3.5 training path carry no Philox code)  // this lane's key inside its group of four, for attention row (b, hq, qi)
                     unsigned bits[4];
                     philox4x32_10((unsigned)key >> 2, (unsigned)(((int64_t)b * Hq + hq) * S + qi), da.o0, da.o1, da.k0, da.k1, bits);
                     const unsigned bsel = (key & 3) == 0 ? bits[0] : (key & 3) == 1 ? bits[1] : (key & 3) == 2 ? bits[2] : bits[3];
@@ -380,11 +380,12 @@ int check_ga(int B, int S, int Hq, int Hkv, int D, int64_t ldq, int64_t ldk, int
 
 extern "C" int mi355_attn_generic_fwd(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
                                       int64_t ldv, void* o, int64_t ldo, float* lse, const uint8_t* key_mask, float scale, void* stream) {
+#define GA_DROP false
     if (check_ga(B, S, Hq, Hkv, D, ldq, ldk, ldv, ldo)) return 1;
     MI355_REQUIRE(q && k && v && o && lse, "attn_generic_fwd: null pointer");
     dim3 grid((S + 127) / 128, Hq, B);
     const DropArgs da = {};
-#define LAUNCH(DD) ga_fwd_kernel<DD, false><<<grid, 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, key_mask, scale * LOG2E, da)
+#define LAUNCH(DD) ga_fwd_kernel<DD, false, GA_DROP><<<grid, 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, key_mask, scale * LOG2E, da)
     switch (D) {
         case 32: LAUNCH(32); break;
         case 64: LAUNCH(64); break;
@@ -393,6 +394,7 @@ extern "C" int mi355_attn_generic_fwd(int B, int S, int Hq, int Hkv, int D, cons
     }
 #undef LAUNCH
     MI355_LAUNCH_CHECK("attn_generic_fwd");
+#undef GA_DROP
     return 0;
 }
 
@@ -400,6 +402,7 @@ extern "C" int mi355_attn_generic_bwd(int B, int S, int Hq, int Hkv, int D, cons
                                       int64_t ldv, const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* lse, float* delta,
                                       void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, const uint8_t* key_mask,
                                       float scale, void* stream) {
+#define GA_DROP false
     if (check_ga(B, S, Hq, Hkv, D, ldq, ldk, ldv, ldo)) return 1;
     if (check_ga(B, S, Hq, Hkv, D, lddq, lddk, lddv, lddo)) return 1;
     MI355_REQUIRE(q && k && v && o && d_o && lse && delta && dq && dk && dv, "attn_generic_bwd: null pointer");
@@ -409,8 +412,8 @@ extern "C" int mi355_attn_generic_bwd(int B, int S, int Hq, int Hkv, int D, cons
     MI355_LAUNCH_CHECK("attn_generic_bwd(delta)");
     dim3 gq((S + 127) / 128, Hq, B);
     const DropArgs da = {};
-#define LAUNCH_DQ(DD) ga_bwd_dq_kernel<DD, false><<<gq, 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dq, lddq, key_mask, scale, da)
-#define LAUNCH_DKV(DD, NP) ga_bwd_dkv_kernel<DD, NP, false><<<dim3(((S + 127) / 128) * NP, Hkv, B), 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, key_mask, scale, da)
+#define LAUNCH_DQ(DD) ga_bwd_dq_kernel<DD, false, GA_DROP><<<gq, 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dq, lddq, key_mask, scale, da)
+#define LAUNCH_DKV(DD, NP) ga_bwd_dkv_kernel<DD, NP, false, GA_DROP><<<dim3(((S + 127) / 128) * NP, Hkv, B), 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, key_mask, scale, da)
     switch (D) {
         case 32: LAUNCH_DQ(32); LAUNCH_DKV(32, 1); break;
         case 64: LAUNCH_DQ(64); LAUNCH_DKV(64, 1); break;
@@ -420,6 +423,7 @@ extern "C" int mi355_attn_generic_bwd(int B, int S, int Hq, int Hkv, int D, cons
 #undef LAUNCH_DQ
 #undef LAUNCH_DKV
     MI355_LAUNCH_CHECK("attn_generic_bwd");
+#undef GA_DROP
     return 0;
 }
 
@@ -442,7 +446,7 @@ extern "C" int mi355_attn_dropout_fwd(int B, int S, int Hq, int Hkv, int D, cons
     DropArgs da;
     if (make_drop_args("attn_dropout_fwd", B, S, Hq, causal, p, seed, offset, &da)) return 1;
     dim3 grid((S + 127) / 128, Hq, B);
-#define LAUNCH(DD) ga_fwd_kernel<DD, true><<<grid, 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, nullptr, scale * LOG2E, da)
+#define LAUNCH(DD) ga_fwd_kernel<DD, true, true><<<grid, 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, nullptr, scale * LOG2E, da)
     switch (D) {
         case 32: LAUNCH(32); break;
         case 64: LAUNCH(64); break;
@@ -468,8 +472,8 @@ extern "C" int mi355_attn_dropout_bwd(int B, int S, int Hq, int Hkv, int D, cons
     ga_delta_kernel<<<(int)(dg > 8192 ? 8192 : dg), 256, 0, ST(stream)>>>(tokens, S, Hq, D, (const bf16_t*)o, ldo, (const bf16_t*)d_o, lddo, delta);
     MI355_LAUNCH_CHECK("attn_dropout_bwd(delta)");
     dim3 gq((S + 127) / 128, Hq, B);
-#define LAUNCH_DQ(DD) ga_bwd_dq_kernel<DD, true><<<gq, 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dq, lddq, nullptr, scale, da)
-#define LAUNCH_DKV(DD, NP) ga_bwd_dkv_kernel<DD, NP, true><<<dim3(((S + 127) / 128) * NP, Hkv, B), 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, nullptr, scale, da)
+#define LAUNCH_DQ(DD) ga_bwd_dq_kernel<DD, true, true><<<gq, 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dq, lddq, nullptr, scale, da)
+#define LAUNCH_DKV(DD, NP) ga_bwd_dkv_kernel<DD, NP, true, true><<<dim3(((S + 127) / 128) * NP, Hkv, B), 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, nullptr, scale, da)
     switch (D) {
         case 32: LAUNCH_DQ(32); LAUNCH_DKV(32, 1); break;
         case 64: LAUNCH_DQ(64); LAUNCH_DKV(64, 1); break;
@@ -487,12 +491,13 @@ extern "C" int mi355_attn_dropout_bwd(int B, int S, int Hq, int Hkv, int D, cons
 extern "C" int mi355_attn_generic_dropout_fwd(int B, int S, int Hq, int Hkv, int D, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
                                               int64_t ldv, void* o, int64_t ldo, float* lse, const uint8_t* key_mask, float scale, float p, uint64_t seed,
                                               uint64_t offset, void* stream) {
+#define GA_DROP true
     if (check_ga(B, S, Hq, Hkv, D, ldq, ldk, ldv, ldo)) return 1;
     MI355_REQUIRE(q && k && v && o && lse, "attn_generic_dropout_fwd: null pointer");
     DropArgs da;
     if (make_drop_args("attn_generic_dropout_fwd", B, S, Hq, 1, p, seed, offset, &da)) return 1;
     dim3 grid((S + 127) / 128, Hq, B);
-#define LAUNCH(DD) ga_fwd_kernel<DD, false><<<grid, 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, key_mask, scale * LOG2E, da)
+#define LAUNCH(DD) ga_fwd_kernel<DD, false, GA_DROP><<<grid, 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, key_mask, scale * LOG2E, da)
     switch (D) {
         case 32: LAUNCH(32); break;
         case 64: LAUNCH(64); break;
@@ -501,6 +506,7 @@ extern "C" int mi355_attn_generic_dropout_fwd(int B, int S, int Hq, int Hkv, int
     }
 #undef LAUNCH
     MI355_LAUNCH_CHECK("attn_generic_dropout_fwd");
+#undef GA_DROP
     return 0;
 }
 
@@ -508,6 +514,7 @@ extern "C" int mi355_attn_generic_dropout_bwd(int B, int S, int Hq, int Hkv, int
                                               int64_t ldv, const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* lse, float* delta,
                                               void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, const uint8_t* key_mask, float scale,
                                               float p, uint64_t seed, uint64_t offset, void* stream) {
+#define GA_DROP true
     if (check_ga(B, S, Hq, Hkv, D, ldq, ldk, ldv, ldo)) return 1;
     if (check_ga(B, S, Hq, Hkv, D, lddq, lddk, lddv, lddo)) return 1;
     MI355_REQUIRE(q && k && v && o && d_o && lse && delta && dq && dk && dv, "attn_generic_dropout_bwd: null pointer");
@@ -518,8 +525,8 @@ extern "C" int mi355_attn_generic_dropout_bwd(int B, int S, int Hq, int Hkv, int
     ga_delta_kernel<<<(int)(dg > 8192 ? 8192 : dg), 256, 0, ST(stream)>>>(tokens, S, Hq, D, (const bf16_t*)o, ldo, (const bf16_t*)d_o, lddo, delta);
     MI355_LAUNCH_CHECK("attn_generic_dropout_bwd(delta)");
     dim3 gq((S + 127) / 128, Hq, B);
-#define LAUNCH_DQ(DD) ga_bwd_dq_kernel<DD, false><<<gq, 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dq, lddq, key_mask, scale, da)
-#define LAUNCH_DKV(DD, NP) ga_bwd_dkv_kernel<DD, NP, false><<<dim3(((S + 127) / 128) * NP, Hkv, B), 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, key_mask, scale, da)
+#define LAUNCH_DQ(DD) ga_bwd_dq_kernel<DD, false, GA_DROP><<<gq, 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dq, lddq, key_mask, scale, da)
+#define LAUNCH_DKV(DD, NP) ga_bwd_dkv_kernel<DD, NP, false, GA_DROP><<<dim3(((S + 127) / 128) * NP, Hkv, B), 256, 0, ST(stream)>>>(B, S, Hq, Hkv, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (const bf16_t*)d_o, lddo, lse, delta, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, key_mask, scale, da)
     switch (D) {
         case 32: LAUNCH_DQ(32); LAUNCH_DKV(32, 1); break;
         case 64: LAUNCH_DQ(64); LAUNCH_DKV(64, 1); break;
@@ -529,5 +536,6 @@ extern "C" int mi355_attn_generic_dropout_bwd(int B, int S, int Hq, int Hkv, int
 #undef LAUNCH_DQ
 #undef LAUNCH_DKV
     MI355_LAUNCH_CHECK("attn_generic_dropout_bwd");
+#undef GA_DROP
     return 0;
 }

@@ -523,7 +523,8 @@ extern "C" int mi355_gemv_bf16_pro(int M, int64_t N, int K, const void* x, int64
     MI355_REQUIRE(prologue == 1 || prologue == 2, "gemv_bf16_pro: prologue 1 (RMSNorm of x) or 2 (SwiGLU of gate-up rows), got %d", prologue);
     MI355_REQUIRE(N > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldx >= (prologue == 2 ? 2 * K : K) && ldw >= K && ldy >= N,
                   "gemv_bf16_pro: K and the leading dimensions must be multiples of 8 (x rows hold 2K elements under prologue 2)");
-    MI355_REQUIRE((int64_t)M * K * 2 <= 65536, "gemv_bf16_pro: the operand rows (%d x %d bf16) exceed the 64 KiB LDS image", M, K);
+    // (the RMSNorm prologue keeps eight row sums in 32 bytes of static LDS beside the dynamic image: together they must stay within the 64 KiB a launch gets by default)
+    MI355_REQUIRE((int64_t)M * K * 2 + 32 <= 65536, "gemv_bf16_pro: the operand rows (%d x %d bf16) plus 32 bytes of row sums exceed the 64 KiB LDS image", M, K);
     MI355_REQUIRE(x && W && y && (!residual || ldr >= N) && (prologue != 1 || norm_w), "gemv_bf16_pro: null pointer or residual pitch too small");
     const int grid = (int)((N + 3) / 4 < 2048 ? (N + 3) / 4 : 2048);
     const size_t lds = (size_t)M * K * 2;

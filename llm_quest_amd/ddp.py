@@ -41,6 +41,10 @@ runs a WINDOW: its next ``MI355_DDP_WINDOW_LAUNCHES`` (default 2) persistent-siz
 dgrad GEMMs of the following block, ~2.2 ms against ~1.3 ms of ring all-reduce for 7 x 31.5 MB on eight ranks -- then the compute stream waits for the group's
 completion event (a bound on the worst case, not a stall in the normal one) and the persistent kernel is back.  Five windows per step instead of a whole backward on
 the slower kernel; ``kernels._WINDOW.stats`` counts both kinds of launch and ``bench.py`` prints them for N > 1.
+The window's length is MEASURED, not assumed (round 6): every group's collectives are bracketed by two events on the communication stream, every window by two on the
+compute stream; ``begin_step`` reads the pairs that have completed and sets ``window_launches = ceil(slowest group's all-reduce / one windowed launch)`` (1..16), so on
+a slower fabric, more ranks or another node count the windows grow with the collectives instead of the compute stream stalling at their end (``window_for``;
+``MI355_DDP_WINDOW_LAUNCHES`` pins the length, ``MI355_DDP_WINDOW_WAIT=0`` drops the bound at a window's end altogether).
 
 Gradient accumulation: wrap every micro-step but the last in ``with sync.no_sync():`` -- the hooks then leave the buckets
 alone (they keep accumulating locally) and ``finish_step`` is a no-op; the last micro-step exchanges the sums.
@@ -118,6 +122,10 @@ class GradSync:
         self._ctl_stream = None       # the per-step token-count check runs here (begin_step)
         self.bucket_blocks = max(1, int(os.environ.get("MI355_DDP_BUCKET_BLOCKS", "7")))      # owner buckets per group (one window per group)
         self.window_launches = max(0, int(os.environ.get("MI355_DDP_WINDOW_LAUNCHES", "2")))  # per-tile NT launches behind a group; 0 = no windows (persistent kernel always)
+        self.window_auto = "MI355_DDP_WINDOW_LAUNCHES" not in os.environ  # sized from the measured all-reduce / launch times (begin_step)
+        self.window_wait = os.environ.get("MI355_DDP_WINDOW_WAIT", "1") != "0"
+        self._timings = []            # per window: [comm start, comm done, compute open, compute close or None, launches]
+        self._tok_check = None        # this step's token-count agreement, not yet read on the host (begin_step -> _verify_tokens)
         self._group = []              # complete buckets waiting for their group to fill
         self._group_events = []       # completion events of the groups, reused every step
 
@@ -180,38 +188,90 @@ class GradSync:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
             buf.div_(self.world)
 
-    def _window_behind(self, device):
+    def _window_behind(self, device, start=None):
         """The collectives just enqueued run beside the compute stream: its next ``window_launches`` persistent-sized NT GEMMs take the per-tile kernel, then it waits for
         their completion event and returns to the persistent kernel (module docstring).  Launches already queued are in front of the buckets' events, i.e. finished
-        before the collectives start."""
+        before the collectives start.  ``start``: event recorded on the communication stream in front of the group's collectives (timing)."""
         if self.comm_stream is None or self.window_launches == 0:
             return
         from . import kernels as K
 
         n = K._WINDOW.stats["windows"] % 8
         while len(self._group_events) <= n:
-            self._group_events.append(torch.cuda.Event())
+            self._group_events.append(torch.cuda.Event(enable_timing=True))
         done = self._group_events[n]
         done.record(self.comm_stream)
-        K.open_gemm_window(self.window_launches, lambda: torch.cuda.current_stream(device).wait_event(done))
+        stream = torch.cuda.current_stream(device)  # the compute stream, captured now: the window's end acts on IT, whichever stream issues the closing launch
+        rec = None
+        if start is not None and self.window_auto:
+            opened, closed = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            opened.record(stream)
+            rec = [start, done, opened, closed, self.window_launches, False]
+            self._timings.append(rec)
+
+        def on_close():
+            if rec is not None:
+                rec[3].record(stream)
+                rec[5] = True
+            if self.window_wait:
+                stream.wait_event(done)
+
+        K.open_gemm_window(self.window_launches, on_close, stream=stream)
         self._beside = True
+
+    @staticmethod
+    def window_for(allreduce_ms, launch_ms, lo=1, hi=16):
+        """Windowed launches that cover an all-reduce of ``allreduce_ms`` when one windowed (per-tile) launch lasts ``launch_ms``."""
+        import math
+
+        if not (allreduce_ms > 0 and launch_ms > 0):
+            return lo
+        return max(lo, min(hi, math.ceil(allreduce_ms / launch_ms)))
+
+    def _retune_window(self):
+        """Read the windows whose four events have completed (no host wait) and size the next step's windows from them."""
+        if not self.window_auto or not self._timings:
+            return
+        ar, per = [], []
+        keep = []
+        for rec in self._timings:
+            start, done, opened, closed, launches, was_closed = rec
+            if not was_closed:
+                continue  # (closed by finish_step before its launches ran out: no launch time to read)
+            if not (done.query() and closed.query()):
+                keep.append(rec)
+                continue
+            ar.append(start.elapsed_time(done))
+            per.append(opened.elapsed_time(closed) / max(launches, 1))
+        self._timings = keep[-16:]
+        if ar and per:
+            per.sort()
+            self.window_launches = self.window_for(max(ar), per[len(per) // 2])
 
     def _flush_group(self):
         """Hand the waiting buckets to the communication stream, back to back, and open the compute stream's window behind them."""
         if not self._group:
             return
         device = None
+        start = None
         for ar in self._group:
+            if ar.grad.is_cuda and start is None and self.window_auto and self.window_launches:
+                if self.comm_stream is None:
+                    self.comm_stream = torch.cuda.Stream(device=ar.grad.device)
+                start = torch.cuda.Event(enable_timing=True)
+                self.comm_stream.wait_stream(torch.cuda.current_stream(ar.grad.device))  # (the first bucket's own event would order it too; this puts `start` behind the compute it waits for)
+                start.record(self.comm_stream)
             self._reduce(ar)
             if ar.grad.is_cuda:
                 device = ar.grad.device
         self._group.clear()
         if device is not None:
-            self._window_behind(device)
+            self._window_behind(device, start)
 
     def _on_ready(self, module):
         if not self.enabled or not self._sync_on:
             return
+        self._verify_tokens()  # (before the first collective whose shape depends on the split decision)
         if self._split_now and module is self.early_tail[0]:
             top = self.early_tail[1]
             if id(top) not in self._done and top.trainable():
@@ -254,9 +314,10 @@ class GradSync:
         return sparse < dense
 
     def _check_equal_tokens(self, tokens):
-        """all_gather_into_tensor needs the same count on every rank.  One 16-byte MAX all-reduce of (T, -T), EVERY step that passes a token
-        count (whatever this rank's byte rule says: the check itself must be collective), on a control stream of its own so that the host only
-        waits for this one small collective, not for the compute stream (~0.1 ms against a step of hundreds)."""
+        """all_gather_into_tensor needs the same count on every rank.  One 16-byte MAX all-reduce of (T, -T), EVERY step that passes a token count (whatever this
+        rank's byte rule says: the check itself must be collective).  With RCCL it runs on a control stream of its own and the host does NOT wait for it here: the
+        result stays on the device until ``_verify_tokens`` reads it -- in front of the step's first bucket hand-off, i.e. before any collective whose shape depends
+        on the split decision, and by then long complete -- so a step has no host synchronisation in ``begin_step`` (round 5 read it back at once)."""
         if self.backend == "nccl":
             dev = self._device()
             if self._ctl_stream is None:
@@ -264,11 +325,26 @@ class GradSync:
             with torch.cuda.stream(self._ctl_stream):
                 t = torch.tensor([int(tokens), -int(tokens)], dtype=torch.int64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-                hi, lo = t.tolist()
+                host = torch.empty(2, dtype=torch.int64, pin_memory=True)
+                host.copy_(t, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._ctl_stream)
+            t.record_stream(self._ctl_stream)
+            self._tok_check = (host, ev)
         else:
             t = torch.tensor([int(tokens), -int(tokens)], dtype=torch.int64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-            hi, lo = t.tolist()
+            self._tok_check = (t, None)
+            self._verify_tokens()
+
+    def _verify_tokens(self):
+        chk, self._tok_check = self._tok_check, None
+        if chk is None:
+            return
+        host, ev = chk
+        if ev is not None:
+            ev.synchronize()  # the control stream's 16-byte collective of begin_step: finished long before the first bucket is complete
+        hi, lo = host.tolist()
         if hi != -lo:
             raise RuntimeError(f"GradSync: ranks hold different embedding token counts ({-lo}..{hi}); the split tied-weight exchange all-gathers "
                                "equal shards -- pad the batches alike or call begin_step() without embedding_tokens (dense exchange)")
@@ -278,6 +354,7 @@ class GradSync:
         deterministic embedding backward sums on every rank alike.  The dense all-reduce of the split bucket runs on the communication stream;
         the rows are added to that bucket afterwards, so the current stream waits for it here.  All ranks hold equally many tokens
         (``begin_step`` checked it)."""
+        self._verify_tokens()
         flat = ids.reshape(-1).contiguous()
         rows = rows.contiguous()
         ids_all = torch.empty(self.world * flat.numel(), dtype=flat.dtype, device=flat.device)
@@ -296,6 +373,7 @@ class GradSync:
         self._done.clear()
         self._group.clear()
         self._split_now = False
+        self._retune_window()
         if embedding_tokens is not None and self.enabled and self._sync_on and self.early_tail is not None:
             self._check_equal_tokens(int(embedding_tokens))  # collective: every rank that passes a count takes part, whatever it then decides
             self._split_now = self.split_pays(embedding_tokens, embedding_row_bytes)
@@ -305,6 +383,7 @@ class GradSync:
         """Reduce buckets not yet sent, then order the compute stream after the communication stream."""
         if not self.enabled or not self._sync_on:
             return
+        self._verify_tokens()
         self._flush_group()  # a partly filled group (the adapter's bucket, the blocks behind the last full group)
         for m in self.owners:  # anything whose hook never fired (e.g. unused in this step)
             ar = self._arena(m)

@@ -66,24 +66,27 @@ PERSIST_MIN_TILES = 512  # csrc/gemm.hip: persist_min_tiles()
 
 class _GemmWindow:
     """A bounded stretch of the compute stream in which NT launches stay off the persistent kernel (``ddp.GradSync`` opens one behind every bucket group it hands to the
-    communication stream): ``left`` launches to go, then ``on_close`` -- the compute stream waits for the group's collectives -- and the library's own choice is back."""
+    communication stream): ``left`` launches to go, then ``on_close`` -- the compute stream waits for the group's collectives -- and the library's own choice is back.
+    ``stream``: the compute stream the window belongs to (captured when it opens); launches on other streams (a vision tower running ahead, an evaluation stream) neither
+    count against it nor close it."""
 
     def __init__(self):
-        self.left, self.on_close = 0, None
+        self.left, self.on_close, self.stream = 0, None, None
         self.stats = {"persistent_eligible": 0, "inside_window": 0, "windows": 0}
 
 
 _WINDOW = _GemmWindow()
 
 
-def open_gemm_window(launches, on_close=None):
-    """The next ``launches`` persistent-sized NT GEMM launches run on the per-tile kernel (a collective's channels hold CUs meanwhile; the persistent kernel's 256 workgroups
-    must all start together, see ``persistent_gemm``); in front of the launch after them ``on_close()`` runs and the persistent kernel is allowed again.  A window opened
-    while one is open extends it; both hand-offs run at its end."""
+def open_gemm_window(launches, on_close=None, stream=None):
+    """The next ``launches`` persistent-sized NT GEMM launches of ``stream`` (default: the current one) run on the per-tile kernel (a collective's channels hold CUs
+    meanwhile; the persistent kernel's 256 workgroups must all start together, see ``persistent_gemm``); in front of the launch after them ``on_close()`` runs and the
+    persistent kernel is allowed again.  A window opened while one is open extends it; both hand-offs run at its end."""
     w = _WINDOW
     if w.left == 0 and w.on_close is None:
         persistent_gemm(False)
         w.stats["windows"] += 1
+        w.stream = stream
     w.left = max(w.left, int(launches))
     if on_close is not None:
         prev = w.on_close
@@ -97,17 +100,24 @@ def close_gemm_window():
     w = _WINDOW
     if w.left == 0 and w.on_close is None:
         return
-    cb, w.left, w.on_close = w.on_close, 0, None
+    cb, w.left, w.on_close, w.stream = w.on_close, 0, None, None
     if cb is not None:
         cb()
     persistent_gemm(True)
 
 
-def _nt_tick(M, N):
-    """Called in front of every NT launch that is large enough for the persistent kernel."""
-    if ((M + 255) // 256) * ((N + 255) // 256) < PERSIST_MIN_TILES:
+def _persist_min_tiles():
+    return int(_PERSIST_USER) if _PERSIST_USER else PERSIST_MIN_TILES
+
+
+def _nt_tick(M, N, eligible=True, device=None):
+    """Called in front of every NT launch.  Counts only launches the library would put on the persistent kernel (csrc/gemm.hip ``persist_ok``: bf16 output, no bias,
+    plain / SwiGLU epilogue, no tile hint -- the caller says so through ``eligible`` -- and at least the threshold's tiles), and only those of the window's own stream."""
+    if not eligible or ((M + 255) // 256) * ((N + 255) // 256) < _persist_min_tiles():
         return
     w = _WINDOW
+    if w.stream is not None and device is not None and torch.cuda.current_stream(device) != w.stream:
+        return
     if w.left > 0:
         w.left -= 1
         w.stats["inside_window"] += 1
@@ -148,13 +158,14 @@ def gemm(form, a, b, out=None, out_dtype=BF16, bias=None, residual=None, gelu=Fa
         if residual.dtype != out.dtype or tuple(residual.shape) != (M, N):
             raise ValueError("gemm: residual must match the output's shape and dtype")
         ldr = residual.stride(0)
+    tile_eff = tile or (_TILE_NT_PLAIN if (form == L.GEMM_NT and not gelu and M >= 4096) else 0) or _TILE_BY_FORM[form] or _TILE_OVERRIDE
     if form == L.GEMM_NT:
-        _nt_tick(M, N)
+        _nt_tick(M, N, eligible=out.dtype == BF16 and bias is None and not gelu and tile_eff == 0 and K % 64 == 0 and K >= 128, device=a.device)
     L.call(
         "mi355_gemm_bf16", form, M, N, K, L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), L.ptr(out), out.stride(0),
         L.dt_code(out.dtype), L.ptr(bias), L.ptr(residual), ldr, L.EPI_GELU if gelu else L.EPI_NONE,
         L.ptr(_workspace(a.device)) if allow_split_k else None, WS_BYTES if allow_split_k else 0,
-        tile or (_TILE_NT_PLAIN if (form == L.GEMM_NT and not gelu and M >= 4096) else 0) or _TILE_BY_FORM[form] or _TILE_OVERRIDE,
+        tile_eff,
     )
     return out
 
@@ -253,7 +264,7 @@ def gemm_gateup_swiglu(x, w_fused, tile=0):
         raise ValueError("gemm_gateup_swiglu: bf16 X [M, K], fused weight [2F, K] with F % 32 == 0")
     gu = torch.empty((M, N), dtype=BF16, device=x.device)
     a = torch.empty((M, N // 2), dtype=BF16, device=x.device)
-    _nt_tick(M, N)
+    _nt_tick(M, N, eligible=not (tile or _TILE_SWIGLU_FWD or _TILE_BY_FORM[L.GEMM_NT] or _TILE_OVERRIDE) and Kd % 64 == 0 and Kd >= 128, device=x.device)
     L.call("mi355_gemm_bf16", L.GEMM_NT, M, N, Kd, L.ptr(x), x.stride(0), L.ptr(w_fused), w_fused.stride(0), L.ptr(gu), gu.stride(0), L.DT_BF16, None,
            L.ptr(a), a.stride(0), L.EPI_SWIGLU_FWD, None, 0, tile or _TILE_SWIGLU_FWD or _TILE_BY_FORM[L.GEMM_NT] or _TILE_OVERRIDE)
     return gu, a
@@ -272,7 +283,7 @@ def gemm_dgrad_swiglu_bwd(dy, w, gu, tile=0):
     out = torch.empty_like(gu)
     if DGRAD_NT and M >= DGRAD_NT_MIN_ROWS:
         wt = transpose(w)  # [F, N_out]: the same product in the K-contiguous form
-        _nt_tick(M, F)
+        _nt_tick(M, F, eligible=not (tile or _TILE_SWIGLU_BWD or _TILE_BY_FORM[L.GEMM_NT] or _TILE_OVERRIDE) and Kd % 64 == 0 and Kd >= 128, device=dy.device)
         L.call("mi355_gemm_bf16", L.GEMM_NT, M, F, Kd, L.ptr(dy), dy.stride(0), L.ptr(wt), wt.stride(0), L.ptr(out), out.stride(0), L.DT_BF16, None,
                L.ptr(gu), gu.stride(0), L.EPI_SWIGLU_BWD, None, 0, tile or _TILE_SWIGLU_BWD or _TILE_BY_FORM[L.GEMM_NT] or _TILE_OVERRIDE)
         return out
@@ -516,7 +527,7 @@ def dgrad_attn_delta(dy, w, ctx, lse, B, S, Hq, D):
     L.require_gpu(dy, wt, ctx, lse)
     out = torch.empty((M, N), dtype=BF16, device=dy.device)
     delta = torch.empty_like(lse)
-    _nt_tick(M, N)
+    _nt_tick(M, N, eligible=Kd % 64 == 0 and Kd >= 128, device=dy.device)
     L.call("mi355_gemm_bf16_attn_delta", M, N, Kd, L.ptr(dy), dy.stride(0), L.ptr(wt), wt.stride(0), L.ptr(out), out.stride(0), L.ptr(ctx), ctx.stride(0),
            S, Hq, D, L.ptr(lse), L.ptr(delta), ws.data_ptr() + off0, ws.data_ptr() + off1)
     return out, delta

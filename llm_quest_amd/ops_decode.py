@@ -50,7 +50,7 @@ def gemv_pro(x2d, w, prologue, norm_w=None, eps=1e-6, residual=None):
 
 def fused_rows(M, Kd):
     """Whether a one-token step of M sequences takes the fused streams (the operand rows must fit the kernel's 64-KiB LDS image)."""
-    return M <= 8 and M * Kd * 2 <= 65536
+    return M <= 8 and M * Kd * 2 + 32 <= 65536  # (csrc/decode.hip: the operand image plus 32 bytes of row sums within 64 KiB)
 
 
 def decode_splits(n_keys, B, Hq):
@@ -283,6 +283,7 @@ class GraphDecoder:
         self.write_pos = torch.tensor([start], dtype=torch.int32, device=dev)
         self.length = torch.tensor([start + 1], dtype=torch.int32, device=dev)
         self.splits = decode_splits(need, B, model.trf_blocks[0].att.num_heads)  # fixed for the captured graph: sized for the longest cache it will see
+        self.capacity = need  # the reserved cache rows: the kernels neither write nor attend a token beyond them, so step() refuses to go there
         self.graph = None
 
     def _step(self):
@@ -292,6 +293,9 @@ class GraphDecoder:
 
     def step(self):
         """Consumes ``self.tok`` (the token chosen last), leaves the next greedy token in ``self.tok`` and returns a copy of it."""
+        if self.kv.start_pos >= self.capacity:
+            raise RuntimeError(f"GraphDecoder: the reserved cache holds {self.capacity} tokens (prompt + max_new_tokens) and all of them are used: a further step "
+                               "would neither store nor attend the current token")
         if self.graph is None:
             self._step()  # first step eagerly: loads every kernel before capture
             self._advance_host()

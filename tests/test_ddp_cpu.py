@@ -281,6 +281,97 @@ def test_tied_head_embedding_bucket_is_exchanged_in_two_parts_gloo():
     assert all(p.exitcode == 0 for p in procs) and res == {0: True, 1: True}
 
 
+def _world8_worker(rank, world, port, out):
+    """The headline step's hand-offs at EIGHT ranks (the 8-rank arithmetic had only ever run with two): 28 block buckets last -> first in groups of
+    7, the tied head / embedding bucket in two parts (64 x 512 tokens: the byte rule says split at 8 ranks) and whole (160 x 512: dense), the adapter's bucket and the
+    rest in finish_step -- every gradient the 8-rank mean."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from llm_quest_amd import ddp
+    from llm_quest_amd.ops import arena_for
+
+    ddp.init_from_env(backend="gloo")
+    V, W, T = 12, 4, 6
+    blocks = [_Owner(7 + i) for i in range(28)]
+    adapter = _Owner(99)
+
+    class _Top(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.emb = torch.nn.Parameter(torch.zeros(V, W))
+            self.norm = torch.nn.Parameter(torch.zeros(W))
+
+    top = _Top()
+    owners = blocks + [adapter]  # (already last -> first)
+    sync = ddp.GradSync(owners, tail_arenas=[arena_for(top)], early_tail=(owners[0], arena_for(top)))
+    flushed = []
+    inner = sync._flush_group
+    sync._flush_group = lambda: (flushed.append(len(sync._group)), inner())[1]
+    g = torch.Generator().manual_seed(40 + rank)
+    head_grad, norm_grad = torch.randn(V, W, generator=g), torch.randn(W, generator=g)
+    ids, rows = torch.randint(0, V, (T,), generator=g), torch.randn(T, W, generator=g)
+
+    def step(split):
+        flushed.clear()
+        for p in list(top.parameters()) + [q for m in owners for q in m.parameters()]:
+            p.grad = None
+        os.environ["MI355_DDP_SPLIT_TIED"] = "on" if split else "off"  # (the tiny bucket's own byte rule is checked in the world-2 test; the real sizes below)
+        sync.begin_step(embedding_tokens=T)
+        ar = arena_for(top)
+        ar.grad_target(top.emb)[0].copy_(head_grad)
+        ar.grad_target(top.norm)[0].copy_(norm_grad)
+        for i, m in enumerate(owners):
+            for p in m.parameters():
+                arena_for(m).grad_target(p)[0].fill_(float(rank + 1 + i))
+            m._grad_ready(m)
+        view, _ = ar.grad_target(top.emb)
+        if sync.splits(ar):
+            ids_all, rows_all, scale = sync.gather_embedding(ids, rows)
+            view.index_add_(0, ids_all, rows_all * scale)
+        else:
+            view.index_add_(0, ids, rows)
+        sync.finish_step()
+        return top.emb.grad.clone(), [m.a.grad.clone() for m in owners], list(flushed)
+
+    parts = []
+    for rk in range(world):
+        gg = torch.Generator().manual_seed(40 + rk)
+        hg, _ng = torch.randn(V, W, generator=gg), torch.randn(W, generator=gg)
+        parts.append(hg.index_add(0, torch.randint(0, V, (T,), generator=gg), torch.randn(T, W, generator=gg)))
+    want_emb = sum(parts) / world
+    ok = True
+    for split in (True, False):
+        emb, grads, fl = step(split)
+        ok &= bool(torch.allclose(emb, want_emb, atol=1e-6))
+        for i, gr in enumerate(grads):
+            ok &= bool(torch.allclose(gr, torch.full_like(gr, sum(rk + 1 + i for rk in range(world)) / world)))
+        ok &= [n for n in fl if n] == [7, 7, 7, 7, 1]  # four groups of block buckets during the backward, the adapter's bucket in finish_step
+    # the byte rule at the real sizes (no memory: meta tensors): 8 ranks, bucket = [151 936, 1 024] bf16 + the final norm
+    import types
+
+    real = types.SimpleNamespace(grad=None, params=[torch.empty(151936, 1024, dtype=torch.bfloat16, device="meta"), torch.empty(1024, dtype=torch.bfloat16, device="meta")])
+    os.environ["MI355_DDP_SPLIT_TIED"] = "auto"
+    probe = ddp.GradSync([_Owner(1)], early_tail=(None, real))
+    ok &= probe.world == 8 and probe.split_pays(64 * 512) and not probe.split_pays(160 * 512)
+    out.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_headline_step_hand_offs_at_eight_ranks_gloo():
+    world = 8
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_world8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+    assert all(p.exitcode == 0 for p in procs) and res == {r: True for r in range(world)}
+
+
 def test_persistent_gemm_switch_restores_the_users_threshold(monkeypatch):
     """kernels.persistent_gemm(False) keeps the library off the persistent NT kernel (whose workgroups must all start together) while collectives run beside
     the compute stream; persistent_gemm(True) puts back what the user had set -- nothing, or their own threshold."""
@@ -334,6 +425,32 @@ def test_gemm_window_bounds_the_per_tile_stretch_behind_a_bucket_group(monkeypat
     assert calls == ["a", "b", "c"] and var not in os.environ and K._WINDOW.left == 0
     K.close_gemm_window()  # idempotent
     assert calls == ["a", "b", "c"]
+
+
+def test_gemm_window_counts_only_persistent_eligible_launches_and_sizes_itself(monkeypatch):
+    """a launch the library would NOT put on the persistent kernel (bias, fp32 output, a tile hint ...: ``eligible=False``) does not use the window up; the
+    user's own MI355_GEMM_PERSIST_MIN_TILES is the threshold; GradSync.window_for sizes a window from the measured all-reduce and launch times."""
+    from llm_quest_amd import ddp
+    from llm_quest_amd import kernels as K
+
+    monkeypatch.delenv("MI355_GEMM_PERSIST_MIN_TILES", raising=False)
+    monkeypatch.setattr(K, "_PERSIST_USER", None)
+    monkeypatch.setattr(K, "_WINDOW", K._GemmWindow())
+    big = (113440, 4096)
+    K.open_gemm_window(2, None)
+    K._nt_tick(*big, eligible=False)
+    K._nt_tick(*big, eligible=False)
+    assert K._WINDOW.left == 2 and K._WINDOW.stats["inside_window"] == 0
+    K._nt_tick(*big)
+    assert K._WINDOW.left == 1
+    K.close_gemm_window()
+    monkeypatch.setattr(K, "_PERSIST_USER", "100000")  # the user's threshold: 7 104 tiles are below it
+    K.open_gemm_window(1, None)
+    K._nt_tick(*big)
+    assert K._WINDOW.left == 1
+    K.close_gemm_window()
+    wf = ddp.GradSync.window_for
+    assert wf(1.3, 1.1) == 2 and wf(5.0, 1.1) == 5 and wf(0.2, 1.1) == 1 and wf(100.0, 1.0) == 16 and wf(0.0, 1.0) == 1 and wf(1.0, 0.0) == 1
 
 
 def test_block_buckets_leave_in_groups(monkeypatch):
