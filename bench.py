@@ -721,7 +721,7 @@ def main():
         if world > 1:  # how the N > 1 step's large NT GEMMs were launched: on the persistent kernel, or on the per-tile kernel inside a window behind a bucket group (ddp.GradSync)
             from llm_quest_amd import kernels as K_
 
-            line["gemm_windows"] = dict(K_._WINDOW.stats, bucket_blocks=sync.bucket_blocks, window_launches=sync.window_launches)
+            line["gemm_windows"] = dict(K_._WINDOW.stats, bucket_blocks=sync.bucket_blocks, window_launches=sync.window_launches, window_sized_from_measurements=sync.window_auto)
         if train_step is not None:
             line["with_optimizer_step"] = train_step
         if fp32_tower is not None:

@@ -1569,6 +1569,20 @@ int launch_persist(GemmParams p, hipStream_t s) {
 //   * requests: every wave asks for its own four pieces of the weight panel and, for slots in which its group multiplies, its own four pieces of the activation
 //     panel; waves 0-3 right behind the barrier that frees the stage, waves 4-7 half a slot later (the CU has one address unit: see gemm_nt_persist_kernel).
 // NT form, bf16 output, K % 64 == 0, K / 64 >= E, N % 8 == 0, no bias.
+//
+// STATUS (round 6): correct on every epilogue kind (tools/experimental/pp_check.py: bit-identical to tile 2 on integer operands, fp32-summation noise on random ones), and
+// SLOWER than gemm_nt_persist_kernel wherever the write-out matters, so the library does not choose it (MI355_GEMM_PP_DEFAULT 0; tile hint 8 / MI355_GEMM_PP select it).
+// Batch 160, isolated, us (hint 7 -> hint 8): QKV 771 -> 881, out-proj + residual 424 -> 453, gate-up + SwiGLU 1 310 -> 1 451, down dgrad + SwiGLU backward 905 -> 1 063,
+// LM head forward 21.8 -> 22.6 ms; long-K shapes level (dqkv 733 -> 752, LM head dgrad 19.3 -> 18.6 ms: the walk).  In the step: +1.5 ... +7 ms per kind.  Why:
+//   * with NO write-out work at all (ablate bit 0) the same launches take 732 / 360 / 1 073 / 621 us and 19.3 ms: -5 ... -31 % -- the overlap is there to be had;
+//   * but a slot in which only one group multiplies does not get shorter than ~0.9 us (against 1.55 us for a slot with both): the stream is two stages deep, a slot's
+//     panels are requested one slot ahead, and under load an LDS-DMA request takes about that long to land -- the lone multiplying wave waits for data, not for the pipe;
+//   * and whatever the writing group puts into the memory pipeline lengthens it further: a sub-block's four stores +0.43 us per slot (ablate bit 1: stores dropped),
+//     its staging +0.17 us; the SwiGLU backward's gate-up loads ~2 us per slot unless requested a slot ahead, and requested ahead (two register sets) the kernel spills.
+//   So a write-out of E chunks costs 2 E slots of 1.5-1.6 us in which the SIMD's matrix pipe does half the work -- more than the 2.45 us it costs with both waves idle.
+//   What would change it: a third stage (192 KB: does not fit beside 256 x 256 tiles), or panels requested two slots ahead into the half of a stage the writing group does
+//   not use.  Tried and dropped on the way: the multiplying group issuing every request while the other writes out (main loop -8 % from the extra scalar state), eight
+//   16-row slots for the SwiGLU backward (1 294 us), its operands a slot ahead in two register sets (36 spilled values, 2 715 us).
 #if GEMM_PART == 6 || !defined(GEMM_PART)
 template <int KIND, bool RES>
 __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmParams p, int ntiles) {

@@ -141,7 +141,8 @@ def test_bench_two_rank_rehearsal_runs_the_whole_n_gt_1_path_on_one_gpu():
     # bucket groups + GEMM windows (ddp.GradSync): only the two launches behind each group (and behind the early dense part of the tied bucket) leave the persistent
     # kernel -- not the whole backward.  At batch 4 no launch is persistent-sized: a step's windows never count down, merge into one and end in finish_step.
     gw = d2["gemm_windows"]
-    assert gw["bucket_blocks"] == 7 and gw["window_launches"] == 2 and gw["windows"] >= 3 and gw["inside_window"] == 0, gw
+    # (window_launches starts at 2 and is then sized from the measured collective / launch times: ddp.GradSync._retune_window)
+    assert gw["bucket_blocks"] == 7 and 1 <= gw["window_launches"] <= 16 and gw["windows"] >= 3 and gw["inside_window"] == 0, gw
     env1 = {k: v for k, v in os.environ.items() if k != "MI355_DDP_REHEARSAL"}
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, env=env1, capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-3000:]
