@@ -592,15 +592,20 @@ def main():
     if ahead is not None:
         ahead.submit(img)
 
+    tower_at = os.environ.get("MI355_BENCH_TOWER_AT", "start")  # A/B: where in the step the next batch's tower forward is submitted to the side stream
+
     def vision():
         if ahead is None:
             return None
         h = ahead.take(img)
-        ahead.submit(img)
+        if tower_at == "start":
+            ahead.submit(img)
         return h
 
     def step():
         loss = vlm_step_loss(vit, llm, ad, img, ids, mask, hf_vit_model=False, vit_hidden=vision())
+        if ahead is not None and tower_at == "backward":
+            ahead.submit(img)
         sync.begin_step(embedding_tokens=ids.numel())  # the tied head / embedding bucket: dense or in two parts, by bytes (ddp.GradSync.split_pays)
         (loss * sync.loss_weight(n_targets) if (args.ragged and world > 1) else loss).backward()
         sync.finish_step()

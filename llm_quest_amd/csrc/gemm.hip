@@ -32,6 +32,12 @@ namespace {
 #ifndef GEMM_SWAP
 #define GEMM_SWAP 0
 #endif
+#ifndef GEMM_C_AUX_WALK
+#define GEMM_C_AUX_WALK 2
+#endif
+#ifndef GEMM_C_AUX_OLD
+#define GEMM_C_AUX_OLD 0
+#endif
 #ifndef MI355_GEMM_WALK_DEFAULT
 #define MI355_GEMM_WALK_DEFAULT 2  // see walk_on()
 #endif
@@ -1179,6 +1185,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmParams p, i
     // streams, stream r takes the run's pairs r, r + 8, ...; at K = 1 024 an XCD's four weight panels (2 MB) stay in its L2 for the whole launch.  A column group's
     // missing panels (N / 256 not a multiple of 4) are walked as empty tiles (everything beyond the matrix: zero operands, no stores).  Needs the full grid of 256.
     constexpr bool walk = WALK;
+    // cache policy of the output stores (0 default, 2 = nt, 16 = sc1, 18 = both).  Round 6, same-box bench.py pairs with the walk by shape: base 435.7 / 436.4 ms, nt on the
+    // weight-stationary launches 434.3 / 435.1, sc1 436.1 / 435.3, sc1 nt 434.5 / 434.8: nt there (the tile is written once and next read by another kernel; the L2 keeps the
+    // weight panels instead)
+    constexpr int CAUX = WALK ? GEMM_C_AUX_WALK : GEMM_C_AUX_OLD;
     const int wk_xcd = blockIdx.x & 7, wk_l = blockIdx.x >> 3, wk_ci = wk_l & 3;
     const int64_t wk_pairs = (int64_t)((p.tiles_n + 3) >> 2) * p.tiles_m;
     const int wk_lo = (int)(wk_pairs * wk_xcd / 8) + (wk_l >> 2), wk_hi = (int)(wk_pairs * (wk_xcd + 1) / 8);
@@ -1430,10 +1440,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmParams p, i
                         o0[e] = pack_bf2(du[0], du[1]);
                         o1[e] = pack_bf2(dg[0], dg[1]);
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(o0, rsrc_c, ok ? (unsigned)((row * p.ldc + cbase) * 2) : OOB, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(o1, rsrc_c, ok ? (unsigned)((row * p.ldc + cbase + p.N) * 2) : OOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(o0, rsrc_c, ok ? (unsigned)((row * p.ldc + cbase) * 2) : OOB, 0, CAUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(o1, rsrc_c, ok ? (unsigned)((row * p.ldc + cbase + p.N) * 2) : OOB, 0, CAUX);
                 } else {
-                    __builtin_amdgcn_raw_buffer_store_b128(o, rsrc_c, ok ? (unsigned)((row * p.ldc + cbase) * 2) : OOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rsrc_c, ok ? (unsigned)((row * p.ldc + cbase) * 2) : OOB, 0, CAUX);
                     if constexpr (KIND == MI355_EPI_ATTN_DELTA) {
                         // o = d(ctx), rounded; uv = ctx: the row's dot product over this lane's 8 columns, folded over the row's eight lanes = half a head (the wave's 64 columns)
                         float dsum = 0.f;
