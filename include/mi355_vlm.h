@@ -26,6 +26,10 @@ extern "C" {
 
 #define MI355_DT_BF16 0
 #define MI355_DT_F32 1
+/* an fp32 value as three bf16 values [hi | lo | hi] in three column blocks of the row (hi = bf16(x), lo = bf16(x - hi)): the activation operand of an fp32-grade
+ * product on bf16 MFMA (mi355_split3_bf16); an OUTPUT dtype of mi355_layernorm_fwd and of mi355_gemm_bf16 (NT, plain / GELU epilogue, no residual): y / C is
+ * bf16 [rows, 3 * width], and the producing kernel saves the fp32 round trip of a separate split pass (reference vlm_engine.py:99-104: the fp32 vision tower) */
+#define MI355_DT_SPLIT3 2
 
 /* GEMM operand forms (all row-major storage):
  *   NT: C[m,n] = sum_k A[m,k] * B[n,k]   (A: MxK, B: NxK)  -- y = x W^T, nn.Linear forward
@@ -66,7 +70,7 @@ int mi355_abi_version(void);
  * Replaces F.linear / nn.Linear (+ bias, + GELU, + residual add) at qwen3_attention.py:91-93,148,
  * qwen3_transformer_block.py:48-53, vit_attention.py:59-61,88, vit_transformer_block.py:59-67,
  * vit_engine.py:43-53, qwen3_model.py:92 and their autograd backward.
- *   out_dtype    MI355_DT_BF16 | MI355_DT_F32 (dtype of C and of `residual`)
+ *   out_dtype    MI355_DT_BF16 | MI355_DT_F32 (dtype of C and of `residual`) | MI355_DT_SPLIT3 (NT form, epilogue NONE / GELU_ERF, no residual: C is bf16 [M, 3N], ldc >= 3N)
  *   bias         fp32 [N] or NULL;  residual  [M,N] with ldr, or NULL (may alias C: accumulate)
  *   workspace    optional fp32 scratch (16-byte aligned) of workspace_bytes: lets problems with few output tiles
  *                and a long K (weight gradients) split K over several workgroups (slabs + reduce); NULL = never split.
@@ -247,7 +251,7 @@ int mi355_scatter_rows(int64_t tokens, int64_t row_bytes, const uint8_t* mask, c
 
 /* LayerNorm on fp32 rows.  mode 0: the reference's ViT/GPT LayerNorm, eps ADDED TO sigma (vit_transformer_block.py:12-31);
  * mode 1: nn.LayerNorm, eps inside the square root (Qwen3.5 vision blocks, qwen3_5_vision_model.py:213-214,406).
- * y bf16 or fp32; saves mean / 1/(sigma-term) fp32 [rows] if non-NULL. */
+ * y bf16, fp32 or MI355_DT_SPLIT3 (bf16 [rows, 3 * width]); saves mean / 1/(sigma-term) fp32 [rows] if non-NULL. */
 int mi355_layernorm_fwd(int64_t rows, int width, const float* x, const float* scale, const float* shift, void* y,
                         int y_dtype, float* mean, float* rsig, float eps, int mode, void* stream);
 

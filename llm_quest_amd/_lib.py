@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI355_LIB_PATH") or os.path.join(_HERE, "libmi355vlm.so")  # override: profiling builds only
 CSRC = os.path.join(_HERE, "csrc")
 
-DT_BF16, DT_F32 = 0, 1
+DT_BF16, DT_F32, DT_SPLIT3 = 0, 1, 2  # DT_SPLIT3: an fp32 value as bf16 [hi | lo | hi] column blocks (include/mi355_vlm.h)
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_SWIGLU_BWD, EPI_SWIGLU_FWD = 0, 1, 2, 3
 EPI_GELU_DUAL_ERF, EPI_GELU_DUAL_TANH, EPI_GELU_BWD_ERF, EPI_GELU_BWD_TANH = 4, 5, 6, 7

@@ -118,6 +118,7 @@ struct GemmParams {
     float* ad_nl2;
     float* ad_ndl;
     int ad_S, ad_Hq;
+    int split3;  // fp32 output kernels only: C is bf16 [M, 3N], the value as [hi | lo | hi] (MI355_DT_SPLIT3)
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -1074,6 +1075,19 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
                                     for (int e = 0; e < nvalid; ++e) c[e] = f2bf(v[e] + (r ? bf2f(r[e]) : 0.f));
                                 }
                             } else {
+                                // (NT on the 8- / 4x64-wave tiles only: one more copy of the passes stops the unroller on the 4-wave 128x128 tile and its accumulators land in scratch)
+                                constexpr bool SPLIT3_OK = !A_TR && !B_TR && !std::is_same_v<T, Cfg256w>;
+                                if (SPLIT3_OK && p.split3) {  // (N % 8 == 0, 16-byte aligned C, no residual: checked by the entry point)
+                                    float lo[8];
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) lo[e] = v[e] - bf2f(f2bf(v[e]));
+                                    const u32x4 hv = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+                                    const u32x4 lv = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(lo[4], lo[5]), pack_bf2(lo[6], lo[7])};
+                                    bf16_t* c3 = reinterpret_cast<bf16_t*>(p.C) + gm * p.ldc + gn;
+                                    *reinterpret_cast<u32x4*>(c3) = hv;
+                                    *reinterpret_cast<u32x4*>(c3 + p.N) = lv;
+                                    *reinterpret_cast<u32x4*>(c3 + 2 * p.N) = hv;
+                                } else {
                                 float* c = reinterpret_cast<float*>(p.C) + gm * p.ldc + gn;
                                 const float* r = p.R ? reinterpret_cast<const float*>(p.R) + gm * p.ldr + gn : nullptr;
                                 if (vec_ok) {
@@ -1086,6 +1100,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int pid, co
                                     *reinterpret_cast<f32x4*>(c + 4) = o1;
                                 } else {
                                     for (int e = 0; e < nvalid; ++e) c[e] = v[e] + (r ? r[e] : 0.f);
+                                }
                                 }
                             }
                         }
@@ -2293,6 +2308,16 @@ extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const 
                                const void* residual, int64_t ldr, int epilogue, void* workspace, int64_t workspace_bytes,
                                int tile_hint, void* stream) {
     MI355_REQUIRE(form >= 0 && form <= 2, "mi355_gemm_bf16: bad form %d", form);
+    const bool split3 = out_dtype == MI355_DT_SPLIT3;
+    if (split3) {
+        MI355_REQUIRE(form == MI355_GEMM_NT && (epilogue == MI355_EPI_NONE || epilogue == MI355_EPI_GELU_ERF) && !residual && (N & 7) == 0 && ldc >= 3 * N && (ldc & 7) == 0 &&
+                          ((uintptr_t)C & 15) == 0,
+                      "mi355_gemm_bf16(split3 output): NT form, plain / GELU epilogue, no residual, N %% 8 == 0, C bf16 [M, 3N] with 16-byte aligned rows");
+        MI355_REQUIRE((tile_hint & 0xff) != 5, "mi355_gemm_bf16(split3 output): not on tile hint 5");
+        out_dtype = MI355_DT_F32;  // the fp32-output kernels carry it (no split-K: the slabs' reduce kernel writes fp32)
+        workspace = nullptr;
+        workspace_bytes = 0;
+    }
     MI355_REQUIRE(out_dtype == MI355_DT_BF16 || out_dtype == MI355_DT_F32, "mi355_gemm_bf16: bad out_dtype");
     if (int rc = check_operands("mi355_gemm_bf16", form, M, N, K, A, lda, B, ldb, C)) return rc;
     MI355_REQUIRE(workspace == nullptr || ((uintptr_t)workspace & 15) == 0, "mi355_gemm_bf16: workspace must be 16-byte aligned");
@@ -2318,6 +2343,7 @@ extern "C" int mi355_gemm_bf16(int form, int64_t M, int64_t N, int64_t K, const 
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
     p.epilogue = epilogue; p.tiles_m = p.tiles_n = 0; p.ksplit = 1; p.ws = nullptr; p.ablate = ablate;
     p.ad_lse = nullptr; p.ad_delta = p.ad_nl2 = p.ad_ndl = nullptr; p.ad_S = p.ad_Hq = 0;
+    p.split3 = split3;
     hipStream_t s = (hipStream_t)stream;
     int cfg = tile_hint;
     if (cfg == 0) {
@@ -2384,6 +2410,7 @@ extern "C" int mi355_gemm_bf16_attn_delta(int64_t M, int64_t N, int64_t K, const
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldctx;
     p.epilogue = MI355_EPI_ATTN_DELTA; p.tiles_m = p.tiles_n = 0; p.ksplit = 1; p.ws = nullptr; p.ablate = 0;
     p.ad_lse = lse; p.ad_delta = delta; p.ad_nl2 = neg_lse_log2e; p.ad_ndl = neg_delta; p.ad_S = S; p.ad_Hq = Hq;
+    p.split3 = 0;
     // the persistent form (same bits) from two rounds of tiles upward
     if ((K & 63) == 0 && K >= 128 && ((M + 255) / 256) * ((N + 255) / 256) >= persist_min_tiles() && ldc * 2 * 256 < 0x7fffffffLL && ldctx * 2 * 256 < 0x7fffffffLL) {
         if ((pp_mask() & 16) && K >= 64 * 5) return mi355_gemm_pp_part6(&p, (hipStream_t)stream);
@@ -2411,6 +2438,7 @@ extern "C" int mi355_gemm_bf16_grouped(int form, int count, const mi355_gemm_pro
         p.M = q.M; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc; p.ldr = q.ldr;
         p.epilogue = MI355_EPI_NONE; p.tiles_m = p.tiles_n = 0; p.ksplit = 1; p.ws = nullptr; p.ablate = 0;
         p.ad_lse = nullptr; p.ad_delta = p.ad_nl2 = p.ad_ndl = nullptr; p.ad_S = p.ad_Hq = 0;
+        p.split3 = 0;
         tiles256 += ((q.M + 255) / 256) * ((q.N + 255) / 256);
         small |= q.M < 256 || q.N < 256;
     }

@@ -437,6 +437,15 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int64_t rows, int wi
             if constexpr (OUT_DT == MI355_DT_BF16) {
                 u32x2 pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
                 *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(y) + row * width + i * 4) = pk;
+            } else if constexpr (OUT_DT == MI355_DT_SPLIT3) {  // [hi | lo | hi]: what mi355_split3_bf16 makes of the fp32 row, without the round trip
+                float lo[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) lo[e] = o[e] - bf2f(f2bf(o[e]));
+                const u32x2 hi = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])}, lw = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3])};
+                bf16_t* d = reinterpret_cast<bf16_t*>(y) + row * 3 * (int64_t)width + i * 4;
+                *reinterpret_cast<u32x2*>(d) = hi;
+                *reinterpret_cast<u32x2*>(d + width) = lw;
+                *reinterpret_cast<u32x2*>(d + 2 * width) = hi;
             } else {
                 *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(y) + row * width + i * 4) = (f32x4){o[0], o[1], o[2], o[3]};
             }
@@ -643,6 +652,8 @@ extern "C" int mi355_layernorm_fwd(int64_t rows, int width, const float* x, cons
     const int grid = row_grid(rows);
     if (y_dtype == MI355_DT_BF16)
         hipLaunchKernelGGL(layernorm_fwd_kernel<MI355_DT_BF16>, dim3(grid), dim3(256), 0, s, rows, width, x, scale, shift, y, mean, rsig, eps, mode);
+    else if (y_dtype == MI355_DT_SPLIT3)
+        hipLaunchKernelGGL(layernorm_fwd_kernel<MI355_DT_SPLIT3>, dim3(grid), dim3(256), 0, s, rows, width, x, scale, shift, y, mean, rsig, eps, mode);
     else
         hipLaunchKernelGGL(layernorm_fwd_kernel<MI355_DT_F32>, dim3(grid), dim3(256), 0, s, rows, width, x, scale, shift, y, mean, rsig, eps, mode);
     MI355_LAUNCH_CHECK("mi355_layernorm_fwd");

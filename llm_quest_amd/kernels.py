@@ -128,8 +128,21 @@ def _nt_tick(M, N, eligible=True, device=None):
     w.stats["persistent_eligible"] += 1
 
 
-def gemm(form, a, b, out=None, out_dtype=BF16, bias=None, residual=None, gelu=False, allow_split_k=True, tile=0):
-    """C = epi(op(A) op(B) + bias) + residual.  form NT: A[M,K] B[N,K]; NN: A[M,K] B[K,N]; TN: A[K,M] B[K,N]."""
+def gemm(form, a, b, out=None, out_dtype=BF16, bias=None, residual=None, gelu=False, allow_split_k=True, tile=0, split3_out=False):
+    """C = epi(op(A) op(B) + bias) + residual.  form NT: A[M,K] B[N,K]; NN: A[M,K] B[K,N]; TN: A[K,M] B[K,N].
+    ``split3_out`` (NT, no residual): the fp32 result leaves the epilogue as bf16 [M, 3N] = [hi | lo | hi] -- the activation operand of the next fp32-grade
+    product (``split3``) without the fp32 round trip through memory."""
+    if split3_out:
+        L.require_gpu(a, b, bias)
+        if form != L.GEMM_NT or residual is not None or out is not None or a.dtype != BF16 or b.dtype != BF16 or a.shape[1] != b.shape[1] or b.shape[0] % 8:
+            raise ValueError("gemm(split3_out): NT form on bf16 operands, N a multiple of 8, no residual, no preallocated output")
+        M, N, Kd = a.shape[0], b.shape[0], a.shape[1]
+        _rowmajor(a, "A")
+        _rowmajor(b, "B")
+        out3 = torch.empty((M, 3 * N), dtype=BF16, device=a.device)
+        L.call("mi355_gemm_bf16", form, M, N, Kd, L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), L.ptr(out3), out3.stride(0), L.DT_SPLIT3, L.ptr(bias), None, 0,
+               L.EPI_GELU if gelu else L.EPI_NONE, None, 0, tile)
+        return out3
     L.require_gpu(a, b, out, bias, residual)
     _rowmajor(a, "A")
     _rowmajor(b, "B")
@@ -704,12 +717,13 @@ def layernorm_fwd(x2d, scale, shift, out_dtype=BF16, eps=1e-5, want_stats=False,
     L.require_gpu(x2d, scale, shift)
     if x2d.dtype != F32 or not x2d.is_contiguous() or scale.dtype != F32 or shift.dtype != F32:
         raise ValueError("layernorm_fwd: x/scale/shift must be fp32, x contiguous")
-    y = torch.empty(x2d.shape, dtype=out_dtype, device=x2d.device)
+    split = isinstance(out_dtype, str) and out_dtype == "split3"  # bf16 [rows, 3 * width] = [hi | lo | hi] of the fp32 result (see ``split3``)
+    y = torch.empty((x2d.shape[0], 3 * x2d.shape[1]) if split else x2d.shape, dtype=BF16 if split else out_dtype, device=x2d.device)
     mean = rsig = None
     if want_stats:
         mean = torch.empty(x2d.shape[0], dtype=F32, device=x2d.device)
         rsig = torch.empty_like(mean)
-    L.call("mi355_layernorm_fwd", x2d.shape[0], x2d.shape[1], L.ptr(x2d), L.ptr(scale), L.ptr(shift), L.ptr(y), L.dt_code(out_dtype), L.ptr(mean), L.ptr(rsig), eps, mode)
+    L.call("mi355_layernorm_fwd", x2d.shape[0], x2d.shape[1], L.ptr(x2d), L.ptr(scale), L.ptr(shift), L.ptr(y), L.DT_SPLIT3 if split else L.dt_code(out_dtype), L.ptr(mean), L.ptr(rsig), eps, mode)
     return (y, mean, rsig) if want_stats else y
 
 

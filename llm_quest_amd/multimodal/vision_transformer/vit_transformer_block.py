@@ -135,11 +135,13 @@ class ViTTransformerBlock(nn.Module):
         if self.training and (self.dropout.p > 0 or self.att.dropout.p > 0):
             raise RuntimeError("ViTTransformerBlock.run_f32 is the frozen tower's inference path: call .eval() (dropout is active)")
         att, ffn = self.att, self.ffn
-        ctx = att.context_f32(K.split3(self.ln_1.normalize(x2d, F32)), B, S)
+        # (round 6: the LayerNorms and the GELU projection write their fp32 results as split operands themselves -- K.split3 of an fp32 tensor reads 4 and writes
+        # 6 bytes per element, 20 GB per step at the bench's batch; only the attention's context still takes the separate pass)
+        ctx = att.context_f32(self.ln_1.normalize(x2d, "split3"), B, S)
         x2 = K.gemm(L.GEMM_NT, K.split3(ctx), split3_cached(att, "wo3", [att.out_proj.weight]), bias=att.out_proj.bias.detach(), residual=x2d, out_dtype=F32)
-        h = K.split3(self.ln_2.normalize(x2, F32))
-        f = K.gemm(L.GEMM_NT, h, split3_cached(ffn, "w1_3", [ffn.layers[0].weight]), bias=ffn.layers[0].bias.detach(), gelu=True, out_dtype=F32)
-        return K.gemm(L.GEMM_NT, K.split3(f), split3_cached(ffn, "w2_3", [ffn.layers[2].weight]), bias=ffn.layers[2].bias.detach(), residual=x2, out_dtype=F32)
+        h = self.ln_2.normalize(x2, "split3")
+        f3 = K.gemm(L.GEMM_NT, h, split3_cached(ffn, "w1_3", [ffn.layers[0].weight]), bias=ffn.layers[0].bias.detach(), gelu=True, split3_out=True)
+        return K.gemm(L.GEMM_NT, f3, split3_cached(ffn, "w2_3", [ffn.layers[2].weight]), bias=ffn.layers[2].bias.detach(), residual=x2, out_dtype=F32)
 
     def forward(self, x):
         """(b, s, d) -> (b, s, d) in x.dtype; trains stand-alone (one autograd node over ``vit_train.block_forward`` / ``block_backward``,

@@ -64,6 +64,31 @@ def test_split_operand_gemm_is_fp32_grade(K, M, N, Kd, gelu):
     assert _rel(plain.cpu(), ref) > 20 * _rel(out.cpu(), ref)
 
 
+@pytest.mark.parametrize("rows,width", [(197 * 3 + 1, 768), (130, 64), (65, 3072)])
+def test_producers_write_the_split_operand_themselves_bit_for_bit(K, rows, width):
+    """Round 6: LayerNorm and the Linear (+ GELU) epilogue leave their fp32 result as [hi | lo | hi] directly (MI355_DT_SPLIT3): the same bits as the fp32 output
+    followed by mi355_split3_bf16, without the fp32 round trip."""
+    from llm_quest_amd import _lib as L
+
+    g = torch.Generator().manual_seed(rows + width)
+    x = (torch.randn(rows, width, generator=g) * 3 + 0.5).cuda()
+    sc, sh = (1 + 0.1 * torch.randn(width, generator=g)).cuda(), (0.1 * torch.randn(width, generator=g)).cuda()
+    for mode in (0, 1):
+        want = K.split3(K.layernorm_fwd(x, sc, sh, out_dtype=F32, mode=mode))
+        got = K.layernorm_fwd(x, sc, sh, out_dtype="split3", mode=mode)
+        assert got.shape == (rows, 3 * width) and torch.equal(got.view(torch.int16), want.view(torch.int16))
+    N = 136 if width == 64 else 256
+    a = K.split3(x)
+    w = K.split3((torch.randn(N, width, generator=g) / width**0.5).cuda(), weight_order=True)
+    bias = torch.randn(N, generator=g).cuda()
+    for gelu in (False, True):
+        want = K.split3(K.gemm(L.GEMM_NT, a, w, bias=bias, gelu=gelu, out_dtype=F32))
+        got = K.gemm(L.GEMM_NT, a, w, bias=bias, gelu=gelu, split3_out=True)
+        assert got.shape == (rows, 3 * N) and torch.equal(got.view(torch.int16), want.view(torch.int16)), (rows, width, gelu)
+    with pytest.raises(ValueError, match="split3_out"):
+        K.gemm(L.GEMM_NT, a, w, residual=torch.zeros(rows, N, device="cuda"), split3_out=True)
+
+
 @pytest.mark.parametrize("B,S,H", [(2, 5, 2), (3, 197, 12), (1, 256, 3), (2, 33, 1), (1, 128, 2), (1, 129, 2), (1, 257, 2), (1, 288, 1)])
 def test_attn_f32_against_fp64(K, B, S, H):
     """softmax(q k^T / sqrt(d)) v, every key visible (vit_attention.py:73-82), on row-strided views of a fused qkv matrix."""
