@@ -735,8 +735,11 @@ def main():
             from llm_quest_amd import kernels as K_
 
             pipe = K_.mfma_pipe_rate(2.0)
+            pipe16 = K_.mfma_pipe_rate(2.0, shape="16x16x32")
             line["roofline"]["power_capped_pipe"] = {
                 "rate": round(pipe, 1), "unit": "TFLOP/s", "achieved_over_rate": round(achieved / pipe, 4),
+                "rate_16x16x32": round(pipe16, 1), "achieved_over_rate_16x16x32": round(achieved / pipe16, 4),
+                "what_16x16x32": "the same on v_mfma_f32_16x16x32_bf16, the shape the GEMMs issue (32 products on a 128 x 64 wave tile's twelve fragments per repetition)",
                 "what": "v_mfma_f32_32x32x16_bf16 on every SIMD, random bf16 operands in registers, no memory traffic, measured on this board right after the timed steps: on random data the "
                         "board's power cap holds the pipe itself below the 2 500 TFLOP/s of `peak` (DESIGN.md section 5)"}
         if world == 1:

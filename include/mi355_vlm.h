@@ -452,7 +452,8 @@ int mi355_argmax_rows(int64_t rows, int64_t V, const void* logits, int64_t ld, i
 /* ---------------------------------------------------------------------------------------------------------------------
  * Measurement aid (csrc/probe.hip), no reference counterpart: `blocks` workgroups of four waves run reps x 16 v_mfma_f32_32x32x16_bf16 on random
  * bf16 operands held in registers (2 * 32*32*16 * 16 * reps * 4 * blocks FLOP, no memory traffic) -- the rate the board's power cap leaves the
- * matrix pipe, which bench.py reports beside the dense peak.  out: blocks * 256 floats (a checksum sink).
+ * matrix pipe, which bench.py reports beside the dense peak.  out: blocks * 256 floats (a checksum sink).  reps < 0: the shape the GEMMs issue instead,
+ * -reps x 32 v_mfma_f32_16x16x32_bf16 on a 128 x 64 wave tile's twelve fragments (2 * 16*16*32 * 32 * -reps * 4 * blocks FLOP).
  * ------------------------------------------------------------------------------------------------------------------- */
 int mi355_mfma_pipe_probe(int blocks, int reps, float* out, void* stream);
 

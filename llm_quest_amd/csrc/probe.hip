@@ -42,10 +42,39 @@ __global__ __launch_bounds__(256, 1) void mfma_pipe_kernel(float* __restrict__ o
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// The shape the GEMMs issue (gemm.hip: v_mfma_f32_16x16x32_bf16 on a 128 x 64 wave tile): one K step = 32 products on eight + four fragments, 32 independent
+// accumulators of four registers.  Round 5's attempt at this loop came out issue-bound as compiled (63 % of the slots: 64 accumulators, the fragments re-materialised);
+// here the twelve fragments stay pinned across the loop and a repetition is exactly 32 back-to-back MFMAs.
+__global__ __launch_bounds__(256, 1) void mfma_pipe16_kernel(float* __restrict__ out, int reps) {
+    u32x4 fr[12];
+    for (int j = 0; j < 12; ++j)
+        for (int e = 0; e < 4; ++e) fr[j][e] = rnd_pair((blockIdx.x * 256 + threadIdx.x) * 64 + j * 4 + e);
+    f32x4 acc[8][4];
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < reps; ++r) {
+        asm volatile("" : "+v"(fr[0]), "+v"(fr[1]), "+v"(fr[2]), "+v"(fr[3]), "+v"(fr[4]), "+v"(fr[5]), "+v"(fr[6]), "+v"(fr[7]), "+v"(fr[8]), "+v"(fr[9]), "+v"(fr[10]), "+v"(fr[11]));
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fr[8 + j]), "v"(fr[i]));  // in place (the intrinsic form compiles to an accumulator copy per product)
+    }
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 }  // namespace
 
 extern "C" int mi355_mfma_pipe_probe(int blocks, int reps, float* out, void* stream) {
-    MI355_REQUIRE(blocks > 0 && blocks <= 65535 && reps > 0 && out, "mfma_pipe_probe: blocks 1..65535, reps > 0, out = blocks * 256 floats");
+    MI355_REQUIRE(blocks > 0 && blocks <= 65535 && reps != 0 && out, "mfma_pipe_probe: blocks 1..65535, reps != 0, out = blocks * 256 floats");
+    if (reps < 0) {  // the 16x16x32 shape: -reps repetitions of 32 products
+        hipLaunchKernelGGL(mfma_pipe16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, -reps);
+        MI355_LAUNCH_CHECK("mfma_pipe_probe(16x16x32)");
+        return 0;
+    }
     hipLaunchKernelGGL(mfma_pipe_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, reps);
     MI355_LAUNCH_CHECK("mfma_pipe_probe");
     return 0;

@@ -1024,7 +1024,7 @@ def attn_generic_dropout_bwd(q, k, v, o, do, lse, B, S, Hq, Hkv, D, dq, dk, dv, 
            L.ptr(key_mask), scale, float(p), int(seed), int(offset))
 
 
-def mfma_pipe_rate(seconds=2.0, blocks=256):
+def mfma_pipe_rate(seconds=2.0, blocks=256, shape="32x32x16"):
     """TFLOP/s the matrix pipe alone sustains on this board (``mi355_mfma_pipe_probe``: random bf16 operands in registers, no memory traffic), timed with HIP events over the
     second half of ``seconds`` of back-to-back launches -- the board's power cap needs about a second to settle the clock.  A measurement aid for ``bench.py``."""
     import torch
@@ -1033,6 +1033,9 @@ def mfma_pipe_rate(seconds=2.0, blocks=256):
     L.require_gpu(out)
     reps = 8000  # ~ 1 ms a launch
     flop = 2.0 * 32 * 32 * 16 * 16 * reps * 4 * blocks
+    if shape == "16x16x32":  # the shape the GEMMs issue: 32 products per repetition (the entry point takes -reps for it)
+        flop = 2.0 * 16 * 16 * 32 * 32 * reps * 4 * blocks
+        reps = -reps
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 
     def run(n):
