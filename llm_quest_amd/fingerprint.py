@@ -14,7 +14,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-EVIDENCE_ROUND = "r05"  # profiles/<EVIDENCE_ROUND>_* are the counter files bench.py reads
+EVIDENCE_ROUND = "r06"  # profiles/<EVIDENCE_ROUND>_* are the counter files bench.py reads
 FILES = ("attention.hip", "attn_common.h", "elementwise.hip", "gemm.hip", "norm_rope.hip", "common.h")
 _FLAG_LINES = re.compile(r"^(CXXFLAGS|ARCH|FLAGS_(?:attention|elementwise|gemm|norm_rope))\s*\??=")
 

@@ -2,7 +2,7 @@
 # Turn the raw output of tools/collect_evidence.sh (merged back under gpurun_out/${ROUND}ev/) into the tracked files under profiles/.
 # Run from the repo root, in the container (no GPU needed).  Every output carries the collection's own stamp (gpurun_out/${ROUND}ev/stamp.json).
 set -e
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 E=${1:-gpurun_out/${ROUND}ev}
 for d in $E/*/; do n=$(ls $d*/ 2>/dev/null | sed 's/_.*//' | sort -u | wc -l); [ "$n" -le 1 ] || { echo "$d holds files of $n processes: stale collection mixed in"; exit 1; }; done
 B=$(python -c "import json;print(json.load(open('$E/stamp.json'))['per_gpu_batch'])"); M=$((B * 709))

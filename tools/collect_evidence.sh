@@ -2,7 +2,7 @@
 # Writes raw rocprofv3 output under gpurun_out/${ROUND}ev/ and a stamp (kernel-source fingerprint, sha-256 of the loaded library, git sha, batch)
 # taken HERE, at collection time; tools/aggregate_evidence.sh turns it into profiles/${ROUND}_* in the container and copies the stamp.
 set -e
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 cd /tmp && export TMPDIR=/tmp
 PART=${PART:-all}  # all | headline | configs  (a gpurun call is limited to 20 minutes: run the two halves as two calls; "configs" adds to the same directory)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${ROUND}ev; [ "$PART" = configs ] || rm -rf $O; mkdir -p $O  # (in the container: delete gpurun_out/${ROUND}ev before the call too -- gpurun MERGES what comes back into what is there)
