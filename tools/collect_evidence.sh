@@ -11,10 +11,10 @@ B=${BATCH:-160}; M=$((B * 709))
 if [ "$PART" != configs ]; then
 SQ1="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
 SQ2="SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --batch $B --steps 4 --warmup 2 --cpu-baseline off --pipe-probe off > $O/bench_trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --batch $B --steps 4 --warmup 2 --cpu-baseline off --pipe-probe off --fp32-tower-leg off --other-configs off > $O/bench_trace.log 2>&1
 echo trace done
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/step_fetch -- python3 $R/bench.py --batch $B --steps 1 --warmup 1 --cpu-baseline off --pipe-probe off > $O/step_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/step_write -- python3 $R/bench.py --batch $B --steps 1 --warmup 1 --cpu-baseline off --pipe-probe off > $O/step_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/step_fetch -- python3 $R/bench.py --batch $B --steps 1 --warmup 1 --cpu-baseline off --pipe-probe off --fp32-tower-leg off --other-configs off > $O/step_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/step_write -- python3 $R/bench.py --batch $B --steps 1 --warmup 1 --cpu-baseline off --pipe-probe off --fp32-tower-leg off --other-configs off > $O/step_write.log 2>&1
 echo step pmc done
 for spec in "NT $M 6144 1024 nt_gateup" "NT $M 1024 6144 nt_dgrad"; do
   set -- $spec
