@@ -972,6 +972,70 @@ def test_persistent_nt_kernel_equals_the_per_tile_kernel_bit_for_bit(M, N, K_, m
     assert torch.equal(gu0, gu2) and torch.equal(a0, a2)
 
 
+@pytest.mark.parametrize("M,N,K_", [(709 * 5 + 3, 1024, 2048), (2600, 4096, 512), (4099, 264, 384), (513, 776, 2048), (300, 256, 320), (2049, 1288, 640), (70000, 1536, 128)])
+def test_weight_stationary_walk_equals_the_per_tile_kernel_bit_for_bit(M, N, K_, monkeypatch):
+    """Round 6: the persistent NT kernel's weight-stationary XCD walk (tile hint 7 with ablation bit 3; the library's own choice by shape, MI355_GEMM_WALK) changes only
+    WHICH workgroup computes a tile and when: every epilogue gives the per-tile kernel's bits on ragged M, N that is no multiple of the tile or of a column group (empty
+    tiles are walked as zero work), fewer pairs than row streams, more tiles than CUs.  Then the same through the automatic choice with the walk forced on / off."""
+    from llm_quest_amd import _lib as L
+    from llm_quest_amd import kernels as K
+
+    W = 7 + (8 << 8)
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K_)
+    rnd = lambda *s: dev((0.3 * torch.randn(*s, generator=g)).to(BF16))
+    x, w, res = rnd(M, K_), rnd(N, K_), rnd(M, N)
+    ref = K.gemm(L.GEMM_NT, x, w, tile=2, allow_split_k=False)
+    got = torch.full_like(ref, 7.0)  # every element must be written
+    K.gemm(L.GEMM_NT, x, w, out=got, tile=W)
+    assert torch.equal(got, ref)
+    assert torch.equal(K.gemm(L.GEMM_NT, x, w, residual=res, tile=W), K.gemm(L.GEMM_NT, x, w, residual=res, tile=2, allow_split_k=False))
+    F = (N // 64) * 32
+    wgu = rnd(2 * F, K_)
+    gu2, a2 = K.gemm_gateup_swiglu(x, wgu, tile=2)
+    guw, aw = K.gemm_gateup_swiglu(x, wgu, tile=W)
+    assert torch.equal(guw, gu2) and torch.equal(aw, a2)
+    dy, w2, gu = rnd(M, K_), rnd(K_, N), rnd(M, 2 * N)
+    assert torch.equal(K.gemm_dgrad_swiglu_bwd(dy, w2, gu, tile=W), K.gemm_dgrad_swiglu_bwd(dy, w2, gu, tile=2))
+    monkeypatch.setenv("MI355_GEMM_PERSIST_MIN_TILES", "1")
+    for mode in ("1", "0", "2"):
+        monkeypatch.setenv("MI355_GEMM_WALK", mode)
+        assert torch.equal(K.gemm(L.GEMM_NT, x, w, allow_split_k=False), ref), mode
+
+
+@pytest.mark.parametrize("M,N,K_", [(709 * 5 + 3, 1024, 1024), (4099, 264, 384), (513, 776, 2048), (300, 256, 320), (5000, 3072, 1024)])
+def test_ping_pong_nt_kernel_is_exact_on_exact_products_and_within_fp32_noise_otherwise(M, N, K_):
+    """Round 6, tile hint 8 (gemm_nt_pp_kernel; opt-in, not the library's choice): the two wave groups run a write-out apart on one stream, so a tile's K-tiles are summed in a
+    ROTATED order.  On small-integer operands every product and partial sum is exact: the same bits as tile 2 for every epilogue.  On random operands the fp32 sums differ
+    in their last bits: a bf16 output may move by one unit in the last place where a sum sits on a rounding boundary (< 0.1 % of the elements), never more."""
+    from llm_quest_amd import _lib as L
+    from llm_quest_amd import kernels as K
+
+    g = torch.Generator().manual_seed(M + N + K_)
+    ints = lambda *s: dev(torch.randint(-2, 3, s, generator=g).float().to(BF16))
+    rnd = lambda *s: dev((0.3 * torch.randn(*s, generator=g)).to(BF16))
+
+    def close(a, b, slack=1.01):
+        af, bf = a.float(), b.float()
+        d = (af - bf).abs()
+        unit = torch.maximum(bf.abs() * 2.0**-7, 1e-4 * bf.pow(2).mean().sqrt())
+        return float((d / unit).max()) <= slack and float((d > 0).float().mean()) < 1e-3
+
+    for mk, same in ((ints, torch.equal), (rnd, close)):
+        x, w, res = mk(M, K_), mk(N, K_), mk(M, N)
+        got = torch.full((M, N), 7.0, dtype=BF16, device="cuda")
+        K.gemm(L.GEMM_NT, x, w, out=got, tile=8)
+        assert same(got, K.gemm(L.GEMM_NT, x, w, tile=2, allow_split_k=False))
+        assert same(K.gemm(L.GEMM_NT, x, w, residual=res, tile=8), K.gemm(L.GEMM_NT, x, w, residual=res, tile=2, allow_split_k=False))
+        F = (N // 64) * 32
+        wgu = mk(2 * F, K_)
+        gu8, a8 = K.gemm_gateup_swiglu(x, wgu, tile=8)
+        gu2, a2 = K.gemm_gateup_swiglu(x, wgu, tile=2)
+        assert same(gu8, gu2) and (torch.equal(a8, a2) if mk is ints else close(a8, a2, slack=8.0))  # (a moved gate-up bit moves the activation's last bits too)
+        dy, w2, gu = mk(M, K_), mk(K_, N), rnd(M, 2 * N)
+        b8, b2 = K.gemm_dgrad_swiglu_bwd(dy, w2, gu, tile=8), K.gemm_dgrad_swiglu_bwd(dy, w2, gu, tile=2)
+        assert torch.equal(b8, b2) if mk is ints else close(b8, b2, slack=8.0)
+
+
 @pytest.mark.parametrize("tanh", [False, True])
 def test_gemm_gelu_epilogues_equal_two_kernels_bit_for_bit(tanh):
     """Linear -> GELU (pre-activation + activation from one launch) and the GELU backward in the next Linear's dgrad epilogue == the
