@@ -196,10 +196,13 @@ class GradSync:
             return
         from . import kernels as K
 
-        n = K._WINDOW.stats["windows"] % 8
-        while len(self._group_events) <= n:
-            self._group_events.append(torch.cuda.Event(enable_timing=True))
-        done = self._group_events[n]
+        if start is not None and self.window_auto:
+            done = torch.cuda.Event(enable_timing=True)  # read back a step or two later (_retune_window): an event of its own, not one of the reused ones
+        else:
+            n = K._WINDOW.stats["windows"] % 8
+            while len(self._group_events) <= n:
+                self._group_events.append(torch.cuda.Event())
+            done = self._group_events[n]
         done.record(self.comm_stream)
         stream = torch.cuda.current_stream(device)  # the compute stream, captured now: the window's end acts on IT, whichever stream issues the closing launch
         rec = None
@@ -210,7 +213,7 @@ class GradSync:
             self._timings.append(rec)
 
         def on_close():
-            if rec is not None:
+            if rec is not None and not K._WINDOW.closed_early:  # (a window cut short by finish_step says nothing about what a launch takes)
                 rec[3].record(stream)
                 rec[5] = True
             if self.window_wait:
@@ -243,7 +246,7 @@ class GradSync:
                 continue
             ar.append(start.elapsed_time(done))
             per.append(opened.elapsed_time(closed) / max(launches, 1))
-        self._timings = keep[-16:]
+        self._timings = keep[-32:]  # (the host runs about a step ahead of the device: a step's windows are usually read at the begin_step after next)
         if ar and per:
             per.sort()
             self.window_launches = self.window_for(max(ar), per[len(per) // 2])

@@ -72,7 +72,7 @@ class _GemmWindow:
     count against it nor close it."""
 
     def __init__(self):
-        self.left, self.on_close, self.stream = 0, None, None
+        self.left, self.on_close, self.stream, self.closed_early = 0, None, None, False
         self.stats = {"persistent_eligible": 0, "inside_window": 0, "windows": 0}
 
 
@@ -101,6 +101,7 @@ def close_gemm_window():
     w = _WINDOW
     if w.left == 0 and w.on_close is None:
         return
+    w.closed_early = w.left > 0  # ended by finish_step before its launches ran out (the hand-off callbacks may ask)
     cb, w.left, w.on_close, w.stream = w.on_close, 0, None, None
     if cb is not None:
         cb()
