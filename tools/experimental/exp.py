@@ -21,9 +21,6 @@ def load():
         L.load()
         lib = ctypes.CDLL(os.path.join(_HERE, "libmi355exp.so"))
         lib.mi355_exp_attn_fwd2.argtypes = [_I, _I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _I, _F, _P]
-        lib.mi355_gated_delta_rule_chunked_workspace_bytes.argtypes = [_I, _I, _I]
-        lib.mi355_gated_delta_rule_chunked_workspace_bytes.restype = _L
-        lib.mi355_gated_delta_rule_chunked_fwd.argtypes = [_I, _I, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _L, _P]
         _lib = lib
     return _lib
 
@@ -43,14 +40,3 @@ def attn_fwd2(q, k, v, B, S, Hq, Hkv, D, key_mask=None, causal=True):
     return o, lse
 
 
-def gated_delta_rule_chunked_fwd(q, k, v, beta, alpha, B, S, Hqk, Hv, Dk, Dv, want_state=False, state=None):
-    """Chunked (WY / UT-transform) forward on fp32-input MFMA: returns (o bf16 [B*S, Hv*Dv], final_state or None); ``state`` is updated in place."""
-    o = torch.empty((B * S, Hv * Dv), dtype=torch.bfloat16, device=q.device)
-    fin = state if state is not None else (torch.empty((B, Hv, Dv, Dk), dtype=torch.float32, device=q.device) if want_state else None)
-    lib = load()
-    need = lib.mi355_gated_delta_rule_chunked_workspace_bytes(B, S, Hv)
-    ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=q.device)
-    rc = lib.mi355_gated_delta_rule_chunked_fwd(B, S, Hqk, Hv, Dk, Dv, L.ptr(q), L.ptr(k), L.ptr(v), v.stride(0), L.ptr(beta), L.ptr(alpha), L.ptr(o), L.ptr(state), L.ptr(fin),
-                                                L.ptr(ws), need, L.stream(q.device))
-    _check(rc, "mi355_gated_delta_rule_chunked_fwd")
-    return o, fin

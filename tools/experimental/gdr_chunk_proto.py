@@ -1,6 +1,7 @@
 """Chunked (WY / UT-transform) form of the gated delta rule, forward and hand-written backward, in plain torch fp64 -- the algorithm
-the HIP kernels in csrc/gdr_chunk.hip implement, checked here against the sequential recurrence the reference runs
-(qwen3_next_attention.py:103-159) and its autograd gradients.  CPU only, no package import:  python tools/gdr_chunk_proto.py
+a chunked kernel pair would implement (round 3 built the forward on fp32 MFMA: 409 us against the sequential kernel's 363 at B = 8 -- it left the tree in round 6;
+on split-bf16 operands its products would cost a fifth), checked here against the sequential recurrence the reference runs
+(qwen3_next_attention.py:103-159) and its autograd gradients.  CPU only, no package import:  python tools/experimental/gdr_chunk_proto.py
 
 Per (batch row, value head), chunk of C tokens with incoming state S0 [Dv, Dk] (rows of K, Q, V are tokens):
     g = cumsum(log alpha), gam = exp(g), D[i, j] = exp(g_i - g_j) (i >= j), Gp_j = exp(g_C - g_j)
