@@ -594,9 +594,15 @@ def main():
 
     tower_at = os.environ.get("MI355_BENCH_TOWER_AT", "start")  # A/B: where in the step the next batch's tower forward is submitted to the side stream
 
+    cached_hidden = []
+
     def vision():
         if ahead is None:
             return None
+        if tower_at == "never":  # TIMING ABLATION ONLY: the tower's forward runs once, outside the timed steps -- what the tower costs the step is the difference
+            if not cached_hidden:
+                cached_hidden.append(ahead.take(img))
+            return cached_hidden[0]
         h = ahead.take(img)
         if tower_at == "start":
             ahead.submit(img)

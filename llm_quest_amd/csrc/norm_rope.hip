@@ -453,6 +453,64 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(int64_t rows, int wi
     }
 }
 
+// The same with the row held in registers (width = 256 NV: 768 and 1024): ONE read of x instead of three passes over it.  Same per-lane accumulation order and the
+// same cross-lane sums as layernorm_fwd_kernel, so the same bits.
+template <int OUT_DT, int NV>
+__global__ __launch_bounds__(256) void layernorm_fwd_rowreg_kernel(int64_t rows, const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                   void* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rsig_out, float eps, int mode) {
+    constexpr int width = 256 * NV;
+    const int lane = threadIdx.x & 63;
+    f32x4 sc[NV], sh[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        sc[j] = *reinterpret_cast<const f32x4*>(scale + (lane + 64 * j) * 4);
+        sh[j] = *reinterpret_cast<const f32x4*>(shift + (lane + 64 * j) * 4);
+    }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+        const float* xr = x + row * width;
+        f32x4 v[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const f32x4*>(xr + (lane + 64 * j) * 4);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
+        const float mu = wave_sum(s) / (float)width;
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ss += (v[j][e] - mu) * (v[j][e] - mu);
+        const float var = wave_sum(ss) / (float)width;
+        const float inv = mode == 0 ? 1.0f / (sqrtf(var) + eps) : rsqrtf(var + eps);
+        if (lane == 0) {
+            if (mean_out) mean_out[row] = mu;
+            if (rsig_out) rsig_out[row] = inv;
+        }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = lane + 64 * j;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = sc[j][e] * ((v[j][e] - mu) * inv) + sh[j][e];
+            if constexpr (OUT_DT == MI355_DT_BF16) {
+                u32x2 pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+                *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(y) + row * width + i * 4) = pk;
+            } else if constexpr (OUT_DT == MI355_DT_SPLIT3) {
+                float lo[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) lo[e] = o[e] - bf2f(f2bf(o[e]));
+                const u32x2 hi = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])}, lw = {pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3])};
+                bf16_t* d = reinterpret_cast<bf16_t*>(y) + row * 3 * (int64_t)width + i * 4;
+                *reinterpret_cast<u32x2*>(d) = hi;
+                *reinterpret_cast<u32x2*>(d + width) = lw;
+                *reinterpret_cast<u32x2*>(d + 2 * width) = hi;
+            } else {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(y) + row * width + i * 4) = (f32x4){o[0], o[1], o[2], o[3]};
+            }
+        }
+    }
+}
+
 // backward of y = scale*n + shift, n = (x-mean)*rsig, rsig = 1/(sigma+eps):
 //   dn = dy*scale;  dx = rsig * (dn - mean(dn) - n * mean(dn*n) * (1/rsig)/(1/rsig - eps)) (+ dres)
 //   dscale = sum_rows dy*n, dshift = sum_rows dy   (per-block partials [parts][2*width], LDS-merged)
@@ -650,6 +708,20 @@ extern "C" int mi355_layernorm_fwd(int64_t rows, int width, const float* x, cons
     MI355_REQUIRE(x && scale && shift && y, "mi355_layernorm_fwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const int grid = row_grid(rows);
+    const bool al16 = (((uintptr_t)x | (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)y) & 15) == 0;
+    if ((width == 768 || width == 1024) && al16) {  // the row in registers: one read of x
+#define LN_ROWREG(DT)                                                                                                                                         \
+    do {                                                                                                                                                      \
+        if (width == 768) hipLaunchKernelGGL((layernorm_fwd_rowreg_kernel<DT, 3>), dim3(grid), dim3(256), 0, s, rows, x, scale, shift, y, mean, rsig, eps, mode); \
+        else hipLaunchKernelGGL((layernorm_fwd_rowreg_kernel<DT, 4>), dim3(grid), dim3(256), 0, s, rows, x, scale, shift, y, mean, rsig, eps, mode);              \
+    } while (0)
+        if (y_dtype == MI355_DT_BF16) LN_ROWREG(MI355_DT_BF16);
+        else if (y_dtype == MI355_DT_SPLIT3) LN_ROWREG(MI355_DT_SPLIT3);
+        else LN_ROWREG(MI355_DT_F32);
+#undef LN_ROWREG
+        MI355_LAUNCH_CHECK("mi355_layernorm_fwd");
+        return 0;
+    }
     if (y_dtype == MI355_DT_BF16)
         hipLaunchKernelGGL(layernorm_fwd_kernel<MI355_DT_BF16>, dim3(grid), dim3(256), 0, s, rows, width, x, scale, shift, y, mean, rsig, eps, mode);
     else if (y_dtype == MI355_DT_SPLIT3)

@@ -10,6 +10,13 @@ from llm_quest_amd.multimodal.vision_transformer.vit_attention import ViTMultiHe
 BF16, F32 = torch.bfloat16, torch.float32
 
 
+import os as _os
+
+# tile of the block's two d-wide projections (out_proj, FFN down: N = emb_dim).  At the frozen tower's 31 520 rows they are 372 tiles of 256 x 256 = 1.45 rounds of the
+# chip; 0 = the library's choice (A/B knob, see profiles/r06_notes.md)
+_TILE_SMALL_N = int(_os.environ.get("MI355_VIT_TILE_SMALLN", "0"))
+
+
 class LayerNorm(nn.Module):
     """scale * (x - mean) / (population_std + eps) + shift, eps = 1e-5 added to sigma (reference: :12-31)."""
 
@@ -120,13 +127,13 @@ class ViTTransformerBlock(nn.Module):
 
             x2 = K.dropout(K.gemm(L.GEMM_NT, ctx, wo, bias=self.att.out_proj.bias.detach(), out_dtype=F32), p, *rng.draw(), residual=x2d)
         else:
-            x2 = K.gemm(L.GEMM_NT, ctx, wo, bias=self.att.out_proj.bias.detach(), residual=x2d, out_dtype=F32)
+            x2 = K.gemm(L.GEMM_NT, ctx, wo, bias=self.att.out_proj.bias.detach(), residual=x2d, out_dtype=F32, tile=_TILE_SMALL_N)
         h = self.ln_2.normalize(x2, BF16)
         f = self.ffn.hidden(h)
         w2 = bf16_cached(self.ffn, "w2", [self.ffn.layers[2].weight])
         if p > 0:
             return K.dropout(K.gemm(L.GEMM_NT, f, w2, bias=self.ffn.layers[2].bias.detach(), out_dtype=F32), p, *rng.draw(), residual=x2)
-        return K.gemm(L.GEMM_NT, f, w2, bias=self.ffn.layers[2].bias.detach(), residual=x2, out_dtype=F32)
+        return K.gemm(L.GEMM_NT, f, w2, bias=self.ffn.layers[2].bias.detach(), residual=x2, out_dtype=F32, tile=_TILE_SMALL_N)
 
     def run_f32(self, x2d, B, S):
         """x2d fp32 [B*S, d] -> fp32 [B*S, d] at the reference's fp32 precision (inference only: the frozen tower of the early-fusion step,
