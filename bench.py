@@ -718,6 +718,7 @@ def main():
                 "units_per_sample": UNITS_PER_SAMPLE,
                 "vision_tower": "frozen ViT forward of the NEXT step's batch on a second HIP stream, one per timed step (vlm_engine.VisionAhead)" if ahead is not None else "in front of the decoder, same stream",
                 "vision_tower_precision": tower + (" (the reference's: fp32-grade split-bf16 GEMMs + exact-fp32 attention)" if tower == "fp32" else " MFMA operands, fp32 residual stream"),
+                **({"ABLATION": f"MI355_BENCH_TOWER_AT={tower_at}: not the workload (the tower's forward is submitted elsewhere or left out of the timed steps)"} if tower_at != "start" else {}),
             },
             "roofline": {
                 "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

@@ -28,7 +28,6 @@ _TILE_BY_FORM = {f: int(os.environ.get("MI355_GEMM_TILE_" + n, "0")) for f, n in
 _TILE_SWIGLU_FWD = int(os.environ.get("MI355_GEMM_TILE_SWIGLU_FWD", "0"))  # profiling knobs: tile of the two fused SwiGLU GEMMs
 _TILE_SWIGLU_BWD = int(os.environ.get("MI355_GEMM_TILE_SWIGLU_BWD", "0"))
 _TILE_NT_PLAIN = int(os.environ.get("MI355_GEMM_TILE_NT_PLAIN", "0"))  # profiling knob: tile of NT launches with the plain epilogue only (the fused forms keep theirs)
-_WGRAD_KFRAC = float(os.environ.get("MI355_ABLATE_WGRAD_KFRAC", "0"))  # timing ablation (see gemm_grouped)
 DGRAD_NT = os.environ.get("MI355_DGRAD_NT", "1") != "0"  # 0: dgrad GEMMs in the NN form on the weight as stored (A/B measurements)
 DGRAD_NT_MIN_ROWS = 4096  # below this the transpose pass is not paid back
 _WS = {}
@@ -214,8 +213,6 @@ def gemm_grouped(form, problems, tile=0):
         if Kd != K2 or tuple(out.shape) != (M, N) or out.dtype != odt:
             raise ValueError(f"gemm_grouped: inconsistent problem {tuple(a.shape)} x {tuple(b.shape)} -> {tuple(out.shape)} {out.dtype}")
         q.M, q.N, q.K = M, N, Kd
-        if _WGRAD_KFRAC and form == L.GEMM_TN:  # TIMING ABLATION ONLY (wrong sums): what a weight-gradient launch balanced over all 256 CUs would take
-            q.K = int(Kd * _WGRAD_KFRAC) // 64 * 64
         q.A, q.lda, q.B, q.ldb, q.C, q.ldc = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0)
         q.residual, q.ldr = None, 0
         if residual is not None:
