@@ -302,8 +302,10 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(int64_t tokens, in
 }
 
 // backward of the same: dn = RoPE^T dy (fp32), then RMSNorm backward per head; dw partials per block.
-template <int D>
-__global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(int64_t tokens, int Hq, int Hkv, const bf16_t* __restrict__ qkv,
+// KONLY: the key heads only (dq == NULL: the training step, where the query heads' share is the write-out of the attention backward's dQ pass) -- no query-side weights,
+// sums or selects: 196 -> fewer registers, a third wave per SIMD for a kernel that waits on its per-token loads
+template <int D, bool KONLY>
+__global__ __launch_bounds__(256, KONLY ? 3 : 2) void qknorm_rope_bwd_kernel(int64_t tokens, int Hq, int Hkv, const bf16_t* __restrict__ qkv,
                                                               const bf16_t* __restrict__ qw, const bf16_t* __restrict__ kw,
                                                               const float* __restrict__ cosT, const float* __restrict__ sinT,
                                                               const int32_t* __restrict__ pos, const float* __restrict__ rstd,
@@ -314,15 +316,17 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(int64_t tokens, in
     const int lane = threadIdx.x & 63;
     const int sub = lane / G::LPH, i = (lane % G::LPH) * QV;
     const int H = Hq + Hkv;
-    const int h0 = dq ? 0 : Hq;  // dq == NULL: the key heads only (the query heads' share ran as the write-out of the attention backward's dQ pass)
+    const int h0 = KONLY ? Hq : (dq ? 0 : Hq);  // dq == NULL: the key heads only (the query heads' share ran as the write-out of the attention backward's dQ pass)
     const int groups = (H - h0 + G::HPW - 1) / G::HPW;
     const int64_t ld = (int64_t)(Hq + 2 * Hkv) * D;
     float dwq1[QV] = {0, 0, 0, 0, 0, 0, 0, 0}, dwq2[QV] = {0, 0, 0, 0, 0, 0, 0, 0}, dwk1[QV] = {0, 0, 0, 0, 0, 0, 0, 0}, dwk2[QV] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool norm = qw != nullptr;
     float wq1[QV] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, wq2[QV] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, wk1[QV] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, wk2[QV] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
     if (norm) {
-        unpack8(*reinterpret_cast<const u32x4*>(qw + i), wq1);
-        unpack8(*reinterpret_cast<const u32x4*>(qw + G::HALF + i), wq2);
+        if constexpr (!KONLY) {
+            unpack8(*reinterpret_cast<const u32x4*>(qw + i), wq1);
+            unpack8(*reinterpret_cast<const u32x4*>(qw + G::HALF + i), wq2);
+        }
         unpack8(*reinterpret_cast<const u32x4*>(kw + i), wk1);
         unpack8(*reinterpret_cast<const u32x4*>(kw + G::HALF + i), wk2);
     }
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(int64_t tokens, in
             const int h = h0 + grp * G::HPW + sub;
             const bool valid = h < H;
             const int hh = valid ? h : h0;
-            const bool isq = hh < Hq;
+            const bool isq = !KONLY && hh < Hq;
             const bf16_t* src = qkv + t * ld + (int64_t)hh * D;
             const bf16_t* g = isq ? dq + t * (int64_t)Hq * D + (int64_t)hh * D : dk + t * (int64_t)Hkv * D + (int64_t)(hh - Hq) * D;
             float x1[QV] = {0, 0, 0, 0, 0, 0, 0, 0}, x2[QV] = {0, 0, 0, 0, 0, 0, 0, 0}, g1[QV], g2[QV];
@@ -694,10 +698,13 @@ extern "C" int mi355_qknorm_rope_bwd(int64_t tokens, int Hq, int Hkv, int D, con
     MI355_REQUIRE(tokens > 0 && parts > 0 && qkv && cos && sin && pos && dk && dqkv && dw_partial, "mi355_qknorm_rope_bwd: bad arguments");  // dq may be NULL: key heads only
     MI355_REQUIRE((qw == nullptr) == (kw == nullptr) && (qw == nullptr || rstd != nullptr), "mi355_qknorm_rope_bwd: pass both norm weights (and rstd) or neither (RoPE only)");
     hipStream_t s = (hipStream_t)stream;
-    if (D == 128)
-        hipLaunchKernelGGL(qknorm_rope_bwd_kernel<128>, dim3(parts), dim3(256), 0, s, tokens, Hq, Hkv, (const bf16_t*)qkv, (const bf16_t*)qw, (const bf16_t*)kw, cos, sin, pos, rstd, (const bf16_t*)dq, (const bf16_t*)dk, (bf16_t*)dqkv, dw_partial);
-    else
-        hipLaunchKernelGGL(qknorm_rope_bwd_kernel<64>, dim3(parts), dim3(256), 0, s, tokens, Hq, Hkv, (const bf16_t*)qkv, (const bf16_t*)qw, (const bf16_t*)kw, cos, sin, pos, rstd, (const bf16_t*)dq, (const bf16_t*)dk, (bf16_t*)dqkv, dw_partial);
+#define QKB(DD, KO) hipLaunchKernelGGL((qknorm_rope_bwd_kernel<DD, KO>), dim3(parts), dim3(256), 0, s, tokens, Hq, Hkv, (const bf16_t*)qkv, (const bf16_t*)qw, (const bf16_t*)kw, cos, sin, pos, rstd, (const bf16_t*)dq, (const bf16_t*)dk, (bf16_t*)dqkv, dw_partial)
+    if (D == 128) {
+        if (dq) QKB(128, false); else QKB(128, true);
+    } else {
+        if (dq) QKB(64, false); else QKB(64, true);
+    }
+#undef QKB
     MI355_LAUNCH_CHECK("mi355_qknorm_rope_bwd");
     return 0;
 }
