@@ -12,7 +12,7 @@ import torch
 from . import _lib as L
 
 BF16, F32 = torch.bfloat16, torch.float32
-NORM_PARTS = 512  # max blocks (= partial rows) of the norm backward kernels
+NORM_PARTS = int(os.environ.get("MI355_NORM_PARTS", "512"))  # max blocks (= partial rows) of the norm backward kernels
 QK_PARTS = int(os.environ.get("MI355_QK_PARTS", "768"))  # ... of the QK-norm + RoPE backward (a wave walks one token at a time: more blocks = more rows in flight)
 
 
